@@ -1,0 +1,115 @@
+"""Pins of the CPU oracle against reference-run numbers recorded in SURVEY.md 6 / 8c and BASELINE.md 2
+(the reference itself cannot be built in this image: it needs netCDF-Fortran) and against the canonical
+MT19937 known answers.  CPU only."""
+import numpy as np
+
+from tests import cases
+
+f32 = np.float32
+
+
+def test_mt19937_scalar_seed_kat(oracle):
+    # seed=100 -> canonical genrand_real1 stream
+    r = oracle.RandomNumberSequence(100).reals(5)
+    want = [0.543404937, 0.671155632, 0.278369397, 0.412046403, 0.424517602]
+    assert np.allclose(r, want, rtol=0, atol=5e-10 + 6e-8)
+    assert [f"{v:.7f}" for v in r] == [f"{v:.7f}" for v in np.float32(want)]
+
+
+def test_mt19937_vector_seed_kat(oracle):
+    # seed=(/10,1/)
+    g = oracle.RandomNumberSequence([10, 1])
+    assert [g.int32() for _ in range(5)] == [168774779, 197189863, 1009846582, -287080014, -590412790]
+    r = oracle.RandomNumberSequence([10, 1]).reals(5)
+    want = np.float32([0.039295942, 0.045911841, 0.235123232, 0.933158994, 0.862533808])
+    assert np.array_equal(r, want)
+
+
+def test_random_real_is_unsigned_over_2p32m1(oracle):
+    g = oracle.RandomNumberSequence([10, 1])
+    h = oracle.RandomNumberSequence([10, 1])
+    for _ in range(1000):
+        i = g.int32() & 0xFFFFFFFF
+        assert h.real() == float(f32(np.float64(i) / np.float64(4294967295.0)))
+
+
+def test_inverse_table_hg_64_moments(oracle):
+    # SURVEY.md 8c(2)
+    t = oracle.inverse_table_legendre(cases.hg_coefficients(0.85, 64), 10001)
+    want = {1: 3.141593, 2: 3.045351, 2501: 0.497639, 5001: 0.252000, 7501: 0.134744, 10000: 0.002211, 10001: 0.0}
+    for k, v in want.items():
+        assert f"{t[k - 1]:.6f}" == f"{v:.6f}", (k, t[k - 1], v)
+    assert abs(np.cos(t.astype(np.float64)).mean() - 0.851692) < 2e-6
+    assert np.all(np.diff(t) <= 0)
+
+
+def test_forward_table_hg_64_moments(oracle):
+    # P(0)=82.1977, P(1)=0.385320, P(2)=0.0731810, P(pi)=0.0456438
+    n = 10001
+    t = oracle.forward_table_legendre(cases.hg_coefficients(0.85, 64), n)
+    d = np.pi / (n - 1)
+
+    def at(a):
+        k = int(a / d)
+        w = 1 - (a - k * d) / d
+        return w * t[k] + (1 - w) * t[min(k + 1, n - 1)]
+
+    assert f"{t[0]:.4f}" == "82.1977"
+    assert abs(at(0.1) - 50.8531) < 2e-3
+    assert f"{at(1.0):.6f}" == "0.385320"
+    assert abs(at(2.0) - 0.0731810) < 2e-7
+    assert f"{t[-1]:.7f}" == "0.0456438"
+
+
+def test_plane_parallel_shipped_namelist(oracle):
+    # Example-Drivers/planeParallel.nml as shipped: tau=1, g=.85 (64 moments), omega=1, mu0=.5, 4 x 1e4
+    # photons, seeds (/batch, iseed=10/), default 9001-entry inverse table.
+    # Reference output recorded in SURVEY.md 6 / 8c: Fup 0.16420, Fdown 0.83580, std dev 0.00363.
+    d = cases.plane_parallel()
+    inv = oracle.inverse_table_legendre(cases.hg_coefficients(0.85, 64), 9001)
+    integ = oracle.Integrator(d["xe"], d["ye"], d["ze"], d["ext"], d["ssa"], d["pf"], [inv])
+    fu, fd = [], []
+    for b in range(1, 5):
+        rng = oracle.RandomNumberSequence([b, 10])
+        ph = oracle.photons_directional(rng, 0.5, 0.0, 10000)
+        r = integ.compute(rng, *ph)
+        fu.append(r["fluxUp"][0, 0])
+        fd.append(r["fluxDown"][0, 0])
+    fu, fd = np.float32(fu), np.float32(fd)
+    mu, md = fu.sum(dtype=np.float32) / f32(4), fd.sum(dtype=np.float32) / f32(4)
+    sd = np.sqrt(((fu - mu) ** 2).sum() / 3)
+    assert f"{mu:.5f}" == "0.16420"
+    assert f"{md:.5f}" == "0.83580"
+    assert f"{sd:.5f}" == "0.00363"
+
+
+def test_step_cloud_work_counters_and_fluxes(oracle):
+    # step cloud 32x1x32, mu0=1, omega=1, 1e6 photons (10 x 1e5, seeds (/10,b/)):
+    # Fup 0.3254, Fdn 0.6746; 18.0 tracer calls / 63.0 cell steps / 17.0 scatterings per photon;
+    # dropped fraction 3.1e-5; 99 draws per photon.   Here: 2 batches (fast) for the counters.
+    d = cases.step_cloud()
+    inv = oracle.inverse_table_legendre(cases.hg_coefficients(0.85, 64), 10001)
+    integ = oracle.Integrator(d["xe"], d["ye"], d["ze"], d["ext"], d["ssa"], d["pf"], [inv])
+    tot = {}
+    fu, fd = [], []
+    nb = 4
+    for b in range(1, nb + 1):
+        rng = oracle.RandomNumberSequence([10, b])
+        ph = oracle.photons_directional(rng, 1.0, 0.0, 100000)
+        r = integ.compute(rng, *ph)
+        fu.append(r["fluxUp"].mean())
+        fd.append(r["fluxDown"].mean())
+        for k in ("nPhotons", "nBad", "tracerCalls", "cellSteps", "scatterings"):
+            tot[k] = tot.get(k, 0) + r[k]
+        tot["draws"] = tot.get("draws", 0) + rng.draws
+    n = tot["nPhotons"]
+    assert n == nb * 100000
+    assert abs(tot["tracerCalls"] / n - 18.0) < 0.1
+    assert abs(tot["cellSteps"] / n - 63.0) < 0.2
+    assert abs(tot["scatterings"] / n - 17.0) < 0.1
+    assert abs(tot["draws"] / n - 99) < 1
+    assert 0 < tot["nBad"] / n < 1e-4
+    assert abs(np.mean(fu) - 0.3254) < 3 * 4.7e-4 * np.sqrt(10 / nb)
+    assert abs(np.mean(fd) - 0.6746) < 3 * 4.7e-4 * np.sqrt(10 / nb)
+    # energy closure with the dropped-photon deficit (quirk Q4)
+    assert abs((np.mean(fu) + np.mean(fd)) - (1 - tot["nBad"] / n)) < 2e-6
