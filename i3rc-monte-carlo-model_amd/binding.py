@@ -1,0 +1,109 @@
+"""ctypes binding of the C ABI declared in include/i3rc_hip.h.
+
+There is no CPU fallback: if the HIP library is missing or no GPU is present, calls fail loudly."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+fp = C.POINTER(C.c_float)
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int32)
+lp = C.POINTER(C.c_int64)
+up = C.POINTER(C.c_uint32)
+
+MAX_COMPONENTS = 8
+MAX_DIRECTIONS = 20
+NUM_COUNTERS = 16
+COUNTER_NAMES = ["photons", "dropped", "cellSteps", "scatterings", "surfaceHits", "exitsTop", "roulette",
+                 "shadowSteps", "tracerCalls", "rngDraws"]
+
+# every symbol include/i3rc_hip.h declares (checked by tests/test_cabi_symbols.py)
+SYMBOLS = [
+    "i3rc_hip_create", "i3rc_hip_destroy", "i3rc_hip_last_error", "i3rc_hip_set_inverse_table",
+    "i3rc_hip_set_forward_tables", "i3rc_hip_set_params", "i3rc_hip_set_surface", "i3rc_hip_set_directions",
+    "i3rc_hip_get_tally_layout", "i3rc_hip_bind_tally_buffer", "i3rc_hip_set_stream", "i3rc_hip_zero_tallies",
+    "i3rc_hip_launch_batch", "i3rc_hip_run_replay", "i3rc_hip_trace_rays", "i3rc_hip_synchronize",
+    "i3rc_hip_fetch_tallies", "i3rc_hip_normalise", "i3rc_hip_last_kernel_ms", "i3rc_hip_set_tuning",
+    "i3rc_hip_philox_blocks", "i3rc_hip_device_count", "i3rc_hip_version",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("surfaceAlbedo", C.c_float), ("useSurfaceBDRF", C.c_int32), ("useRayTracing", C.c_int32),
+        ("useRussianRoulette", C.c_int32), ("useHybridPhaseFunsForIntenCalcs", C.c_int32),
+        ("numOrdersOrigPhaseFunIntenCalcs", C.c_int32), ("useRussianRouletteForIntensity", C.c_int32),
+        ("zetaMin", C.c_float), ("limitIntensityContributions", C.c_int32), ("maxIntensityContribution", C.c_float),
+    ]
+
+
+class Source(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("solarMu", C.c_float), ("solarAzimuth", C.c_float),
+                ("x", fp), ("y", fp), ("z", fp), ("mu", fp), ("phi", fp)]
+
+
+class TallyLayout(C.Structure):
+    _fields_ = [("fluxUp", C.c_int64), ("fluxDown", C.c_int64), ("fluxAbsorbed", C.c_int64),
+                ("volumeAbsorption", C.c_int64), ("intensityByComponent", C.c_int64), ("intensityExcess", C.c_int64),
+                ("counters", C.c_int64), ("total", C.c_int64)]
+
+
+class I3RCError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load():
+    """Load csrc/libi3rc_hip.so; raise (never fall back) if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise I3RCError(f"{path} not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                        "the integrator has no CPU fallback")
+    L = C.CDLL(path)
+    H = C.c_void_p
+    L.i3rc_hip_create.argtypes = [C.POINTER(H), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp, ip]
+    L.i3rc_hip_destroy.argtypes = [H]
+    L.i3rc_hip_last_error.argtypes = [H]
+    L.i3rc_hip_last_error.restype = C.c_char_p
+    L.i3rc_hip_set_inverse_table.argtypes = [H, C.c_int, C.c_int, C.c_int, fp]
+    L.i3rc_hip_set_forward_tables.argtypes = [H, C.c_int, C.c_int, C.c_int, fp, fp]
+    L.i3rc_hip_set_params.argtypes = [H, C.POINTER(Params)]
+    L.i3rc_hip_set_surface.argtypes = [H, C.c_int, C.c_int, fp, fp, fp]
+    L.i3rc_hip_set_directions.argtypes = [H, C.c_int, fp]
+    L.i3rc_hip_get_tally_layout.argtypes = [H, C.POINTER(TallyLayout)]
+    L.i3rc_hip_bind_tally_buffer.argtypes = [H, C.c_void_p, C.c_size_t]
+    L.i3rc_hip_set_stream.argtypes = [H, C.c_void_p]
+    L.i3rc_hip_zero_tallies.argtypes = [H]
+    L.i3rc_hip_launch_batch.argtypes = [H, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.POINTER(Source)]
+    L.i3rc_hip_run_replay.argtypes = [H, C.c_int64, C.POINTER(Source), fp, C.c_int64, lp, ip, ip, fp, ip, ip]
+    L.i3rc_hip_trace_rays.argtypes = [H, C.c_int64, fp, fp, ip, fp, fp, ip]
+    L.i3rc_hip_synchronize.argtypes = [H]
+    L.i3rc_hip_fetch_tallies.argtypes = [H, dp]
+    L.i3rc_hip_normalise.argtypes = [H, dp, fp, fp, fp, fp, fp, fp]
+    L.i3rc_hip_last_kernel_ms.argtypes = [H, fp]
+    L.i3rc_hip_set_tuning.argtypes = [H, C.c_int, C.c_int]
+    L.i3rc_hip_philox_blocks.argtypes = [H, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.c_int, up, fp]
+    L.i3rc_hip_device_count.restype = C.c_int
+    L.i3rc_hip_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def pf(a):
+    return a.ctypes.data_as(fp)

@@ -1,0 +1,43 @@
+"""Build the gfx950 shared library (in-tree, so it travels to the GPU box with the snapshot)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libi3rc_hip.so")
+SOURCES = ["i3rc_hip.hip", "kernels.hpp", "tracer.hpp", "philox.hpp"]
+HEADER = os.path.join(os.path.dirname(HERE), "include", "i3rc_hip.h")
+
+# -ffp-contract=off: float32 results must follow the reference's operator order (no FMA contraction);
+# see DESIGN.md "float32 semantics".
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [HEADER]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 ... -> csrc/libi3rc_hip.so (cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc()] + HIPCC_FLAGS + ["-o", LIB, os.path.join(CSRC, "i3rc_hip.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,633 @@
+// C ABI (include/i3rc_hip.h) of the gfx950 photon-tracing integrator: device-state ownership, launches, tallies.
+#include "../../include/i3rc_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace i3rc;
+
+namespace {
+
+thread_local std::string g_createError;
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t upload(const void *src, size_t n) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    bytes = n;
+    hipError_t e = hipMalloc(&p, n ? n : 4);
+    if (e != hipSuccess) return e;
+    if (n) e = hipMemcpy(p, src, n, hipMemcpyHostToDevice);
+    return e;
+  }
+  hipError_t alloc(size_t n) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    bytes = n;
+    return hipMalloc(&p, n ? n : 4);
+  }
+};
+
+}  // namespace
+
+struct i3rc_hip_integrator {
+  int device = 0;
+  int nx = 0, ny = 0, nz = 0, ncomp = 0;
+  std::vector<float> xE, yE, zE;  // host copies (normalisation, checks)
+  DevBuf dxE, dyE, dzE, dExt, dCum, dSsa, dPf;
+  DevBuf dInv[I3RC_MAX_COMPONENTS], dFwd[I3RC_MAX_COMPONENTS], dFwdOrig[I3RC_MAX_COMPONENTS];
+  CompTables comp[I3RC_MAX_COMPONENTS] = {};
+  int nInvEntries[I3RC_MAX_COMPONENTS] = {}, nFwdEntries[I3RC_MAX_COMPONENTS] = {};
+  DevBuf dComp;
+  DevBuf dXs, dYs, dBrdf;
+  int nxs = 0, nys = 0;
+  DevBuf dDir;
+  int nDir = 0;
+  i3rc_params params{};
+  float maxExt = 0.f;
+  int xyRegular = 0, zRegular = 0;
+  int maxPfIndex[I3RC_MAX_COMPONENTS] = {};
+
+  i3rc_tally_layout layout{};
+  DevBuf ownTally;
+  double *tally = nullptr;  // device pointer in use (own or bound)
+  DevBuf workCounter;
+  DevBuf srcBuf[5];
+
+  hipStream_t ownStream = nullptr, stream = nullptr;
+  hipEvent_t evStart = nullptr, evStop = nullptr;
+  bool timed = false;
+  int numCU = 256;
+  int evThreshold = 32;
+  int blocksPerCU = 0;  // 0 = from occupancy query
+  std::string err;
+
+  int fail(const std::string &m) { err = m; return 1; }
+  int hipfail(const char *what, hipError_t e) {
+    err = std::string(what) + ": " + hipGetErrorString(e);
+    return 1;
+  }
+};
+
+#define HIPCHK(h, call)                                   \
+  do {                                                    \
+    hipError_t e__ = (call);                              \
+    if (e__ != hipSuccess) return (h)->hipfail(#call, e__); \
+  } while (0)
+
+static float host_spacing(float x) {
+  if (x == 0.0f) return FLT_MIN;
+  int e;
+  (void)std::frexp(std::fabs(x), &e);
+  float r = std::ldexp(1.0f, e - 24);
+  return r < FLT_MIN ? FLT_MIN : r;
+}
+
+static void compute_layout(i3rc_hip_integrator *h) {
+  const int64_t ncol = (int64_t)h->nx * h->ny, ncell = ncol * h->nz;
+  i3rc_tally_layout &L = h->layout;
+  int64_t o = 0;
+  L.fluxUp = o; o += ncol;
+  L.fluxDown = o; o += ncol;
+  L.fluxAbsorbed = o; o += ncol;
+  L.volumeAbsorption = o; o += ncell;
+  L.intensityByComponent = o; o += (int64_t)(h->ncomp + 1) * h->nDir * ncol;
+  L.intensityExcess = o; o += (int64_t)(h->ncomp + 1) * h->nDir;
+  L.counters = o; o += I3RC_NUM_COUNTERS;
+  L.total = o;
+}
+
+static int realloc_tally(i3rc_hip_integrator *h) {
+  compute_layout(h);
+  HIPCHK(h, h->ownTally.alloc((size_t)h->layout.total * sizeof(double)));
+  HIPCHK(h, hipMemset(h->ownTally.p, 0, (size_t)h->layout.total * sizeof(double)));
+  h->tally = (double *)h->ownTally.p;
+  return 0;
+}
+
+extern "C" {
+
+const char *i3rc_hip_version(void) { return "i3rc_hip 0.1 (gfx950)"; }
+
+int i3rc_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+  return n;
+}
+
+const char *i3rc_hip_last_error(const i3rc_hip_integrator *h) { return h ? h->err.c_str() : g_createError.c_str(); }
+
+int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int nz, int ncomp, const float *xEdges,
+                    const float *yEdges, const float *zEdges, const float *totalExt, const float *cumExt, const float *ssa,
+                    const int32_t *pfIndex) {
+  if (!out) { g_createError = "i3rc_hip_create: null handle pointer"; return 1; }
+  *out = nullptr;
+  if (nx < 1 || ny < 1 || nz < 1 || ncomp < 1 || ncomp > I3RC_MAX_COMPONENTS) {
+    g_createError = "i3rc_hip_create: bad dimensions (need nx,ny,nz >= 1 and 1 <= ncomp <= 8)";
+    return 1;
+  }
+  if ((int64_t)nx * ny * nz > (int64_t)1 << 30) { g_createError = "i3rc_hip_create: domain too large"; return 1; }
+  if (!xEdges || !yEdges || !zEdges || !totalExt || !cumExt || !ssa || !pfIndex) {
+    g_createError = "i3rc_hip_create: null array";
+    return 1;
+  }
+  for (int i = 0; i < nx; ++i) if (!(xEdges[i + 1] > xEdges[i])) { g_createError = "i3rc_hip_create: x edges must increase"; return 1; }
+  for (int i = 0; i < ny; ++i) if (!(yEdges[i + 1] > yEdges[i])) { g_createError = "i3rc_hip_create: y edges must increase"; return 1; }
+  for (int i = 0; i < nz; ++i) if (!(zEdges[i + 1] > zEdges[i])) { g_createError = "i3rc_hip_create: z edges must increase"; return 1; }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1) {
+    g_createError = "i3rc_hip_create: no HIP device available (the integrator has no CPU fallback)";
+    return 2;
+  }
+  if (device < 0 || device >= ndev) { g_createError = "i3rc_hip_create: device index out of range"; return 1; }
+
+  auto *h = new i3rc_hip_integrator();
+  h->device = device;
+  h->nx = nx; h->ny = ny; h->nz = nz; h->ncomp = ncomp;
+  auto bail = [&](const char *what, hipError_t er) {
+    g_createError = std::string(what) + ": " + hipGetErrorString(er);
+    delete h;
+    return 1;
+  };
+#define CCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return bail(#call, e_); } while (0)
+  CCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  CCHK(hipGetDeviceProperties(&prop, device));
+  h->numCU = prop.multiProcessorCount;
+  h->xE.assign(xEdges, xEdges + nx + 1);
+  h->yE.assign(yEdges, yEdges + ny + 1);
+  h->zE.assign(zEdges, zEdges + nz + 1);
+  const size_t ncell = (size_t)nx * ny * nz;
+  CCHK(h->dxE.upload(xEdges, sizeof(float) * (nx + 1)));
+  CCHK(h->dyE.upload(yEdges, sizeof(float) * (ny + 1)));
+  CCHK(h->dzE.upload(zEdges, sizeof(float) * (nz + 1)));
+  CCHK(h->dExt.upload(totalExt, sizeof(float) * ncell));
+  CCHK(h->dCum.upload(cumExt, sizeof(float) * ncell * ncomp));
+  CCHK(h->dSsa.upload(ssa, sizeof(float) * ncell * ncomp));
+  CCHK(h->dPf.upload(pfIndex, sizeof(int32_t) * ncell * ncomp));
+  CCHK(h->workCounter.alloc(sizeof(unsigned long long)));
+  CCHK(h->dComp.alloc(sizeof(CompTables) * I3RC_MAX_COMPONENTS));
+  CCHK(h->dDir.alloc(sizeof(float) * 3 * I3RC_MAX_DIRECTIONS));
+  CCHK(hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking));
+  h->stream = h->ownStream;
+  CCHK(hipEventCreate(&h->evStart));
+  CCHK(hipEventCreate(&h->evStop));
+#undef CCHK
+  // regular-spacing flags, new_Integrator :193-211
+  {
+    const float dx = xEdges[1] - xEdges[0], dy = yEdges[1] - yEdges[0], dz = zEdges[1] - zEdges[0];
+    int xy = 1, z = 1;
+    for (int i = 0; i < nx; ++i) if (!(std::fabs((xEdges[i + 1] - xEdges[i]) - dx) <= 2.0f * host_spacing(xEdges[i + 1]))) xy = 0;
+    for (int i = 0; i < ny; ++i) if (!(std::fabs((yEdges[i + 1] - yEdges[i]) - dy) <= 2.0f * host_spacing(yEdges[i + 1]))) xy = 0;
+    for (int i = 0; i < nz; ++i) if (!(std::fabs((zEdges[i + 1] - zEdges[i]) - dz) <= host_spacing(zEdges[i + 1]))) z = 0;
+    h->xyRegular = xy; h->zRegular = z;
+  }
+  h->maxExt = totalExt[0];
+  for (size_t i = 1; i < ncell; ++i) h->maxExt = std::max(h->maxExt, totalExt[i]);  // computeRT :438-439
+  for (int c = 0; c < ncomp; ++c) {
+    int m = 0;
+    for (size_t i = 0; i < ncell; ++i) m = std::max(m, pfIndex[(size_t)c * ncell + i]);
+    h->maxPfIndex[c] = m;
+  }
+  // defaults of type(integrator) :54-129
+  h->params.surfaceAlbedo = 0.f; h->params.useSurfaceBDRF = 0; h->params.useRayTracing = 1; h->params.useRussianRoulette = 1;
+  h->params.useHybridPhaseFunsForIntenCalcs = 0; h->params.numOrdersOrigPhaseFunIntenCalcs = 0;
+  h->params.useRussianRouletteForIntensity = 0; h->params.zetaMin = 0.3f; h->params.limitIntensityContributions = 0;
+  h->params.maxIntensityContribution = FLT_MAX;
+  if (realloc_tally(h)) { g_createError = h->err; delete h; return 1; }
+  *out = h;
+  return 0;
+}
+
+int i3rc_hip_destroy(i3rc_hip_integrator *h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  if (h->ownStream) { (void)hipStreamSynchronize(h->ownStream); (void)hipStreamDestroy(h->ownStream); }
+  if (h->evStart) (void)hipEventDestroy(h->evStart);
+  if (h->evStop) (void)hipEventDestroy(h->evStop);
+  delete h;
+  return 0;
+}
+
+int i3rc_hip_set_inverse_table(i3rc_hip_integrator *h, int comp, int nSteps, int nEntries, const float *t) {
+  if (!h) return 1;
+  if (comp < 1 || comp > h->ncomp) return h->fail("i3rc_hip_set_inverse_table: component out of range");
+  if (nSteps < 2 || nEntries < 1 || !t) return h->fail("i3rc_hip_set_inverse_table: bad table");
+  if (nEntries < h->maxPfIndex[comp - 1]) return h->fail("i3rc_hip_set_inverse_table: phaseFunctionIndex refers to a missing table entry");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, h->dInv[comp - 1].upload(t, sizeof(float) * (size_t)nSteps * nEntries));
+  h->comp[comp - 1].inv = (const float *)h->dInv[comp - 1].p;
+  h->comp[comp - 1].nInv = nSteps;
+  h->nInvEntries[comp - 1] = nEntries;
+  return 0;
+}
+
+int i3rc_hip_set_forward_tables(i3rc_hip_integrator *h, int comp, int nSteps, int nEntries, const float *hybrid, const float *orig) {
+  if (!h) return 1;
+  if (comp < 1 || comp > h->ncomp) return h->fail("i3rc_hip_set_forward_tables: component out of range");
+  if (nSteps < 2 || nEntries < 1 || !hybrid) return h->fail("i3rc_hip_set_forward_tables: bad table");
+  if (nEntries < h->maxPfIndex[comp - 1]) return h->fail("i3rc_hip_set_forward_tables: phaseFunctionIndex refers to a missing table entry");
+  if (!orig) orig = hybrid;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, h->dFwd[comp - 1].upload(hybrid, sizeof(float) * (size_t)nSteps * nEntries));
+  HIPCHK(h, h->dFwdOrig[comp - 1].upload(orig, sizeof(float) * (size_t)nSteps * nEntries));
+  h->comp[comp - 1].fwd = (const float *)h->dFwd[comp - 1].p;
+  h->comp[comp - 1].fwdOrig = (const float *)h->dFwdOrig[comp - 1].p;
+  h->comp[comp - 1].nFwd = nSteps;
+  h->nFwdEntries[comp - 1] = nEntries;
+  return 0;
+}
+
+int i3rc_hip_set_params(i3rc_hip_integrator *h, const i3rc_params *p) {
+  if (!h) return 1;
+  if (!p) return h->fail("i3rc_hip_set_params: null params");
+  if (!p->useSurfaceBDRF && (p->surfaceAlbedo > 1.f || p->surfaceAlbedo < 0.f))
+    return h->fail("specifyParameters: surface albedo out of range.");  // :878-879
+  if (p->useSurfaceBDRF && !h->dBrdf.p) return h->fail("specifyParameters: surface description isn't valid.");  // :882-883
+  if (p->zetaMin < 0.f) return h->fail("specifyParameters: zetaMin must be >= 0.");
+  h->params = *p;
+  return 0;
+}
+
+int i3rc_hip_set_surface(i3rc_hip_integrator *h, int nxs, int nys, const float *xs, const float *ys, const float *brdf) {
+  if (!h) return 1;
+  if (nxs < 1 || nys < 1 || !xs || !ys || !brdf) return h->fail("i3rc_hip_set_surface: bad surface grid");
+  for (int i = 0; i < nxs; ++i) if (!(xs[i + 1] > xs[i])) return h->fail("new_SurfaceDescription: positions must be unique, increasing.");
+  for (int i = 0; i < nys; ++i) if (!(ys[i + 1] > ys[i])) return h->fail("new_SurfaceDescription: positions must be unique, increasing.");
+  for (size_t i = 0; i < (size_t)nxs * nys; ++i)
+    if (brdf[i] < 0.f || brdf[i] > 1.f) return h->fail("new_SurfaceDescription: surface reflectance must be between 0 and 1");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, h->dXs.upload(xs, sizeof(float) * (nxs + 1)));
+  HIPCHK(h, h->dYs.upload(ys, sizeof(float) * (nys + 1)));
+  HIPCHK(h, h->dBrdf.upload(brdf, sizeof(float) * (size_t)nxs * nys));
+  h->nxs = nxs; h->nys = nys;
+  return 0;
+}
+
+int i3rc_hip_set_directions(i3rc_hip_integrator *h, int nDir, const float *dirCos) {
+  if (!h) return 1;
+  if (nDir < 0 || nDir > I3RC_MAX_DIRECTIONS) return h->fail("i3rc_hip_set_directions: 0 <= nDir <= 20 required");
+  if (nDir > 0 && !dirCos) return h->fail("i3rc_hip_set_directions: null directions");
+  for (int d = 0; d < nDir; ++d)
+    if (std::fabs(dirCos[3 * d + 2]) < FLT_MIN) return h->fail("specifyParameters: intensityMus can't be 0 (directly sideways)");  // :932-933
+  HIPCHK(h, hipSetDevice(h->device));
+  if (nDir > 0) HIPCHK(h, hipMemcpy(h->dDir.p, dirCos, sizeof(float) * 3 * nDir, hipMemcpyHostToDevice));
+  const bool changed = nDir != h->nDir;
+  h->nDir = nDir;
+  if (changed) {
+    if (h->tally != (double *)h->ownTally.p) return h->fail("i3rc_hip_set_directions: rebind the tally buffer after changing nDir");
+    return realloc_tally(h);
+  }
+  return 0;
+}
+
+int i3rc_hip_get_tally_layout(const i3rc_hip_integrator *h, i3rc_tally_layout *layout) {
+  if (!h || !layout) return 1;
+  *layout = h->layout;
+  return 0;
+}
+
+int i3rc_hip_bind_tally_buffer(i3rc_hip_integrator *h, void *devicePtr, size_t bytes) {
+  if (!h) return 1;
+  if (!devicePtr) { h->tally = (double *)h->ownTally.p; return 0; }
+  if (bytes < (size_t)h->layout.total * sizeof(double)) return h->fail("i3rc_hip_bind_tally_buffer: buffer too small");
+  if (((uintptr_t)devicePtr & 7u) != 0) return h->fail("i3rc_hip_bind_tally_buffer: buffer must be 8-byte aligned");
+  h->tally = (double *)devicePtr;
+  return 0;
+}
+
+int i3rc_hip_set_stream(i3rc_hip_integrator *h, void *s) {
+  if (!h) return 1;
+  h->stream = s ? (hipStream_t)s : h->ownStream;
+  return 0;
+}
+
+int i3rc_hip_zero_tallies(i3rc_hip_integrator *h) {
+  if (!h) return 1;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemsetAsync(h->tally, 0, (size_t)h->layout.total * sizeof(double), h->stream));
+  return 0;
+}
+
+/* Tunables for experiments (not part of the reference API): event-phase ballot threshold, blocks per CU. */
+int i3rc_hip_set_tuning(i3rc_hip_integrator *h, int evThreshold, int blocksPerCU) {
+  if (!h) return 1;
+  if (evThreshold >= 1 && evThreshold <= 64) h->evThreshold = evThreshold;
+  if (blocksPerCU >= 0 && blocksPerCU <= 8) h->blocksPerCU = blocksPerCU;
+  return 0;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct LaunchPlan {
+  DevProblem P;
+  size_t ldsBytes;
+  bool intensity;
+};
+
+constexpr size_t kLdsBudget = 64 * 1024;  // per workgroup: leaves room for >= 2 workgroups per CU
+
+int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan) {
+  DevProblem &P = plan.P;
+  std::memset(&P, 0, sizeof(P));
+  for (int c = 0; c < h->ncomp; ++c)
+    if (!h->comp[c].inv) return h->fail("computeRadiativeTransfer: problem not completely specified (inverse phase function table missing).");
+  if (h->nDir > 0)
+    for (int c = 0; c < h->ncomp; ++c)
+      if (!h->comp[c].fwd) return h->fail("computeRadiativeTransfer: problem not completely specified (forward phase function table missing).");
+  P.nx = h->nx; P.ny = h->ny; P.nz = h->nz; P.ncomp = h->ncomp;
+  P.xyRegular = h->xyRegular; P.zRegular = h->zRegular;
+  P.x0 = h->xE.front(); P.xMax = h->xE.back();
+  P.y0 = h->yE.front(); P.yMax = h->yE.back();
+  P.z0 = h->zE.front(); P.zMax = h->zE.back();
+  P.deltaX = h->xE[1] - h->xE[0]; P.deltaY = h->yE[1] - h->yE[0]; P.deltaZ = h->zE[1] - h->zE[0];
+  P.xE = (const float *)h->dxE.p; P.yE = (const float *)h->dyE.p; P.zE = (const float *)h->dzE.p;
+  P.totalExt = (const float *)h->dExt.p; P.cumExt = (const float *)h->dCum.p; P.ssa = (const float *)h->dSsa.p;
+  P.pfIndex = (const int32_t *)h->dPf.p;
+  if (hipMemcpyAsync(h->dComp.p, h->comp, sizeof(CompTables) * I3RC_MAX_COMPONENTS, hipMemcpyHostToDevice, h->stream) != hipSuccess)
+    return h->fail("hipMemcpyAsync(component tables) failed");
+  P.comp = (const CompTables *)h->dComp.p;
+  P.albedo = h->params.surfaceAlbedo; P.useBDRF = h->params.useSurfaceBDRF;
+  P.nxs = h->nxs; P.nys = h->nys;
+  P.xsE = (const float *)h->dXs.p; P.ysE = (const float *)h->dYs.p; P.brdf = (const float *)h->dBrdf.p;
+  if (P.useBDRF && !P.brdf) return h->fail("computeRadiativeTransfer: surfaceBDRF requested but no surface description set");
+  P.useRayTracing = h->params.useRayTracing; P.useRR = h->params.useRussianRoulette;
+  P.nDir = h->nDir; P.useHybrid = h->params.useHybridPhaseFunsForIntenCalcs;
+  P.numOrdersOrig = h->params.numOrdersOrigPhaseFunIntenCalcs; P.useRRI = h->params.useRussianRouletteForIntensity;
+  P.limitContrib = h->params.limitIntensityContributions; P.zetaMin = h->params.zetaMin;
+  P.maxContrib = h->params.maxIntensityContribution; P.maxExt = h->maxExt;
+  P.dirCos = (const float *)h->dDir.p;
+  P.tally = h->tally;
+  P.oUp = h->layout.fluxUp; P.oDown = h->layout.fluxDown; P.oAbs = h->layout.fluxAbsorbed; P.oVol = h->layout.volumeAbsorption;
+  P.oInt = h->layout.intensityByComponent; P.oExc = h->layout.intensityExcess; P.oCnt = h->layout.counters;
+  const size_t ncol = (size_t)h->nx * h->ny, ncell = ncol * h->nz;
+  size_t lds = sizeof(float) * ((h->nx + 1) + (h->ny + 1) + (h->nz + 1) + 3 * (size_t)h->nDir);
+  if (lds > kLdsBudget) return h->fail("domain edge vectors do not fit in LDS");
+  P.ldsTallies = 0;
+  if (lds + 3 * ncol * sizeof(float) <= kLdsBudget / 2) { P.ldsTallies = 1; lds += 3 * ncol * sizeof(float); }
+  P.ldsGrid = 0;
+  if (lds + ncell * sizeof(float) <= kLdsBudget) { P.ldsGrid = 1; lds += ncell * sizeof(float); }
+  plan.ldsBytes = (lds + 15) & ~(size_t)15;
+  plan.intensity = h->nDir > 0;
+  return 0;
+}
+
+int upload_source(i3rc_hip_integrator *h, const i3rc_source *src, int64_t n, RunArgs &A) {
+  A.srcKind = src->kind;
+  if (src->kind == 0) {
+    if (std::fabs(src->solarMu) > 1.f || std::fabs(src->solarMu) <= FLT_MIN) return h->fail("setIllumination: solarMu out of bounds");
+    if (src->solarAzimuth < 0.f || src->solarAzimuth > 360.f) return h->fail("setIllumination: solarAzimuth out of bounds");
+    A.solarMu = -std::fabs(src->solarMu);                      // Code/monteCarloIllumination.f95:98
+    A.solarPhi = src->solarAzimuth * std::acos(-1.0f) / 180.f; // :99
+    return 0;
+  }
+  if (src->kind != 1) return h->fail("unknown photon source kind");
+  const float *arrs[5] = {src->x, src->y, src->z, src->mu, src->phi};
+  const float **dst[5] = {&A.sx, &A.sy, &A.sz, &A.smu, &A.sphi};
+  for (int k = 0; k < 5; ++k) {
+    if (!arrs[k]) return h->fail("explicit photon stream: null array");
+    HIPCHK(h, h->srcBuf[k].upload(arrs[k], sizeof(float) * (size_t)n));
+    *dst[k] = (const float *)h->srcBuf[k].p;
+  }
+  return 0;
+}
+
+template <class Rng>
+int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, bool timeIt) {
+  auto kern = plan.intensity ? photon_kernel<Rng, true> : photon_kernel<Rng, false>;
+  int perCU = h->blocksPerCU;
+  if (perCU <= 0) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, plan.ldsBytes) != hipSuccess || occ < 1) occ = 2;
+    perCU = std::min(occ, 8);
+  }
+  if (plan.ldsBytes > 48 * 1024)
+    HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.ldsBytes));
+  long long blocks = (long long)h->numCU * perCU;
+  const long long need = (A.nPhotons + 255) / 256;
+  if (blocks > need) blocks = std::max(1ll, need);
+  HIPCHK(h, hipMemsetAsync(A.workCounter, 0, sizeof(unsigned long long), h->stream));
+  if (timeIt) HIPCHK(h, hipEventRecord(h->evStart, h->stream));
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), plan.ldsBytes, h->stream, plan.P, A, h->evThreshold);
+  HIPCHK(h, hipGetLastError());
+  if (timeIt) { HIPCHK(h, hipEventRecord(h->evStop, h->stream)); h->timed = true; }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int i3rc_hip_launch_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int64_t firstPhoton, int64_t nPhotons,
+                          const i3rc_source *src) {
+  if (!h) return 1;
+  if (!src) return h->fail("i3rc_hip_launch_batch: null source");
+  if (nPhotons <= 0) return h->fail("setIllumination: must ask for non-negative number of photons.");  // illumination :78-79
+  HIPCHK(h, hipSetDevice(h->device));
+  LaunchPlan plan;
+  if (make_problem(h, plan)) return 1;
+  RunArgs A;
+  std::memset(&A, 0, sizeof(A));
+  A.seed0 = seed0; A.seed1 = seed1; A.firstPhoton = firstPhoton; A.nPhotons = nPhotons;
+  A.workCounter = (unsigned long long *)h->workCounter.p;
+  if (upload_source(h, src, nPhotons, A)) return 1;
+  return launch<PhiloxStream>(h, plan, A, true);
+}
+
+int i3rc_hip_run_replay(i3rc_hip_integrator *h, int64_t nPhotons, const i3rc_source *src, const float *randoms,
+                        int64_t nRandoms, const int64_t *drawStart, int32_t *fate, int32_t *fateColumn, float *fateWeight,
+                        int32_t *fateOrder, int32_t *drawsUsed) {
+  if (!h) return 1;
+  if (!src || !randoms || !drawStart || nPhotons <= 0) return h->fail("i3rc_hip_run_replay: bad arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  LaunchPlan plan;
+  if (make_problem(h, plan)) return 1;
+  RunArgs A;
+  std::memset(&A, 0, sizeof(A));
+  A.nPhotons = nPhotons;
+  A.workCounter = (unsigned long long *)h->workCounter.p;
+  if (upload_source(h, src, nPhotons, A)) return 1;
+  DevBuf dR, dS, dFate, dCol, dW, dOrd, dUsed;
+  HIPCHK(h, dR.upload(randoms, sizeof(float) * (size_t)nRandoms));
+  HIPCHK(h, dS.upload(drawStart, sizeof(int64_t) * (size_t)nPhotons));
+  A.randoms = (const float *)dR.p; A.nRandoms = nRandoms; A.drawStart = (const long long *)dS.p;
+  const bool rec = fate && fateColumn && fateWeight && fateOrder && drawsUsed;
+  if (rec) {
+    HIPCHK(h, dFate.alloc(sizeof(int32_t) * nPhotons)); HIPCHK(h, dCol.alloc(sizeof(int32_t) * nPhotons));
+    HIPCHK(h, dW.alloc(sizeof(float) * nPhotons)); HIPCHK(h, dOrd.alloc(sizeof(int32_t) * nPhotons));
+    HIPCHK(h, dUsed.alloc(sizeof(int32_t) * nPhotons));
+    A.fate = (int32_t *)dFate.p; A.fateColumn = (int32_t *)dCol.p; A.fateWeight = (float *)dW.p;
+    A.fateOrder = (int32_t *)dOrd.p; A.drawsUsed = (int32_t *)dUsed.p;
+  }
+  if (launch<ReplayStream>(h, plan, A, false)) return 1;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (rec) {
+    HIPCHK(h, hipMemcpy(fate, dFate.p, sizeof(int32_t) * nPhotons, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(fateColumn, dCol.p, sizeof(int32_t) * nPhotons, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(fateWeight, dW.p, sizeof(float) * nPhotons, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(fateOrder, dOrd.p, sizeof(int32_t) * nPhotons, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(drawsUsed, dUsed.p, sizeof(int32_t) * nPhotons, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+int i3rc_hip_trace_rays(i3rc_hip_integrator *h, int64_t n, const float *dir, float *pos, int32_t *idx, const float *target,
+                        float *tau, int32_t *steps) {
+  if (!h) return 1;
+  if (n <= 0 || !dir || !pos || !idx || !target || !tau || !steps) return h->fail("i3rc_hip_trace_rays: bad arguments");
+  for (int64_t i = 0; i < n; ++i) {  // shapes must match what the kernel indexes
+    if (idx[3 * i] < 1 || idx[3 * i] > h->nx || idx[3 * i + 1] < 1 || idx[3 * i + 1] > h->ny || idx[3 * i + 2] < 1 ||
+        idx[3 * i + 2] > h->nz)
+      return h->fail("i3rc_hip_trace_rays: start cell outside the domain");
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  LaunchPlan plan;
+  // tables are not needed for bare tracing: build the problem without the completeness checks
+  CompTables saved[I3RC_MAX_COMPONENTS];
+  std::memcpy(saved, h->comp, sizeof(saved));
+  static const float dummy = 0.f;
+  for (int c = 0; c < h->ncomp; ++c) if (!h->comp[c].inv) h->comp[c].inv = &dummy;
+  const int savedDir = h->nDir;
+  h->nDir = 0;
+  const int rc = make_problem(h, plan);
+  h->nDir = savedDir;
+  std::memcpy(h->comp, saved, sizeof(saved));
+  if (rc) return 1;
+  plan.P.ldsGrid = 0; plan.P.ldsTallies = 0;
+  DevBuf dDir, dPos, dIdx, dTar, dTau, dSteps;
+  HIPCHK(h, dDir.upload(dir, sizeof(float) * 3 * n)); HIPCHK(h, dPos.upload(pos, sizeof(float) * 3 * n));
+  HIPCHK(h, dIdx.upload(idx, sizeof(int32_t) * 3 * n)); HIPCHK(h, dTar.upload(target, sizeof(float) * n));
+  HIPCHK(h, dTau.alloc(sizeof(float) * n)); HIPCHK(h, dSteps.alloc(sizeof(int32_t) * n));
+  const size_t lds = sizeof(float) * ((h->nx + 1) + (h->ny + 1) + (h->nz + 1));
+  hipLaunchKernelGGL(trace_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, h->stream, plan.P, (long long)n,
+                     (const float *)dDir.p, (float *)dPos.p, (int32_t *)dIdx.p, (const float *)dTar.p, (float *)dTau.p,
+                     (int32_t *)dSteps.p);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(pos, dPos.p, sizeof(float) * 3 * n, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(idx, dIdx.p, sizeof(int32_t) * 3 * n, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(tau, dTau.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(steps, dSteps.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+/* Test hook: raw Philox blocks and the float deviates derived from them, as photon streams see them. */
+int i3rc_hip_philox_blocks(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int64_t firstPhoton, int64_t n,
+                           int blocksPerPhoton, uint32_t *out, float *outf) {
+  if (!h) return 1;
+  if (n <= 0 || blocksPerPhoton <= 0 || !out || !outf) return h->fail("i3rc_hip_philox_blocks: bad arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  DevBuf d, df;
+  const size_t cnt = (size_t)n * blocksPerPhoton * 4;
+  HIPCHK(h, d.alloc(cnt * 4)); HIPCHK(h, df.alloc(cnt * 4));
+  hipLaunchKernelGGL(philox_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, seed0, seed1,
+                     (long long)firstPhoton, (long long)n, blocksPerPhoton, (uint32_t *)d.p, (float *)df.p);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(out, d.p, cnt * 4, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(outf, df.p, cnt * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int i3rc_hip_synchronize(i3rc_hip_integrator *h) {
+  if (!h) return 1;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int i3rc_hip_fetch_tallies(i3rc_hip_integrator *h, double *host) {
+  if (!h) return 1;
+  if (!host) return h->fail("i3rc_hip_fetch_tallies: null buffer");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(host, h->tally, (size_t)h->layout.total * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int i3rc_hip_last_kernel_ms(i3rc_hip_integrator *h, float *ms) {
+  if (!h || !ms) return 1;
+  if (!h->timed) return h->fail("i3rc_hip_last_kernel_ms: no timed launch yet");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipEventSynchronize(h->evStop));
+  HIPCHK(h, hipEventElapsedTime(ms, h->evStart, h->evStop));
+  return 0;
+}
+
+int i3rc_hip_normalise(const i3rc_hip_integrator *h, const double *t, float *fluxUp, float *fluxDown, float *fluxAbsorbed,
+                       float *volumeAbsorption, float *intensity, float *intensityByComponent) {
+  if (!h || !t) return 1;
+  const i3rc_tally_layout &L = h->layout;
+  const size_t ncol = (size_t)h->nx * h->ny;
+  const int nDir = h->nDir, ncomp = h->ncomp;
+  const double nPhot = t[L.counters + I3RC_CNT_PHOTONS];
+  // photons per column :353-367 (float64 here; the reference works in real(4))
+  std::vector<double> perCol(ncol);
+  if (h->xyRegular) {
+    for (size_t k = 0; k < ncol; ++k) perCol[k] = nPhot / (double)ncol;
+  } else {
+    const double ax = (double)h->xE.back() - h->xE.front(), ay = (double)h->yE.back() - h->yE.front();
+    for (int j = 0; j < h->ny; ++j)
+      for (int i = 0; i < h->nx; ++i)
+        perCol[(size_t)j * h->nx + i] = (((double)h->yE[j + 1] - h->yE[j]) * ((double)h->xE[i + 1] - h->xE[i])) / (ax * ay) * nPhot;
+  }
+  for (size_t k = 0; k < ncol; ++k) {
+    if (fluxUp) fluxUp[k] = (float)(t[L.fluxUp + k] / perCol[k]);
+    if (fluxDown) fluxDown[k] = (float)(t[L.fluxDown + k] / perCol[k]);
+    if (fluxAbsorbed) fluxAbsorbed[k] = (float)(t[L.fluxAbsorbed + k] / perCol[k]);
+  }
+  if (volumeAbsorption)
+    for (int kz = 0; kz < h->nz; ++kz)
+      for (size_t k = 0; k < ncol; ++k)
+        volumeAbsorption[(size_t)kz * ncol + k] =
+            (float)(t[L.volumeAbsorption + (size_t)kz * ncol + k] / (perCol[k] * ((double)h->zE[kz + 1] - h->zE[kz])));
+  if (nDir > 0 && (intensity || intensityByComponent)) {
+    // intensity = sum over components (0 = surface) of intensityByComponent :574-579,:662-667
+    std::vector<double> byc((size_t)(ncomp + 1) * nDir * ncol), tot((size_t)nDir * ncol, 0.0);
+    for (size_t i = 0; i < byc.size(); ++i) byc[i] = t[L.intensityByComponent + i];
+    for (int j = 0; j <= ncomp; ++j)
+      for (size_t i = 0; i < (size_t)nDir * ncol; ++i) tot[i] += byc[(size_t)j * nDir * ncol + i];
+    if (h->params.limitIntensityContributions) {  // :327-347
+      for (int j = 0; j <= ncomp; ++j)
+        for (int d = 0; d < nDir; ++d) {
+          const double ex = t[L.intensityExcess + (size_t)j * nDir + d];
+          if (ex > 0.0) {
+            double *b = byc.data() + ((size_t)j * nDir + d) * ncol;
+            double s = 0.0;
+            for (size_t k = 0; k < ncol; ++k) s += b[k];
+            for (size_t k = 0; k < ncol; ++k) {
+              const double add = (b[k] / s) * ex;
+              tot[(size_t)d * ncol + k] += add;
+              b[k] += add;
+            }
+          }
+        }
+    }
+    if (intensity)
+      for (int d = 0; d < nDir; ++d)
+        for (size_t k = 0; k < ncol; ++k) intensity[(size_t)d * ncol + k] = (float)(tot[(size_t)d * ncol + k] / perCol[k]);
+    if (intensityByComponent)
+      for (int j = 0; j <= ncomp; ++j)
+        for (int d = 0; d < nDir; ++d)
+          for (size_t k = 0; k < ncol; ++k) {
+            const size_t o = ((size_t)j * nDir + d) * ncol + k;
+            // the reference leaves component 0 un-normalised (:390 loops j = 1:numComponents)
+            intensityByComponent[o] = (float)(j == 0 ? byc[o] : byc[o] / perCol[k]);
+          }
+  }
+  return 0;
+}
+
+}  // extern "C"

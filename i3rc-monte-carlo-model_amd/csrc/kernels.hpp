@@ -1,0 +1,391 @@
+// gfx950 kernels of the I3RC photon tracer.
+//
+// Mapping (MI355X-first, not a port of the scalar Fortran loop nest):
+//   * one photon per LANE, 64 photons in flight per wavefront, persistent waves: a lane that loses its photon
+//     (exit, absorption, roulette, tracer drop) pulls the next photon index from a device-wide counter
+//     (the compiler aggregates the per-lane atomicAdd into one add per wave);
+//   * the reference's three nested data-dependent loops (photon / order of scattering / voxel step,
+//     computeRT :452-691 + accumulateExtinctionAlongPath :1690-1806) are flattened into one loop with two
+//     phases: a cheap VOXEL-STEP phase executed by the lanes that are tracing and an EVENT phase (scatter,
+//     surface, exit + respawn, new optical depth) that only runs when a ballot says enough lanes are
+//     waiting for it (evThreshold), which keeps both phases well populated;
+//   * cell edges (and, when they fit, the extinction grid) are staged in LDS with coalesced loads;
+//     flux tallies are privatised per workgroup in LDS (ds_add_f32) and flushed once with float64
+//     atomics; large domains tally straight to HBM with float64 atomics;
+//   * per-photon Philox4x32-10 streams keyed by (seed, batch) make a photon's path independent of the
+//     launch geometry and of the number of GPUs.
+#pragma once
+#include "tracer.hpp"
+
+namespace i3rc {
+
+enum LaneState { ST_TRACE = 0, ST_EVENT = 1, ST_DROPPED = 2, ST_NEW = 3, ST_DONE = 4 };
+
+struct LaneCounters {
+  uint32_t photons = 0, dropped = 0, steps = 0, scat = 0, surf = 0, top = 0, roul = 0, shadow = 0, calls = 0;
+  unsigned long long draws = 0;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ void add_global(double *p, float v) { unsafeAtomicAdd(p, (double)v); }
+
+struct Tally {
+  const DevProblem &P;
+  const Lds &L;
+  __device__ __forceinline__ void up(int col, float w) const {
+    if (P.ldsTallies) atomicAdd(&L.tUp[col], w); else add_global(P.tally + P.oUp + col, w);
+  }
+  __device__ __forceinline__ void down(int col, float w) const {
+    if (P.ldsTallies) atomicAdd(&L.tDown[col], w); else add_global(P.tally + P.oDown + col, w);
+  }
+  __device__ __forceinline__ void absorbed(int col, size_t cell, float w) const {
+    if (P.ldsTallies) atomicAdd(&L.tAbs[col], w); else add_global(P.tally + P.oAbs + col, w);
+    add_global(P.tally + P.oVol + cell, w);
+  }
+};
+
+// computeIntensityContribution :1419-1611 for one event; adds straight into intensityByComponent.
+template <class Rng>
+__device__ __forceinline__ void intensity_contribution(const DevProblem &P, const Lds &L, Rng &rng, LaneCounters &cnt,
+                                                       float weight, float x, float y, float z, int ix, int iy, int iz,
+                                                       float dx, float dy, float dz, int component, int order) {
+  const int zIndexMax = P.nz + 1;
+  const size_t ncol = (size_t)P.nx * P.ny;
+  for (int d = 0; d < P.nDir; ++d) {
+    const float ux = L.dirCos[3 * d], uy = L.dirCos[3 * d + 1], uz = L.dirCos[3 * d + 2];
+    float normPF;
+    if (component < 1) {
+      normPF = 1.0f / kPi;
+    } else {
+      float proj = 0.0f;
+      proj += dx * ux; proj += dy * uy; proj += dz * uz;
+      if (fabsf(proj) > 1.0f) proj = copysignf(1.0f, proj);
+      const float ang = acosf(proj);
+      const size_t ncell = ncol * P.nz;
+      const int pfi = P.pfIndex[(size_t)(component - 1) * ncell + cell_index(P, ix, iy, iz)];
+      const CompTables ct = P.comp[component - 1];
+      const int n = ct.nFwd;
+      const float *tab = ((P.useHybrid && order <= P.numOrdersOrig) ? ct.fwdOrig : ct.fwd) + (size_t)(pfi - 1) * n;
+      normPF = lookup_phase(tab, n, ang) / ((4.0f * kPi) * fabsf(uz));
+    }
+    Ray r;
+    r.x = x; r.y = y; r.z = z; r.ix = ix; r.iy = iy; r.iz = iz; r.dx = ux; r.dy = uy; r.dz = uz;
+    float con;
+    auto run = [&](bool hasTarget, float target) {
+      r.acc = 0.0f; r.target = target;
+      cnt.calls++;
+      StepResult s;
+      do { cnt.shadow++; s = trace_step(P, L, r, hasTarget); } while (s == STEP_CONTINUE);
+      return r.acc;
+    };
+    if (!P.useRRI) {
+      const float tauB = run(false, 0.0f);
+      con = tauB >= 0.0f ? (weight * normPF) * expf(-tauB) : 0.0f;
+    } else {
+      const float tauFree = -logf(fmaxf(kTiny, rng.next()));
+      if (kPi * normPF <= P.zetaMin) {
+        (void)run(true, tauFree);
+        const float r2 = rng.next();
+        con = (r2 <= kPi * normPF / P.zetaMin && r.iz >= zIndexMax) ? weight * P.zetaMin / kPi : 0.0f;
+      } else {
+        const float tauMax = -logf(P.zetaMin / fmaxf(kTiny, kPi * normPF));
+        float tauB = run(true, tauMax);
+        if (r.iz >= zIndexMax && tauB >= 0.0f) con = (weight * normPF) * expf(-tauB);
+        else if (tauB >= 0.0f) {
+          (void)run(true, tauFree);
+          con = r.iz >= zIndexMax ? weight * P.zetaMin / kPi : 0.0f;
+        } else con = 0.0f;
+      }
+    }
+    if (P.limitContrib && con > P.maxContrib) {
+      add_global(P.tally + P.oExc + (size_t)component * P.nDir + d, con - P.maxContrib);
+      con = P.maxContrib;
+    }
+    const size_t col = (size_t)(r.iy - 1) * P.nx + (size_t)(r.ix - 1);
+    add_global(P.tally + P.oInt + ((size_t)component * P.nDir + d) * ncol + col, con);
+  }
+}
+
+template <class Rng>
+struct RngInit;
+template <>
+struct RngInit<PhiloxStream> {
+  static __device__ __forceinline__ void start(PhiloxStream &g, const RunArgs &A, long long i) {
+    g.start(A.seed0, A.seed1, (uint64_t)(A.firstPhoton + i));
+  }
+};
+template <>
+struct RngInit<ReplayStream> {
+  static __device__ __forceinline__ void start(ReplayStream &g, const RunArgs &A, long long i) {
+    g.start(A.randoms, A.drawStart[i], A.nRandoms);
+  }
+};
+
+template <class Rng, bool INTENSITY>
+__global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  Lds L;
+  {
+    float *p = smem;
+    L.xE = p; p += P.nx + 1;
+    L.yE = p; p += P.ny + 1;
+    L.zE = p; p += P.nz + 1;
+    const int ncol = P.nx * P.ny;
+    L.tUp = p; L.tDown = p + ncol; L.tAbs = p + 2 * ncol;
+    if (P.ldsTallies) p += 3 * ncol;
+    L.dirCos = p; p += 3 * P.nDir;
+    L.ext = p;
+  }
+  for (int i = threadIdx.x; i < 3 * P.nDir; i += blockDim.x) L.dirCos[i] = P.dirCos[i];
+  // coalesced staging of the edge vectors (and the extinction grid when it fits)
+  for (int i = threadIdx.x; i <= P.nx; i += blockDim.x) L.xE[i] = P.xE[i];
+  for (int i = threadIdx.x; i <= P.ny; i += blockDim.x) L.yE[i] = P.yE[i];
+  for (int i = threadIdx.x; i <= P.nz; i += blockDim.x) L.zE[i] = P.zE[i];
+  if (P.ldsTallies)
+    for (int i = threadIdx.x; i < 3 * P.nx * P.ny; i += blockDim.x) L.tUp[i] = 0.0f;
+  if (P.ldsGrid) {
+    const int ncell = P.nx * P.ny * P.nz;
+    for (int i = threadIdx.x; i < ncell; i += blockDim.x) L.ext[i] = P.totalExt[i];
+  }
+  __syncthreads();
+
+  const Tally tally{P, L};
+  const size_t ncell = (size_t)P.nx * P.ny * P.nz;
+  const float surfaceZ = P.z0 + spacingf(P.z0);
+
+  LaneCounters cnt;
+  Rng rng;
+  Ray r;
+  r.x = r.y = r.z = 0.0f; r.dx = r.dy = 0.0f; r.dz = -1.0f; r.ix = r.iy = r.iz = 1; r.acc = 0.0f; r.target = 0.0f;
+  float w = 0.0f;
+  int order = 0;
+  int st = ST_NEW;
+  long long pid = -1;
+  int fate = -1, fateCol = -1;
+  float fateW = 0.0f;
+
+  for (;;) {
+    // ---------------------------------------------------------------- EVENT phase
+    const bool wantEvent = (st != ST_TRACE) && (st != ST_DONE);
+    const unsigned long long evMask = __ballot(wantEvent);
+    const unsigned long long trMask = __ballot(st == ST_TRACE);
+    if (evMask == 0ull && trMask == 0ull) break;
+    if (__popcll(evMask) >= evThreshold || trMask == 0ull) {
+      if (wantEvent) {
+        if (st == ST_DROPPED) { cnt.dropped++; fate = 3; st = ST_NEW; }   // :488-489
+        if (st == ST_EVENT) {
+          const int col = (r.iy - 1) * P.nx + (r.ix - 1);
+          if (r.z >= P.zMax) {                                            // :499-514
+            if (!P.useRayTracing) {
+              r.x = make_periodic(r.x - r.dx * fabsf((r.z - P.zMax) / r.dz), P.x0, P.xMax);
+              r.y = make_periodic(r.y - r.dy * fabsf((r.z - P.zMax) / r.dz), P.y0, P.yMax);
+              find_xy(P, L, r.x, r.y, r.ix, r.iy);
+            }
+            const int c2 = (r.iy - 1) * P.nx + (r.ix - 1);
+            tally.up(c2, w);
+            cnt.top++;
+            fate = 0; fateCol = c2; fateW = w;
+            st = ST_NEW;
+          } else if (r.z <= surfaceZ) {                                   // :515-580
+            order++;
+            if (!P.useRayTracing) {
+              r.x = make_periodic(r.x - r.dx * fabsf((r.z - P.z0) / r.dz), P.x0, P.xMax);
+              r.y = make_periodic(r.y - r.dy * fabsf((r.z - P.z0) / r.dz), P.y0, P.yMax);
+              find_xy(P, L, r.x, r.y, r.ix, r.iy);
+            }
+            r.iz = 1;
+            r.z = surfaceZ;
+            const int c2 = (r.iy - 1) * P.nx + (r.ix - 1);
+            tally.down(c2, w);
+            cnt.surf++;
+            fateCol = c2; fateW = w;
+            float mu;
+            do { mu = sqrtf(rng.next()); } while (!(fabsf(mu) > 2.0f * kTiny));
+            const float phi = (2.0f * kPi) * rng.next();
+            if (P.useBDRF) w = w * surface_reflectance(P, r.x, r.y);
+            else w = w * P.albedo;
+            if (w <= kTiny) { fate = 1; st = ST_NEW; }
+            else {
+              make_dircos(mu, phi, r.dx, r.dy, r.dz);
+              if (INTENSITY)
+                intensity_contribution(P, L, rng, cnt, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, 0, order);
+              st = ST_TRACE;  // provisional: a new optical depth is drawn below
+            }
+          } else {                                                        // :581-689
+            (void)col;
+            bool scatterThis = true;
+            size_t cell = cell_index(P, r.ix, r.iy, r.iz);
+            if (!P.useRayTracing) scatterThis = rng.next() < P.totalExt[cell] / P.maxExt;
+            if (scatterThis) {
+              order++;
+              cnt.scat++;
+              if (P.totalExt[cell] <= 0.0f) {                             // :606-632 (quirk Q2 kept)
+                if (r.x - L.xE[r.ix - 1] <= 0.0f && r.dx > 0.0f) {
+                  r.x = r.x - spacingf(r.x);
+                  r.ix = r.ix - 1;
+                  if (r.ix <= 0) { r.ix = P.nx; r.x = L.xE[r.ix - 1]; r.x = r.x - 2.0f * spacingf(r.x); }
+                }
+                if (r.y - L.yE[r.iy - 1] <= 0.0f && r.dy > 0.0f) {
+                  r.y = r.y - spacingf(r.y);
+                  r.iy = r.iy - 1;
+                  if (r.iy <= 0) { r.iy = P.ny; r.y = L.xE[r.iy - 1]; r.y = r.x - 2.0f * spacingf(r.y); }
+                }
+                if (r.z - L.zE[r.iz - 1] <= 0.0f && r.dz > 0.0f) { r.z = r.z - spacingf(r.z); r.iz = r.iz - 1; }
+                cell = cell_index(P, r.ix, r.iy, r.iz);
+              }
+              const float rc = rng.next();                                // :637-638
+              int comp = 1;
+              if (P.ncomp > 1) {
+                const float *cum = P.cumExt + cell;
+                comp = find_index(rc, [cum, ncell](int k) { return k == 1 ? 0.0f : cum[(size_t)(k - 2) * ncell]; },
+                                  P.ncomp + 1, 0);
+              }
+              const float ssa = P.ssa[(size_t)(comp - 1) * ncell + cell];
+              if (ssa < 1.0f) {                                           // :642-649
+                tally.absorbed((r.iy - 1) * P.nx + (r.ix - 1), cell, w * (1.0f - ssa));
+                w = w * ssa;
+              }
+              if (INTENSITY)
+                intensity_contribution(P, L, rng, cnt, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, comp, order);
+              if (P.useRR && w < 0.5f) {                                  // :673-680
+                cnt.roul++;
+                if (rng.next() >= w / 1.0f) w = 0.0f; else w = 1.0f;
+              }
+              if (w <= kTiny) { fate = 2; st = ST_NEW; }
+              else {
+                const int pfi = P.pfIndex[(size_t)(comp - 1) * ncell + cell];
+                const int n = P.comp[comp - 1].nInv;
+                const float theta = scattering_angle(rng.next(), P.comp[comp - 1].inv + (size_t)(pfi - 1) * n, n);
+                next_direct(rng, cosf(theta), r.dx, r.dy, r.dz);          // :684-687
+                st = ST_TRACE;
+              }
+            } else {
+              st = ST_TRACE;
+            }
+          }
+        }
+        if (st == ST_NEW) {
+          if (pid >= 0 && A.fate) {
+            A.fate[pid] = fate; A.fateColumn[pid] = fateCol; A.fateWeight[pid] = fateW; A.fateOrder[pid] = order;
+            A.drawsUsed[pid] = (int32_t)rng.draws;
+          }
+          if (pid >= 0) cnt.draws += rng.draws;
+          const long long next = (long long)atomicAdd(A.workCounter, 1ull);
+          if (next >= A.nPhotons) { st = ST_DONE; pid = -1; }
+          else {                                                          // :453-470
+            pid = next;
+            RngInit<Rng>::start(rng, A, pid);
+            float px, py, pz, mu, phi;
+            if (A.srcKind == 0) {   // newPhotonStream_Directional, Code/monteCarloIllumination.f95:91-99
+              px = rng.next(); py = rng.next();
+              pz = 1.0f - spacingf(1.0f);
+              mu = A.solarMu; phi = A.solarPhi;
+            } else {
+              px = A.sx[pid]; py = A.sy[pid]; pz = A.sz[pid]; mu = A.smu[pid]; phi = A.sphi[pid];
+            }
+            order = 0; fate = -1; fateCol = -1; fateW = 0.0f;
+            make_dircos(mu, phi, r.dx, r.dy, r.dz);
+            w = 1.0f;
+            cnt.photons++;
+            r.x = P.x0 + px * (P.xMax - P.x0);
+            r.y = P.y0 + py * (P.yMax - P.y0);
+            r.z = P.z0 + pz * (P.zMax - P.z0);
+            r.ix = 1; r.iy = 1; r.iz = 1;
+            find_xy(P, L, r.x, r.y, r.ix, r.iy);
+            find_z(P, L, r.z, r.iz);
+            st = ST_TRACE;
+          }
+        }
+        if (st == ST_TRACE) {                                             // :480
+          const float tau = -logf(fmaxf(kTiny, rng.next()));
+          r.acc = 0.0f; r.target = tau;
+          if (P.useRayTracing) cnt.calls++;
+          else {                                                          // :494-496 max cross-section move
+            r.x = make_periodic(r.x + r.dx * tau / P.maxExt, P.x0, P.xMax);
+            r.y = make_periodic(r.y + r.dy * tau / P.maxExt, P.y0, P.yMax);
+            r.z = r.z + r.dz * tau / P.maxExt;
+            st = ST_EVENT;
+          }
+        }
+      }
+    }
+    // ---------------------------------------------------------------- VOXEL-STEP phase
+    if (st == ST_TRACE) {
+      cnt.steps++;
+      const StepResult s = trace_step(P, L, r, true);
+      if (s == STEP_DONE) st = ST_EVENT;
+      else if (s == STEP_ERROR) st = ST_DROPPED;
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue: flush tallies + counters
+  __syncthreads();
+  if (P.ldsTallies) {
+    const int ncol = P.nx * P.ny;
+    for (int i = threadIdx.x; i < ncol; i += blockDim.x) {
+      const float u = L.tUp[i], d = L.tDown[i], a = L.tAbs[i];
+      if (u != 0.0f) add_global(P.tally + P.oUp + i, u);
+      if (d != 0.0f) add_global(P.tally + P.oDown + i, d);
+      if (a != 0.0f) add_global(P.tally + P.oAbs + i, a);
+    }
+  }
+  const double c[10] = {(double)cnt.photons, (double)cnt.dropped, (double)cnt.steps, (double)cnt.scat, (double)cnt.surf,
+                        (double)cnt.top, (double)cnt.roul, (double)cnt.shadow, (double)(cnt.calls), (double)cnt.draws};
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    const double s = wave_sum(c[k]);
+    if ((threadIdx.x & 63) == 0 && s != 0.0) unsafeAtomicAdd(P.tally + P.oCnt + k, s);
+  }
+}
+
+// Test hook: independent tracer calls, one ray per thread.
+__global__ void __launch_bounds__(256) trace_rays_kernel(const DevProblem P, long long n, const float *dir, float *pos,
+                                                         int32_t *idx, const float *target, float *tau, int32_t *steps) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  Lds L;
+  L.xE = smem; L.yE = L.xE + P.nx + 1; L.zE = L.yE + P.ny + 1;
+  L.tUp = L.tDown = L.tAbs = L.ext = L.dirCos = nullptr;
+  for (int i = threadIdx.x; i <= P.nx; i += blockDim.x) L.xE[i] = P.xE[i];
+  for (int i = threadIdx.x; i <= P.ny; i += blockDim.x) L.yE[i] = P.yE[i];
+  for (int i = threadIdx.x; i <= P.nz; i += blockDim.x) L.zE[i] = P.zE[i];
+  __syncthreads();
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Ray r;
+  r.x = pos[3 * i]; r.y = pos[3 * i + 1]; r.z = pos[3 * i + 2];
+  r.dx = dir[3 * i]; r.dy = dir[3 * i + 1]; r.dz = dir[3 * i + 2];
+  r.ix = idx[3 * i]; r.iy = idx[3 * i + 1]; r.iz = idx[3 * i + 2];
+  r.acc = 0.0f;
+  const bool hasTarget = target[i] >= 0.0f;
+  r.target = target[i];
+  int ns = 0;
+  StepResult s;
+  do { ns++; s = trace_step(P, L, r, hasTarget); } while (s == STEP_CONTINUE && ns < (1 << 24));
+  pos[3 * i] = r.x; pos[3 * i + 1] = r.y; pos[3 * i + 2] = r.z;
+  idx[3 * i] = r.ix; idx[3 * i + 1] = r.iy; idx[3 * i + 2] = r.iz;
+  tau[i] = r.acc;
+  steps[i] = ns;
+}
+
+// Test hook: raw Philox blocks as the photon streams see them.
+__global__ void philox_kernel(uint32_t seed0, uint32_t seed1, long long firstPhoton, long long n, int blocksPerPhoton,
+                              uint32_t *out, float *outf) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  PhiloxStream g;
+  g.start(seed0, seed1, (uint64_t)(firstPhoton + i));
+  for (int b = 0; b < blocksPerPhoton; ++b) {
+    const Philox4 o = philox4x32_10(g.id_lo, g.id_hi, (uint32_t)b, 0u, seed0, seed1);
+    for (int k = 0; k < 4; ++k) {
+      out[(i * blocksPerPhoton + b) * 4 + k] = o.v[k];
+      outf[(i * blocksPerPhoton + b) * 4 + k] = g.next();
+    }
+  }
+}
+
+}  // namespace i3rc

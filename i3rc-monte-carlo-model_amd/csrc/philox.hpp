@@ -1,0 +1,82 @@
+// Philox4x32-10 counter-based RNG (Salmon, Moraes, Dror, Shaw, SC'11), one stream per photon.
+//   key     = (seed0, seed1)            -- the driver's seed = (/iseed, batch/) (monteCarloDriver.f95:277)
+//   counter = (photon_lo, photon_hi, block, 0)
+// Deviates are converted exactly as the reference's getRandomReal does (Code/RandomNumbersForMC.f95:275-299):
+//   real( dble(unsigned 32-bit int) / (2**32 - 1) )  in [0, 1], both ends reachable.
+// (float)((double)u * (1.0 / 4294967295.0)) equals that quotient for every one of the 2^32 inputs
+// (checked exhaustively on the host), and avoids a float64 divide per deviate.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace i3rc {
+
+struct Philox4 { uint32_t v[4]; };
+
+__host__ __device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                 uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)M0 * c0;
+    const uint64_t p1 = (uint64_t)M1 * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += W0;
+    k1 += W1;
+  }
+  Philox4 o;
+  o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+  return o;
+}
+
+__host__ __device__ inline float u32_to_unit_float(uint32_t u) {
+  return (float)((double)u * (1.0 / 4294967295.0));
+}
+
+// Per-lane stream with a 4-deep buffer held in registers (no dynamic register indexing).
+struct PhiloxStream {
+  uint32_t k0, k1, id_lo, id_hi, block;
+  uint32_t b1, b2, b3;  // buffered outputs 1..3 of the current block
+  int have;             // how many of b1..b3 are still unused (3,2,1,0)
+  uint32_t draws;
+
+  __device__ inline void start(uint32_t seed0, uint32_t seed1, uint64_t photon) {
+    k0 = seed0; k1 = seed1;
+    id_lo = (uint32_t)photon; id_hi = (uint32_t)(photon >> 32);
+    block = 0; have = 0; draws = 0; b1 = b2 = b3 = 0;
+  }
+  __device__ inline float next() {
+    uint32_t u;
+    if (have == 0) {
+      Philox4 o = philox4x32_10(id_lo, id_hi, block, 0u, k0, k1);
+      block++;
+      u = o.v[0]; b1 = o.v[1]; b2 = o.v[2]; b3 = o.v[3];
+      have = 3;
+    } else {
+      u = have == 3 ? b1 : (have == 2 ? b2 : b3);
+      have--;
+    }
+    draws++;
+    return u32_to_unit_float(u);
+  }
+};
+
+// Test stream: deviates come from a buffer (the reference's MT19937 floats); see i3rc_hip_run_replay.
+struct ReplayStream {
+  const float *buf;
+  int64_t pos, end;
+  uint32_t draws;
+  __device__ inline void start(const float *b, int64_t p, int64_t e) { buf = b; pos = p; end = e; draws = 0; }
+  __device__ inline float next() {
+    float r = pos < end ? buf[pos] : 0.5f;
+    pos++; draws++;
+    return r;
+  }
+};
+
+}  // namespace i3rc

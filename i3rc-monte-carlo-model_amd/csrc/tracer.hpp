@@ -1,0 +1,251 @@
+// Device-side photon tracer for gfx950 (CDNA4): the per-photon physics of
+// Integrators/monteCarloRadiativeTransfer.f95 computeRT (:400-707) and the procedures it calls in the loop.
+// float32 arithmetic in the reference's operator order (the build uses -ffp-contract=off), 1-based cell
+// indices, so that the "step <= 0 => drop photon" escape, the 2*spacing() snaps and the periodic nudges
+// (quirks Q2-Q5 of SURVEY.md 8a) behave exactly as they do on the CPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+#include "../../include/i3rc_hip.h"
+#include "philox.hpp"
+
+namespace i3rc {
+
+constexpr float kTiny = FLT_MIN;
+constexpr float kHuge = FLT_MAX;
+constexpr float kPi   = 3.14159265358979312f;  // monteCarloRadiativeTransfer.f95:43 (rounded to real(4))
+
+// Per-component phase-function tables (:100-105): inverse [nEntries][nInv], forward [nEntries][nFwd].
+struct CompTables {
+  const float *inv, *fwd, *fwdOrig;
+  int nInv, nFwd;
+};
+
+// Everything the kernel reads, by value in the kernarg segment (wave-uniform -> SGPRs).
+struct DevProblem {
+  int nx, ny, nz, ncomp;
+  int xyRegular, zRegular;
+  float x0, y0, z0, xMax, yMax, zMax, deltaX, deltaY, deltaZ;
+  const float *xE, *yE, *zE;          // n+1 each (global; staged to LDS by every workgroup)
+  const float *totalExt;              // [nz][ny][nx]
+  const float *cumExt, *ssa;          // [ncomp][nz][ny][nx]
+  const int32_t *pfIndex;             // [ncomp][nz][ny][nx]
+  const CompTables *comp;             // [ncomp] phase-function tables (device memory: indexed per lane)
+  // surface
+  float albedo; int useBDRF; int nxs, nys;
+  const float *xsE, *ysE, *brdf;
+  // switches
+  int useRayTracing, useRR, nDir, useHybrid, numOrdersOrig, useRRI, limitContrib;
+  float zetaMin, maxContrib, maxExt;
+  const float *dirCos;                // [nDir][3] (global; staged to LDS)
+  // tallies (float64, packed; offsets in elements)
+  double *tally;
+  long long oUp, oDown, oAbs, oVol, oInt, oExc, oCnt;
+  int ldsTallies;                     // 1: fluxUp/Down/Absorbed privatised in LDS (ncol small)
+  int ldsGrid;                        // 1: totalExt staged in LDS
+};
+
+struct RunArgs {
+  uint32_t seed0, seed1;
+  long long firstPhoton, nPhotons;
+  unsigned long long *workCounter;    // device word, zeroed before launch
+  int srcKind; float solarMu, solarPhi;
+  const float *sx, *sy, *sz, *smu, *sphi;   // explicit stream (device)
+  // replay
+  const float *randoms; long long nRandoms; const long long *drawStart;
+  int32_t *fate, *fateColumn; float *fateWeight; int32_t *fateOrder, *drawsUsed;
+};
+
+// LDS carve-up shared by all device functions (offsets in floats from the dynamic LDS base).
+struct Lds {
+  float *xE, *yE, *zE;    // edges
+  float *tUp, *tDown, *tAbs;  // privatised flux tallies (valid when ldsTallies)
+  float *ext;             // totalExt copy (valid when ldsGrid)
+  float *dirCos;          // intensity directions
+};
+
+// Fortran SPACING() for real(4)
+__device__ __forceinline__ float spacingf(float x) {
+  const uint32_t e = __float_as_uint(x) & 0x7f800000u;
+  return e > (23u << 23) ? __uint_as_float(e - (23u << 23)) : kTiny;
+}
+
+// findIndex, Code/numericUtilities.f95:195-248 (1-based table; firstGuess <= 0: absent)
+template <class Tab>
+__device__ __forceinline__ int find_index(float value, Tab T, int n, int firstGuess) {
+  int lower, upper;
+  if (firstGuess > 0) {
+    lower = firstGuess;
+    int inc = 1;
+    for (;;) {
+      upper = min(lower + inc, n);
+      if (lower == n || (T(lower) <= value && T(upper) > value)) break;
+      if (T(lower) > value) { upper = lower; lower = max(upper - inc, 1); }
+      else lower = upper;
+      inc *= 2;
+    }
+  } else { lower = 0; upper = n; }
+  for (;;) {
+    if (lower == n || upper <= lower + 1) break;
+    const int mid = (lower + upper) / 2;
+    if (value >= T(mid)) lower = mid; else upper = mid;
+  }
+  return lower;
+}
+
+// makePeriodic :2063-2082
+__device__ __forceinline__ float make_periodic(float a, float aMin, float aMax) {
+  for (;;) {
+    if (a <= aMax && a > aMin) break;
+    if (a > aMax) a = a - (aMax - aMin);
+    else if (a == aMin) a = aMax;
+    else a = a + (aMax - aMin);
+  }
+  return a;
+}
+
+// makeDirectionCosines :2041-2059
+__device__ __forceinline__ void make_dircos(float mu, float phi, float &dx, float &dy, float &dz) {
+  const float sinTheta = sqrtf(1.0f - mu * mu);
+  const float c = cosf(phi), s = sinf(phi);
+  dx = sinTheta * c; dy = sinTheta * s; dz = mu;
+}
+
+struct Ray {
+  float x, y, z;
+  float dx, dy, dz;
+  int ix, iy, iz;
+  float acc, target;
+};
+
+enum StepResult { STEP_CONTINUE = 0, STEP_DONE = 1, STEP_ERROR = 2 };
+
+__device__ __forceinline__ size_t cell_index(const DevProblem &P, int ix, int iy, int iz) {
+  return ((size_t)(iz - 1) * P.ny + (size_t)(iy - 1)) * P.nx + (size_t)(ix - 1);
+}
+
+// One iteration of accumulationLoop, accumulateExtinctionAlongPath :1690-1806.
+// hasTarget == false: trace to the boundary.
+__device__ __forceinline__ StepResult trace_step(const DevProblem &P, const Lds &L, Ray &r, bool hasTarget) {
+  const int sx = r.dx >= 0.0f ? 1 : 0, sy = r.dy >= 0.0f ? 1 : 0, sz = r.dz >= 0.0f ? 1 : 0;
+  const int cx = r.dx >= 0.0f ? 1 : -1, cy = r.dy >= 0.0f ? 1 : -1, cz = r.dz >= 0.0f ? 1 : -1;
+  const float ex = L.xE[r.ix + sx - 1], ey = L.yE[r.iy + sy - 1], ez = L.zE[r.iz + sz - 1];
+  const float stx = fabsf(r.dx) >= 2.0f * kTiny ? (ex - r.x) / r.dx : kHuge;
+  const float sty = fabsf(r.dy) >= 2.0f * kTiny ? (ey - r.y) / r.dy : kHuge;
+  const float stz = fabsf(r.dz) >= 2.0f * kTiny ? (ez - r.z) / r.dz : kHuge;
+  float step = stx;
+  if (sty < step) step = sty;
+  if (stz < step) step = stz;
+  if (step <= 0.0f) { r.acc = -2.0f; return STEP_ERROR; }
+
+  const size_t cell = cell_index(P, r.ix, r.iy, r.iz);
+  const float ext = P.ldsGrid ? L.ext[cell] : P.totalExt[cell];
+  if (hasTarget) {
+    if (r.acc + step * ext > r.target) {
+      step = (r.target - r.acc) / ext;
+      r.x = r.x + step * r.dx;
+      r.y = r.y + step * r.dy;
+      r.z = r.z + step * r.dz;
+      r.acc = r.target;
+      return STEP_DONE;
+    }
+  }
+  r.acc = r.acc + step * ext;
+
+  if (stx <= step) { r.x = ex; r.ix += cx; }
+  else { r.x = r.x + step * r.dx; if (fabsf(ex - r.x) <= 2.0f * spacingf(r.x)) r.ix += cx; }
+  if (sty <= step) { r.y = ey; r.iy += cy; }
+  else { r.y = r.y + step * r.dy; if (fabsf(ey - r.y) <= 2.0f * spacingf(r.y)) r.iy += cy; }
+  if (stz <= step) { r.z = ez; r.iz += cz; }
+  else { r.z = r.z + step * r.dz; if (fabsf(ez - r.z) <= 2.0f * spacingf(r.z)) r.iz += cz; }
+
+  // periodic wrap :1774-1788 (y uses x's sign, as the reference does)
+  const float nudge = (float)(cx * 2);
+  if (r.ix <= 0) { r.ix = P.nx; r.x = P.xMax + nudge * spacingf(r.x); }
+  else if (r.ix >= P.nx + 1) { r.ix = 1; r.x = P.x0 + nudge * spacingf(r.x); }
+  if (r.iy <= 0) { r.iy = P.ny; r.y = P.yMax + nudge * spacingf(r.y); }
+  else if (r.iy >= P.ny + 1) { r.iy = 1; r.y = P.y0 + nudge * spacingf(r.y); }
+
+  if (r.iz > P.nz) { r.z = P.zMax + 2.0f * spacingf(P.zMax); return STEP_DONE; }
+  if (r.iz < 1) { r.z = P.z0; return STEP_DONE; }
+  return STEP_CONTINUE;
+}
+
+// findXYIndicies :1353-1374, findZIndex :1376-1388
+__device__ __forceinline__ void find_xy(const DevProblem &P, const Lds &L, float x, float y, int &ix, int &iy) {
+  if (P.xyRegular) {
+    int i = min((int)((x - P.x0) / P.deltaX) + 1, P.nx);
+    int j = min((int)((y - P.y0) / P.deltaY) + 1, P.ny);
+    if (fabsf(L.xE[i] - x) < spacingf(x)) i = i + 1;
+    if (fabsf(L.yE[j] - y) < spacingf(y)) j = j + 1;
+    if (i == P.nx + 1) i = 1;
+    if (j == P.ny + 1) j = 1;
+    ix = i; iy = j;
+  } else {
+    const float *xe = L.xE, *ye = L.yE;
+    ix = find_index(x, [xe](int k) { return xe[k - 1]; }, P.nx + 1, ix);
+    iy = find_index(y, [ye](int k) { return ye[k - 1]; }, P.ny + 1, iy);
+  }
+}
+__device__ __forceinline__ void find_z(const DevProblem &P, const Lds &L, float z, int &iz) {
+  if (P.zRegular) {
+    int k = min((int)((z - P.z0) / P.deltaZ) + 1, P.nz);
+    if (fabsf(L.zE[k] - z) < spacingf(z)) k = k + 1;
+    iz = k;
+  } else {
+    const float *ze = L.zE;
+    iz = find_index(z, [ze](int k) { return ze[k - 1]; }, P.nz + 1, iz);
+  }
+}
+
+// computeScatteringAngle :1390-1417 (quirk Q1: `left` is not rescaled by n)
+__device__ __forceinline__ float scattering_angle(float r, const float *tab, int n) {
+  const int k = (int)(r * (float)n) + 1;
+  if (k < n) {
+    const float left = r - (float)(k - 1) / (float)n;
+    return (1.0f - left) * tab[k - 1] + left * tab[k];
+  }
+  return tab[n - 1];
+}
+
+// next_direct :2086-2113
+template <class Rng>
+__device__ __forceinline__ void next_direct(Rng &rng, float cosS, float &s0, float &s1, float &s2) {
+  float d = 2.0f, ax = 0.0f, ay = 0.0f;
+  while (d > 1.0f) {
+    ax = 1.0f - 2.0f * rng.next();
+    ay = 1.0f - 2.0f * rng.next();
+    d = ax * ax + ay * ay;
+  }
+  float b = sqrtf((1.0f - cosS * cosS) / d);
+  ax = ax * b;
+  ay = ay * b;
+  b = s0 * ax - s1 * ay;
+  d = cosS - b / (1.0f + fabsf(s2));
+  s0 = s0 * d + ax;
+  s1 = s1 * d - ay;
+  s2 = s2 * cosS - copysignf(fabsf(b), s2 * b);
+}
+
+// lookUpPhaseFuncValsFromTable :1613-1652
+__device__ __forceinline__ float lookup_phase(const float *tab, int n, float angle) {
+  const float dTheta = kPi / (float)(n - 1);
+  const int k = (int)(angle / dTheta) + 1;
+  if (k < n) {
+    const float w = 1.0f - (angle - (float)(k - 1) * dTheta) / dTheta;
+    return w * tab[k - 1] + (1.0f - w) * tab[k];
+  }
+  return tab[n - 1];
+}
+
+// computeSurfaceReflectance, Code/surfaceProperties.f95:121-148, with the Lambertian R (:154-162)
+__device__ __forceinline__ float surface_reflectance(const DevProblem &P, float x, float y) {
+  const float *xs = P.xsE, *ys = P.ysE;
+  const int ix = find_index(make_periodic(x, xs[0], xs[P.nxs]), [xs](int k) { return xs[k - 1]; }, P.nxs + 1, 0);
+  const int iy = find_index(make_periodic(y, ys[0], ys[P.nys]), [ys](int k) { return ys[k - 1]; }, P.nys + 1, 0);
+  return P.brdf[(size_t)(iy - 1) * P.nxs + (ix - 1)];
+}
+
+}  // namespace i3rc

@@ -1,0 +1,191 @@
+/*
+ * include/i3rc_hip.h -- C ABI of the MI355X (gfx950) photon-tracing integrator.
+ *
+ * Drop-in boundary for the hot path of the I3RC community Monte Carlo model:
+ *   Integrators/monteCarloRadiativeTransfer.f95  computeRadiativeTransfer (:262-398) -> computeRT (:400-707)
+ * The reference has no FFI; its boundary is the Fortran-95 module `monteCarloRadiativeTransfer`.  The
+ * Fortran shell in i3rc-monte-carlo-model_amd/fortran/ keeps that module API and calls these entry points
+ * through iso_c_binding; Python tests and bench.py bind them with ctypes.
+ *
+ * Conventions
+ *   - return 0 on success, non-zero on failure; i3rc_hip_last_error() gives the text the shell hands to
+ *     setStateToFailure (Code/ErrorMessages.f95:159-233).
+ *   - host arrays are borrowed for the duration of the call only; device state is owned by the handle.
+ *   - grids are x-fastest: cell (ix,iy,iz) 1-based  ->  [(iz-1)*ny + (iy-1)]*nx + (ix-1); per-component
+ *     arrays add a slowest component axis (Fortran (nx,ny,nz,ncomp) column-major, passed as is).
+ *   - tallies come back RAW (un-normalised sums over photons) in float64; the caller applies the
+ *     normalisation of computeRadiativeTransfer :353-395 (the shell does; so does i3rc_hip_normalise).
+ *   - no torch types, no C++ types: plain pointers and sizes.
+ */
+#ifndef I3RC_HIP_H
+#define I3RC_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct i3rc_hip_integrator i3rc_hip_integrator;
+
+#define I3RC_MAX_COMPONENTS 8
+#define I3RC_MAX_DIRECTIONS 20 /* Example-Drivers/monteCarloDriver.f95:63 maxNumRad */
+
+/* Algorithm switches and scalars: the private components of type(integrator)
+ * (monteCarloRadiativeTransfer.f95:50-142) that specifyParameters (:830-1069) sets. */
+typedef struct i3rc_params {
+  float   surfaceAlbedo;                   /* :70  used when useSurfaceBDRF == 0 */
+  int32_t useSurfaceBDRF;                  /* :83  BRDF grid given by i3rc_hip_set_surface */
+  int32_t useRayTracing;                   /* :63  1 = photon tracing (0 = max cross-section) */
+  int32_t useRussianRoulette;              /* :65  RussianRouletteW fixed at 1 (:66) */
+  int32_t useHybridPhaseFunsForIntenCalcs; /* :118 */
+  int32_t numOrdersOrigPhaseFunIntenCalcs; /* :120 */
+  int32_t useRussianRouletteForIntensity;  /* :123 */
+  float   zetaMin;                         /* :124 */
+  int32_t limitIntensityContributions;     /* :127 */
+  float   maxIntensityContribution;        /* :128 */
+} i3rc_params;
+
+/* Photon source for one batch: what new_PhotonStream (Code/monteCarloIllumination.f95:46-50) encodes. */
+typedef struct i3rc_source {
+  int32_t kind;          /* 0 = Directional generated on device (newPhotonStream_Directional :62-104);
+                            1 = explicit stream: host arrays x,y,z (0..1), mu, phi (radians), n each */
+  float   solarMu;       /* kind 0: as passed to new_PhotonStream (sign ignored: mu = -abs(solarMu)) */
+  float   solarAzimuth;  /* kind 0: degrees */
+  const float *x, *y, *z, *mu, *phi; /* kind 1 */
+} i3rc_source;
+
+/* Counter block appended to the tallies (float64 so the whole buffer reduces with one all-reduce). */
+enum {
+  I3RC_CNT_PHOTONS = 0,   /* photons started (numPhotonsProcessed, :459) */
+  I3RC_CNT_DROPPED,       /* tracer-error drops (nBad, :488) */
+  I3RC_CNT_CELL_STEPS,    /* accumulateExtinctionAlongPath iterations, photon paths */
+  I3RC_CNT_SCATTERINGS,   /* scattering events (:591) */
+  I3RC_CNT_SURFACE_HITS,  /* fluxDown tallies (:531) */
+  I3RC_CNT_EXITS_TOP,     /* fluxUp tallies (:513) */
+  I3RC_CNT_ROULETTE,      /* roulette plays (:673) */
+  I3RC_CNT_SHADOW_STEPS,  /* tracer iterations spent in local-estimate rays (:1517-1595) */
+  I3RC_CNT_TRACER_CALLS,  /* calls of the tracer, all kinds */
+  I3RC_CNT_RNG_DRAWS,     /* uniform deviates consumed */
+  I3RC_NUM_COUNTERS = 16
+};
+
+/* Layout (in float64 elements) of the packed tally buffer of a handle. */
+typedef struct i3rc_tally_layout {
+  int64_t fluxUp, fluxDown, fluxAbsorbed; /* offsets; nx*ny each                          (:135-136) */
+  int64_t volumeAbsorption;               /* nx*ny*nz                                      (:137)     */
+  int64_t intensityByComponent;           /* (ncomp+1)*nDir*nx*ny, component 0 = surface   (:139-140) */
+  int64_t intensityExcess;                /* (ncomp+1)*nDir                                (:130)     */
+  int64_t counters;                       /* I3RC_NUM_COUNTERS                                        */
+  int64_t total;                          /* number of float64 elements                               */
+} i3rc_tally_layout;
+
+/* ---- lifetime -------------------------------------------------------------------------------------- */
+
+/* new_Integrator (:162-254): deep-copies the optical-property grids to `device`.
+ * totalExt[nz][ny][nx]; cumExt/ssa/pfIndex [ncomp][nz][ny][nx] as produced by
+ * getOpticalPropertiesByComponent (Code/opticalProperties.f95:429-539) incl. the 1+spacing(1.) nudge (:233). */
+int i3rc_hip_create(i3rc_hip_integrator **h, int device, int nx, int ny, int nz, int ncomp,
+                    const float *xEdges, const float *yEdges, const float *zEdges,
+                    const float *totalExt, const float *cumExt, const float *ssa, const int32_t *pfIndex);
+
+/* finalize_Integrator (:1258-1349) */
+int i3rc_hip_destroy(i3rc_hip_integrator *h);
+
+const char *i3rc_hip_last_error(const i3rc_hip_integrator *h); /* h may be NULL: error of the last failed create */
+
+/* ---- setup ----------------------------------------------------------------------------------------- */
+
+/* inversePhaseFunctions(comp)%values(nSteps, nEntries) (:104-105, built by tabulateInversePhaseFunctions
+ * :1809-1861); comp is 1-based; t is [nEntries][nSteps]. */
+int i3rc_hip_set_inverse_table(i3rc_hip_integrator *h, int comp, int nSteps, int nEntries, const float *t);
+
+/* tabulatedPhaseFunctions / tabulatedOrigPhaseFunctions (:100-103, :1863-1923); orig may equal hybrid. */
+int i3rc_hip_set_forward_tables(i3rc_hip_integrator *h, int comp, int nSteps, int nEntries,
+                                const float *hybrid, const float *orig);
+
+/* specifyParameters (:830-1069), scalar switches */
+int i3rc_hip_set_params(i3rc_hip_integrator *h, const i3rc_params *p);
+
+/* specifyParameters(surfaceBDRF=) (:954-956): Lambertian albedo grid brdf[nys][nxs] on its own edges
+ * (Code/surfaceProperties.f95:34-38; uniform surface = 1x1 with edges (0, huge) :98-117). */
+int i3rc_hip_set_surface(i3rc_hip_integrator *h, int nxs, int nys, const float *xsEdges, const float *ysEdges,
+                         const float *brdf);
+
+/* specifyParameters(intensityMus=, intensityPhis=) (:1026-1045): dirCos[nDir][3] already converted with
+ * makeDirectionCosines (:2041-2059).  nDir = 0 switches computeIntensity off. */
+int i3rc_hip_set_directions(i3rc_hip_integrator *h, int nDir, const float *dirCos);
+
+/* ---- tallies --------------------------------------------------------------------------------------- */
+
+int i3rc_hip_get_tally_layout(const i3rc_hip_integrator *h, i3rc_tally_layout *layout);
+
+/* Optional: accumulate into caller-owned DEVICE memory (e.g. a torch tensor handed to RCCL) of at least
+ * layout.total float64 elements.  NULL restores the handle's own buffer. */
+int i3rc_hip_bind_tally_buffer(i3rc_hip_integrator *h, void *devicePtr, size_t bytes);
+
+/* Run on this HIP stream (hipStream_t as void*); NULL = the handle's own stream. */
+int i3rc_hip_set_stream(i3rc_hip_integrator *h, void *hipStream);
+
+/* computeRadiativeTransfer :296-309: zero all tallies and counters (asynchronous on the stream). */
+int i3rc_hip_zero_tallies(i3rc_hip_integrator *h);
+
+/* ---- the hot path ---------------------------------------------------------------------------------- */
+
+/* computeRT (:400-707) for one batch of nPhotons, ASYNCHRONOUS on the handle's stream; tallies accumulate.
+ * RNG: per-photon Philox4x32-10 stream keyed by (seed0, seed1) -- the driver's seed=(/iseed, batch/)
+ * (Example-Drivers/monteCarloDriver.f95:277) -- with the photon's index (firstPhoton + i) as counter, so a
+ * photon's trajectory does not depend on how batches are split across launches or GPUs. */
+int i3rc_hip_launch_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int64_t firstPhoton,
+                          int64_t nPhotons, const i3rc_source *src);
+
+/* Test hook: same kernel, but every uniform deviate is read from `randoms` (float32, e.g. the reference's
+ * MT19937 stream): photon i consumes randoms[drawStart[i]], randoms[drawStart[i]+1], ... in the reference's
+ * draw order.  Optional per-photon outputs (host arrays of n, may be NULL):
+ * fate (0 exit top, 1 died at surface, 2 roulette kill, 3 dropped), last flux column, its weight, order,
+ * number of deviates consumed.  Synchronous. */
+int i3rc_hip_run_replay(i3rc_hip_integrator *h, int64_t nPhotons, const i3rc_source *src,
+                        const float *randoms, int64_t nRandoms, const int64_t *drawStart,
+                        int32_t *fate, int32_t *fateColumn, float *fateWeight, int32_t *fateOrder,
+                        int32_t *drawsUsed);
+
+/* Test hook: nRays independent calls of accumulateExtinctionAlongPath (:1654-1807) on the device.
+ * pos/dir [nRays][3], idx [nRays][3] (1-based) in/out; target[nRays] (<0: trace to the boundary);
+ * tau[nRays] out (-2 = tracer error), steps[nRays] out.  Synchronous. */
+int i3rc_hip_trace_rays(i3rc_hip_integrator *h, int64_t nRays, const float *dir, float *pos, int32_t *idx,
+                        const float *target, float *tau, int32_t *steps);
+
+/* Wait for the stream; copy the packed tally buffer (layout.total float64) to the host. */
+int i3rc_hip_synchronize(i3rc_hip_integrator *h);
+int i3rc_hip_fetch_tallies(i3rc_hip_integrator *h, double *hostTallies);
+
+/* computeRadiativeTransfer :327-395 on a host copy of the packed tallies: redistribute intensityExcess,
+ * divide by photons per column (regular grid: N/(nx*ny), else column-area weighted), volumeAbsorption also
+ * by layer depth.  Output float32 arrays (any may be NULL) in reportResults' shapes (:711-826):
+ * fluxUp/fluxDown/fluxAbsorbed [ny][nx], volumeAbsorption [nz][ny][nx], intensity [nDir][ny][nx],
+ * intensityByComponent [ncomp+1][nDir][ny][nx]. */
+int i3rc_hip_normalise(const i3rc_hip_integrator *h, const double *hostTallies,
+                       float *fluxUp, float *fluxDown, float *fluxAbsorbed, float *volumeAbsorption,
+                       float *intensity, float *intensityByComponent);
+
+/* Timing of the most recent i3rc_hip_launch_batch, measured with HIP events on the launch stream.
+ * Synchronises.  Returns milliseconds in *ms. */
+int i3rc_hip_last_kernel_ms(i3rc_hip_integrator *h, float *ms);
+
+/* Experiment knobs (not part of the reference API): lanes that must be waiting before a wavefront runs its
+ * event phase (1..64, default 32) and workgroups per CU (0 = occupancy query). */
+int i3rc_hip_set_tuning(i3rc_hip_integrator *h, int evThreshold, int blocksPerCU);
+
+/* Test hook: the raw Philox4x32-10 blocks (out[n][blocksPerPhoton][4]) of photons firstPhoton..+n-1 and the
+ * float32 deviates the photon streams derive from them (outf, same shape). */
+int i3rc_hip_philox_blocks(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int64_t firstPhoton, int64_t n,
+                           int blocksPerPhoton, uint32_t *out, float *outf);
+
+/* Library / device probe that needs no GPU work: returns the number of HIP devices (or -1). */
+int i3rc_hip_device_count(void);
+const char *i3rc_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

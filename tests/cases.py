@@ -42,3 +42,16 @@ def step_cloud(ssa=1.0, nlayers=32, ncolumns=32):
     col = np.concatenate([np.full(ncolumns // 2, 2, np.float32), np.full(ncolumns // 2, 18, np.float32)]) / f32(250.0)
     ext = np.ascontiguousarray(np.broadcast_to(col[None, None, :], (nlayers, 1, ncolumns)), dtype=np.float32)
     return dict(xe=xe, ye=ye, ze=ze, ext=ext, ssa=np.full_like(ext, f32(ssa)), pf=np.ones(ext.shape, np.int32))
+
+
+def irregular_domain(seed=3, nx=7, ny=5, nz=9, ssa=0.95):
+    """Small irregularly spaced domain with empty cells: exercises findIndex paths and zero-extinction steps."""
+    rng = np.random.default_rng(seed)
+    xe = np.concatenate([[0.0], np.cumsum(rng.uniform(5, 40, nx))]).astype(np.float32)
+    ye = np.concatenate([[0.0], np.cumsum(rng.uniform(5, 40, ny))]).astype(np.float32)
+    ze = (np.concatenate([[0.0], np.cumsum(rng.uniform(5, 30, nz))]) + 100.0).astype(np.float32)
+    ext = rng.uniform(0.0, 0.08, (nz, ny, nx)).astype(np.float32)
+    ext[rng.random(ext.shape) < 0.3] = 0.0
+    pf = np.where(ext > 0, 1, 0).astype(np.int32)
+    s = np.where(ext > 0, f32(ssa), f32(0.0)).astype(np.float32)
+    return dict(xe=xe, ye=ye, ze=ze, ext=ext, ssa=s, pf=pf)

@@ -1,0 +1,148 @@
+"""CPU-only checks: C-ABI library exports, host-side table builders vs the oracle, domain expansion rules,
+Philox known answers."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import i3rc_monte_carlo_model_amd as M
+from tests import cases
+from tests.philox_ref import philox4x32_10
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    lib = M.build.build()
+    assert os.path.exists(lib)
+    L = ctypes.CDLL(lib)
+    header = open(os.path.join(ROOT, "include", "i3rc_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(i3rc_hip_[a-z_]+)\s*\(", header)))
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(L, name), name
+    assert sorted(M.binding.SYMBOLS) == declared
+    assert b"gfx950" in L.i3rc_hip_version.__class__(("i3rc_hip_version", L)).restype.__name__.encode() or True
+    L.i3rc_hip_version.restype = ctypes.c_char_p
+    assert b"gfx950" in L.i3rc_hip_version()
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors, philox4x32 10 rounds
+    assert philox4x32_10((0, 0, 0, 0), (0, 0)) == (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)
+    f = 0xFFFFFFFF
+    assert philox4x32_10((f, f, f, f), (f, f)) == (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)
+    assert philox4x32_10((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0)) == (
+        0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)
+
+
+def test_inverse_and_forward_tables_match_oracle(oracle):
+    hg = M.henyey_greenstein(0.85, 64)
+    assert np.array_equal(hg.legendre, cases.hg_coefficients(0.85, 64))
+    tab = M.PhaseFunctionTable([hg])
+    inv = tab.inverse_table(10001)[0]
+    ref = oracle.inverse_table_legendre(hg.legendre, 10001)
+    # numpy's float32 cos/acos differ from libm by an ulp: tolerance 2e-6 rad (table step is ~3e-4)
+    assert np.abs(inv - ref).max() <= 2e-6
+    assert inv[0] == ref[0] and inv[-1] == 0.0
+    fwd = tab.forward_table(10001)[0]
+    rf = oracle.forward_table_legendre(hg.legendre, 10001)
+    assert (np.abs(fwd - rf) / np.abs(rf)).max() < 1e-4
+    mus, w = M.phasefunctions.lobatto(64)
+    m2, w2 = oracle.lobatto(64)
+    assert np.array_equal(mus, m2) and np.array_equal(w, w2)
+    mus, w = M.phasefunctions.lobatto(7)
+    m2, w2 = oracle.lobatto(7)
+    assert np.array_equal(mus, m2) and np.array_equal(w, w2)
+
+
+def test_tabulated_phase_function_tables_match_oracle(oracle):
+    ang = np.linspace(0, 1, 901, dtype=np.float32) * np.float32(3.141592654)
+    val = ((1 - 0.7 ** 2) / (1 + 0.7 ** 2 - 2 * 0.7 * np.cos(ang.astype(np.float64))) ** 1.5).astype(np.float32)
+    p = M.PhaseFunction(angles=ang, values=val)
+    a = M.phasefunctions.inverse_phase_function(p, 9001)
+    b = oracle.inverse_table_tabulated(ang, val, 9001)
+    assert np.abs(a - b).max() <= 2e-6
+    fa = M.PhaseFunctionTable([p]).forward_table(9001)[0]
+    fb = oracle.forward_table_tabulated(ang, val, 9001)
+    assert (np.abs(fa - fb) / np.abs(fb)).max() < 1e-4
+    ha = M.phasefunctions.hybrid_phase_functions(fa, 7.0)
+    hb = oracle.hybrid_tables(fb, 7.0)
+    assert (np.abs(ha - hb) / np.abs(hb)).max() < 1e-3
+
+
+def test_hybrid_phase_function_replaces_forward_peak(oracle):
+    # HG g=0.85 has no crossing with a 7-degree Gaussian (the reference then keeps the original); a sharper
+    # peak (g=0.95) does.
+    hg = M.henyey_greenstein(0.85, 64)
+    fwd = M.PhaseFunctionTable([hg]).forward_table(9001)
+    assert np.array_equal(M.phasefunctions.hybrid_phase_functions(fwd, 7.0), fwd)
+    hg = M.henyey_greenstein(0.95, 299)
+    fwd = M.PhaseFunctionTable([hg]).forward_table(9001)
+    ha = M.phasefunctions.hybrid_phase_functions(fwd, 7.0)
+    hb = oracle.hybrid_tables(oracle.forward_table_legendre(hg.legendre, 9001), 7.0)
+    assert (np.abs(ha - hb) / np.abs(hb)).max() < 1e-3
+    assert ha[0, 0] < 0.8 * fwd[0, 0]          # the forward peak was flattened
+    assert np.array_equal(ha[0, 4000:], fwd[0, 4000:])  # the rest is untouched
+    mu = np.cos(np.linspace(0, np.pi, 9001))
+    assert abs(np.trapezoid(ha[0].astype(np.float64), -mu) - 2.0) < 2e-3  # still normalised
+
+
+def test_optical_properties_by_component_layout():
+    # one horizontally uniform component, one partial-height component
+    x = np.arange(0, 5, dtype=np.float32) * 10
+    y = np.arange(0, 4, dtype=np.float32) * 10
+    z = np.arange(0, 7, dtype=np.float32) * 5
+    d = M.new_Domain(x, y, z)
+    table = M.PhaseFunctionTable([M.henyey_greenstein(0.85, 8), M.henyey_greenstein(0.5, 8)])
+    rng = np.random.default_rng(1)
+    e3 = rng.uniform(0.0, 0.1, (3, 3, 4)).astype(np.float32)
+    d.addOpticalComponent("cloud", e3, np.full_like(e3, 0.9), np.full(e3.shape, 2, np.int32), table, zLevelBase=2)
+    e1 = np.array([0.01, 0.02, 0.0, 0.03, 0.04, 0.05], np.float32)
+    d.addOpticalComponent("gas", e1, np.full_like(e1, 0.5), np.array([1, 1, 0, 1, 1, 1], np.int32), table)
+    total, cum, ssa, pfi, tables = d.getOpticalPropertiesByComponent()
+    assert total.shape == (6, 3, 4) and cum.shape == (2, 6, 3, 4)
+    ext_a = np.zeros((6, 3, 4), np.float32)
+    ext_a[1:4] = e3
+    ext_b = np.broadcast_to(e1[:, None, None], (6, 3, 4))
+    assert np.allclose(total, ext_a + ext_b)
+    nz = total > 0
+    assert np.allclose(cum[1][nz], 1.0) and np.all(cum[:, ~nz] == 0)
+    assert np.allclose(cum[0][nz], (ext_a / np.where(nz, total, 1))[nz])
+    assert np.all(ssa[0, 0] == 0) and np.all(pfi[0, 0] == 0)  # component absent in layer 1
+    assert np.all(ssa[1, 2] == 0.5) and np.all(pfi[0, 1:4] == 2)
+    with pytest.raises(M.I3RCError):
+        d.addOpticalComponent("bad", e3, np.full_like(e3, 1.5), np.ones(e3.shape, np.int32), table)
+    with pytest.raises(M.I3RCError):
+        d.addOpticalComponent("bad", e3, np.full_like(e3, 0.5), np.ones(e3.shape, np.int32), table, zLevelBase=5)
+    with pytest.raises(M.I3RCError):
+        M.new_Domain(x[::-1], y, z)
+
+
+def test_photon_stream_and_surface_validation():
+    with pytest.raises(M.I3RCError):
+        M.new_PhotonStream(0.0, 0.0, 10)
+    with pytest.raises(M.I3RCError):
+        M.new_PhotonStream(0.5, 361.0, 10)
+    with pytest.raises(M.I3RCError):
+        M.new_PhotonStream(0.5, 0.0, 0)
+    s = M.new_PhotonStream(-0.5, 90.0, 7)
+    assert s.morePhotonsExist() and s.n == 7
+    with pytest.raises(M.I3RCError):
+        M.new_SurfaceDescription([1.5])
+    u = M.new_SurfaceDescription([0.2])
+    assert u.albedo.shape == (1, 1) and u.x[1] == np.finfo(np.float32).max
+
+
+def test_no_gpu_fails_loudly():
+    # On a box without a GPU the product path must refuse to run rather than fall back to the CPU.
+    L = M.binding.load()
+    if L.i3rc_hip_device_count() > 0:
+        pytest.skip("GPU present")
+    d = cases.step_cloud()
+    dom = M.new_Domain(d["xe"], d["ye"], d["ze"])
+    dom.addOpticalComponent("cloud", d["ext"], d["ssa"], d["pf"], M.PhaseFunctionTable([M.henyey_greenstein(0.85, 8)]))
+    with pytest.raises(M.I3RCError, match="no HIP device"):
+        M.new_Integrator(dom)
