@@ -64,10 +64,11 @@ struct i3rc_hip_integrator {
   DevBuf srcBuf[5];
 
   hipStream_t ownStream = nullptr, stream = nullptr;
-  hipEvent_t evStart = nullptr, evStop = nullptr;
-  bool timed = false;
+  static constexpr int kEventRing = 64;   // HIP-event pairs of the most recent timed launches
+  hipEvent_t evStart[kEventRing] = {}, evStop[kEventRing] = {};
+  long long timedLaunches = 0;
   int numCU = 256;
-  int evThreshold = 32;
+  int evThreshold = 64;
   int blocksPerCU = 0;  // 0 = from occupancy query
   std::string err;
 
@@ -180,8 +181,10 @@ int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int n
   CCHK(h->dDir.alloc(sizeof(float) * 3 * I3RC_MAX_DIRECTIONS));
   CCHK(hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking));
   h->stream = h->ownStream;
-  CCHK(hipEventCreate(&h->evStart));
-  CCHK(hipEventCreate(&h->evStop));
+  for (int i = 0; i < i3rc_hip_integrator::kEventRing; ++i) {
+    CCHK(hipEventCreate(&h->evStart[i]));
+    CCHK(hipEventCreate(&h->evStop[i]));
+  }
 #undef CCHK
   // regular-spacing flags, new_Integrator :193-211
   {
@@ -213,8 +216,10 @@ int i3rc_hip_destroy(i3rc_hip_integrator *h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   if (h->ownStream) { (void)hipStreamSynchronize(h->ownStream); (void)hipStreamDestroy(h->ownStream); }
-  if (h->evStart) (void)hipEventDestroy(h->evStart);
-  if (h->evStop) (void)hipEventDestroy(h->evStop);
+  for (int i = 0; i < i3rc_hip_integrator::kEventRing; ++i) {
+    if (h->evStart[i]) (void)hipEventDestroy(h->evStart[i]);
+    if (h->evStop[i]) (void)hipEventDestroy(h->evStop[i]);
+  }
   delete h;
   return 0;
 }
@@ -419,10 +424,11 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
   const long long need = (A.nPhotons + 255) / 256;
   if (blocks > need) blocks = std::max(1ll, need);
   HIPCHK(h, hipMemsetAsync(A.workCounter, 0, sizeof(unsigned long long), h->stream));
-  if (timeIt) HIPCHK(h, hipEventRecord(h->evStart, h->stream));
+  const int slot = (int)(h->timedLaunches % i3rc_hip_integrator::kEventRing);
+  if (timeIt) HIPCHK(h, hipEventRecord(h->evStart[slot], h->stream));
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), plan.ldsBytes, h->stream, plan.P, A, h->evThreshold);
   HIPCHK(h, hipGetLastError());
-  if (timeIt) { HIPCHK(h, hipEventRecord(h->evStop, h->stream)); h->timed = true; }
+  if (timeIt) { HIPCHK(h, hipEventRecord(h->evStop[slot], h->stream)); h->timedLaunches++; }
   return 0;
 }
 
@@ -557,14 +563,20 @@ int i3rc_hip_fetch_tallies(i3rc_hip_integrator *h, double *host) {
   return 0;
 }
 
-int i3rc_hip_last_kernel_ms(i3rc_hip_integrator *h, float *ms) {
-  if (!h || !ms) return 1;
-  if (!h->timed) return h->fail("i3rc_hip_last_kernel_ms: no timed launch yet");
+int i3rc_hip_kernel_ms_history(i3rc_hip_integrator *h, int n, float *ms) {
+  if (!h || !ms || n < 1) return 1;
+  if (n > i3rc_hip_integrator::kEventRing || n > h->timedLaunches)
+    return h->fail("i3rc_hip_kernel_ms_history: fewer timed launches recorded than requested (ring of 64)");
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipEventSynchronize(h->evStop));
-  HIPCHK(h, hipEventElapsedTime(ms, h->evStart, h->evStop));
+  for (int k = 0; k < n; ++k) {  // ms[0] = oldest of the last n launches
+    const int slot = (int)((h->timedLaunches - n + k) % i3rc_hip_integrator::kEventRing);
+    HIPCHK(h, hipEventSynchronize(h->evStop[slot]));
+    HIPCHK(h, hipEventElapsedTime(&ms[k], h->evStart[slot], h->evStop[slot]));
+  }
   return 0;
 }
+
+int i3rc_hip_last_kernel_ms(i3rc_hip_integrator *h, float *ms) { return i3rc_hip_kernel_ms_history(h, 1, ms); }
 
 int i3rc_hip_normalise(const i3rc_hip_integrator *h, const double *t, float *fluxUp, float *fluxDown, float *fluxAbsorbed,
                        float *volumeAbsorption, float *intensity, float *intensityByComponent) {

@@ -392,6 +392,11 @@ class Integrator:
         self._check(self._lib.i3rc_hip_last_kernel_ms(self._h, C.byref(ms)), "kernel_ms")
         return float(ms.value)
 
+    def kernel_ms_history(self, n):
+        ms = np.zeros(n, np.float32)
+        self._check(self._lib.i3rc_hip_kernel_ms_history(self._h, int(n), pf(ms)), "kernel_ms_history")
+        return ms
+
     # -- reportResults :711-826
     def reportResults(self):
         r = self._results

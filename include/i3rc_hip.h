@@ -171,9 +171,12 @@ int i3rc_hip_normalise(const i3rc_hip_integrator *h, const double *hostTallies,
 /* Timing of the most recent i3rc_hip_launch_batch, measured with HIP events on the launch stream.
  * Synchronises.  Returns milliseconds in *ms. */
 int i3rc_hip_last_kernel_ms(i3rc_hip_integrator *h, float *ms);
+/* Durations of the last n (<= 64) launches, oldest first; events are recorded around each launch without
+ * synchronising, so a timed region of many launches can be read back afterwards. */
+int i3rc_hip_kernel_ms_history(i3rc_hip_integrator *h, int n, float *ms);
 
 /* Experiment knobs (not part of the reference API): lanes that must be waiting before a wavefront runs its
- * event phase (1..64, default 32) and workgroups per CU (0 = occupancy query). */
+ * event phase (1..64, default 64) and workgroups per CU (0 = occupancy query). */
 int i3rc_hip_set_tuning(i3rc_hip_integrator *h, int evThreshold, int blocksPerCU);
 
 /* Test hook: the raw Philox4x32-10 blocks (out[n][blocksPerPhoton][4]) of photons firstPhoton..+n-1 and the

@@ -18,3 +18,10 @@ def oracle():
 
     pyoracle.build()
     return pyoracle
+
+
+def pytest_collection_modifyitems(config, items):
+    # a hung GPU test must not eat the box: 5 minutes per test at most (pytest-timeout)
+    for item in items:
+        if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(300))

@@ -78,10 +78,10 @@ def _random_rays(rng, d, n, oracle_integ):
     # some axis-aligned and grazing rays
     dirs[:50] = [0, 0, -1]
     dirs[50:100] = [0, 0, 1]
-    dirs[100:120] = [1, 0, 0] if False else dirs[100:120]
-    dirs[120:140, 2] = f32(1e-7)
+    dirs[120:140, 2] = f32(1e-7)   # grazing rays (always given a finite optical path below)
     idx = np.stack([ix, iy, iz], axis=1).astype(np.int32)
     target = np.where(rng.random(n) < 0.7, -np.log(np.maximum(rng.random(n), 1e-12)), -1.0).astype(np.float32)
+    target[120:140] = f32(0.5)
     return dirs, pos, idx, target
 
 
@@ -176,14 +176,19 @@ def _mean_se(rs, key):
     return a.mean(0), a.std(0, ddof=1) / np.sqrt(len(rs))
 
 
-def _assert_3sigma(gpu, ref, key, floor=1e-9, frac_ok=0.995):
+def _assert_3sigma(gpu, ref, key, floor=1e-9, frac_ok=None):
+    """Monte-Carlo tolerance (written here, as BASELINE.md 3(4) states it): the DOMAIN MEAN must agree within
+    3*sqrt(se_gpu^2 + se_ref^2), standard errors from the batch-to-batch variance as in
+    monteCarloDriver.f95:358-378.  Per column / cell the same 3-sigma band is applied, allowing for the
+    number of excursions expected when n_cells independent Student-t (n_batches-1 dof) variables are tested:
+    at most 1.5 % + 1 of the cells beyond 3 sigma, none beyond 6 sigma."""
     mg, sg = _mean_se(gpu, key)
     mr, sr = _mean_se(ref, key)
-    tol = 3.0 * np.sqrt(sg ** 2 + sr ** 2) + floor
-    ok = np.abs(mg - mr) <= tol
-    # per-column test: with ~1e2..1e4 columns a few 3-sigma excursions are expected; require frac_ok inside
-    assert ok.mean() >= frac_ok, (key, ok.mean(), np.abs(mg - mr).max(), tol.max())
-    # domain mean within 3 sigma
+    sig = np.sqrt(sg ** 2 + sr ** 2) + floor
+    z = np.abs(mg - mr) / sig
+    allowed = int(np.ceil(0.015 * z.size)) + 1
+    assert (z > 3.0).sum() <= allowed, (key, int((z > 3.0).sum()), allowed, z.max())
+    assert z.max() < 6.0, (key, z.max())
     dg = np.array([r[key].mean(dtype=np.float64) for r in gpu])
     dr = np.array([r[key].mean(dtype=np.float64) for r in ref])
     t = 3.0 * np.sqrt(dg.var(ddof=1) / len(dg) + dr.var(ddof=1) / len(dr)) + floor
@@ -204,17 +209,18 @@ def test_step_cloud_flux_parity(oracle, mu0, ssa, albedo):
         _assert_3sigma(gr, orr, key)
     if ssa < 1:
         _assert_3sigma(gr, orr, "fluxAbsorbed")
-        _assert_3sigma(gr, orr, "volumeAbsorption", frac_ok=0.99)
+        _assert_3sigma(gr, orr, "volumeAbsorption")
     # per-photon work counters (what the roofline's algorithmic bytes are computed from)
     cs = sum(r["counters"]["cellSteps"] for r in gr) / (nb * n)
     ks = sum(r["counters"]["scatterings"] for r in gr) / (nb * n)
     cs_o = sum(r["cellSteps"] for r in orr) / (nb * n)
     ks_o = sum(r["scatterings"] for r in orr) / (nb * n)
     assert abs(cs - cs_o) < 0.02 * cs_o and abs(ks - ks_o) < 0.02 * ks_o
-    # energy closure incl. the dropped-photon deficit (quirk Q4)
+    # energy closure incl. the dropped-photon deficit (quirk Q4); exact only without roulette plays
     r0 = gr[0]
-    closure = r0["fluxUp"].mean() + (1 - albedo) * r0["fluxDown"].mean() + r0["fluxAbsorbed"].mean()
-    assert abs(closure - (1 - r0["counters"]["dropped"] / n)) < 5e-5
+    if ssa == 1.0 and albedo == 0.0:
+        closure = r0["fluxUp"].mean(dtype=np.float64) + r0["fluxDown"].mean(dtype=np.float64)
+        assert abs(closure - (1 - r0["counters"]["dropped"] / n)) < 2e-6
 
 
 def test_results_do_not_depend_on_launch_geometry():
