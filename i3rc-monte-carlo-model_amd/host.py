@@ -22,6 +22,8 @@ from . import binding as B
 from .binding import I3RCError, f32, pf
 from .phasefunctions import PI_MCRT, PhaseFunctionTable, hybrid_phase_functions, spacing
 
+r32 = np.float32  # scalar float32 (f32() from the binding makes contiguous ARRAYS)
+
 DEFAULT_MIN_TABLE_SIZE = 9001  # monteCarloRadiativeTransfer.f95:36-37
 
 
@@ -159,7 +161,7 @@ class Domain:
         total = cum[-1].copy()
         mask = total > np.finfo(np.float32).tiny
         with np.errstate(all="ignore"):
-            cum = np.where(mask[None], cum / np.where(mask, total, f32(1.0))[None], cum).astype(np.float32)
+            cum = np.where(mask[None], cum / np.where(mask, total, r32(1.0))[None], cum).astype(np.float32)
         return total, cum, ssa, pfi, [c["table"] for c in self.components]
 
 
@@ -178,7 +180,7 @@ class Integrator:
         self._lib = B.load()
         total, cum, ssa, pfi, tables = atmosphere.getOpticalPropertiesByComponent()
         # :233-234: nudge the last cumulative slice so that r == 1 still selects the last component
-        one = f32(1.0)
+        one = r32(1.0)
         last = cum[-1]
         last[np.abs(last - one) <= np.spacing(one)] = one + np.spacing(one)
         self.nz, self.ny, self.nx = total.shape
@@ -287,8 +289,8 @@ class Integrator:
         if "intensityMus" in kw:
             d = []
             for m, ph in zip(f32(kw["intensityMus"]), f32(kw["intensityPhis"])):
-                phr = f32(f32(ph * PI_MCRT) / f32(180.0))
-                st = np.sqrt(f32(1.0) - m * m, dtype=np.float32)
+                phr = r32(r32(ph * PI_MCRT) / r32(180.0))
+                st = np.sqrt(r32(1.0) - m * m, dtype=np.float32)
                 d.append([st * np.cos(phr, dtype=np.float32), st * np.sin(phr, dtype=np.float32), m])  # :2041-2059
             self.intensityDirections = np.array(d, np.float32).reshape(-1, 3)
             self.computeIntensity = True
@@ -402,7 +404,7 @@ class Integrator:
         r = self._results
         if r is None:
             raise I3RCError("reportResults: no results available")
-        ncol = f32(self.nx * self.ny)
+        ncol = r32(self.nx * self.ny)
         out = dict(meanFluxUp=r["fluxUp"].sum(dtype=np.float32) / ncol, meanFluxDown=r["fluxDown"].sum(dtype=np.float32) / ncol,
                    meanFluxAbsorbed=r["fluxAbsorbed"].sum(dtype=np.float32) / ncol,
                    fluxUp=r["fluxUp"], fluxDown=r["fluxDown"], fluxAbsorbed=r["fluxAbsorbed"],

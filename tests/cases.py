@@ -55,3 +55,92 @@ def irregular_domain(seed=3, nx=7, ny=5, nz=9, ssa=0.95):
     pf = np.where(ext > 0, 1, 0).astype(np.int32)
     s = np.where(ext > 0, f32(ssa), f32(0.0)).astype(np.float32)
     return dict(xe=xe, ye=ye, ze=ze, ext=ext, ssa=s, pf=pf)
+
+
+# ---- I3RC phase-1 fields (data fixture made by tests/golden/make_i3rc_inputs.py) ---------------------------
+import os as _os
+
+_GOLDEN = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "i3rc_phase1_inputs.npz")
+
+
+def _inputs():
+    return np.load(_GOLDEN)
+
+
+def radar_cloud(ssa=1.0):
+    """640 x 1 x 54 MMCR cloud, I3RC-Examples/i3rcRadarCloud.f95:28-31,107-125: file row j -> layer nz+1-j,
+    optical depth per cell / deltaZ; deltaX = 50, deltaZ = 45."""
+    tau = _inputs()["mmcr_tau"]                      # [54 rows, 640]
+    nz, nx = tau.shape
+    ext = (tau[::-1, :] / f32(45.0)).astype(np.float32)[:, None, :]
+    xe = f32(50.0) * np.arange(0, nx + 1, dtype=np.float32)
+    ye = np.array([0.0, f32(50.0) * f32(nx)], np.float32)
+    ze = f32(45.0) * np.arange(0, nz + 1, dtype=np.float32)
+    return dict(xe=xe, ye=ye, ze=ze, ext=np.ascontiguousarray(ext), ssa=np.full(ext.shape, f32(ssa), np.float32),
+                pf=np.ones(ext.shape, np.int32))
+
+
+def radar_cloud_64(ssa=1.0):
+    """BASELINE.json's labelled 64 x 64 x 54 synthetic: ext3(i,j,k) = ext2(10*mod(i+j-2,64)+1, k),
+    deltaX = deltaY = 500, deltaZ = 45."""
+    r = radar_cloud(ssa)
+    e2 = r["ext"][:, 0, :]
+    i = np.arange(1, 65)[None, :]
+    j = np.arange(1, 65)[:, None]
+    col = 10 * np.mod(i + j - 2, 64)                 # 0-based column of the radar field
+    ext = np.ascontiguousarray(e2[:, col], dtype=np.float32)   # [54, 64(j), 64(i)]
+    xe = f32(500.0) * np.arange(0, 65, dtype=np.float32)
+    return dict(xe=xe, ye=xe.copy(), ze=r["ze"], ext=ext, ssa=np.full(ext.shape, f32(ssa), np.float32),
+                pf=np.ones(ext.shape, np.int32))
+
+
+def landsat_cloud(ssa=1.0, nlayers=119):
+    """128 x 128 x 119 Landsat scene, I3RC-Examples/i3rcLandsatCloud.f95:27-35,92-108: cloud fills the lowest
+    nint(dz/20) layers of each column with ext = tau / (nint(dz/20)*20); z0 = 200; deltaXY = 30, deltaZ = 20.
+    nlayers=36 gives BASELINE.json's labelled 128 x 128 x 36 synthetic."""
+    inp = _inputs()
+    tau = inp["landsat_tau"]                         # [y, x]
+    thick = (inp["landsat_dz_km"] * f32(1000.0)).astype(np.float32)
+    ny, nx = tau.shape
+    if nlayers == 119:
+        dzl = f32(20.0)
+        nfill = np.rint(thick / dzl).astype(np.int64)
+        with np.errstate(all="ignore"):
+            e = np.where(tau > np.finfo(np.float32).tiny, tau / (nfill.astype(np.float32) * dzl), f32(0.0)).astype(np.float32)
+        ze = dzl * np.arange(0, nlayers + 1, dtype=np.float32) + f32(200.0)
+    else:
+        dzl = f32(2380.0) / f32(nlayers)
+        nfill = np.where(tau > 0, np.maximum(1, np.rint(thick / dzl).astype(np.int64)), 0)
+        with np.errstate(all="ignore"):
+            e = np.where(tau > 0, tau / (nfill.astype(np.float32) * dzl), f32(0.0)).astype(np.float32)
+        ze = (dzl * np.arange(0, nlayers + 1, dtype=np.float32) + f32(200.0)).astype(np.float32)
+    k = np.arange(nlayers)[:, None, None]
+    ext = np.where(k < nfill[None], e[None], f32(0.0)).astype(np.float32)
+    s = np.where(ext > 0, f32(ssa), f32(0.0)).astype(np.float32)
+    pf = np.where(ext > 0, 1, 0).astype(np.int32)
+    xe = f32(30.0) * np.arange(0, nx + 1, dtype=np.float32)
+    ye = f32(30.0) * np.arange(0, ny + 1, dtype=np.float32)
+    return dict(xe=xe, ye=ye, ze=ze, ext=np.ascontiguousarray(ext), ssa=s, pf=pf)
+
+
+def c1_phase_function():
+    """Deirmendjian C1 tabulated phase function (1801 angle/value pairs), i3rcRadarCloud.f95:70-76."""
+    inp = _inputs()
+    ang = (inp["c1_angle_deg"] * np.arccos(f32(-1.0)) / f32(180.0)).astype(np.float32)
+    return ang, inp["c1_value"].astype(np.float32)
+
+
+def two_component(seed=5, nx=6, ny=4, nz=8):
+    """Two components (cloud in the middle layers + a horizontally uniform background), two table entries."""
+    rng = np.random.default_rng(seed)
+    xe = f32(25.0) * np.arange(0, nx + 1, dtype=np.float32)
+    ye = f32(40.0) * np.arange(0, ny + 1, dtype=np.float32)
+    ze = f32(30.0) * np.arange(0, nz + 1, dtype=np.float32)
+    cloud = np.zeros((nz, ny, nx), np.float32)
+    cloud[2:6] = rng.uniform(0.0, 0.06, (4, ny, nx)).astype(np.float32)
+    cloud[rng.random(cloud.shape) < 0.2] = 0
+    pf1 = np.where(cloud > 0, rng.integers(1, 3, cloud.shape), 0).astype(np.int32)
+    ssa1 = np.where(cloud > 0, f32(0.98), f32(0.0)).astype(np.float32)
+    gas = np.broadcast_to(np.linspace(0.004, 0.001, nz, dtype=np.float32)[:, None, None], (nz, ny, nx)).copy()
+    return dict(xe=xe, ye=ye, ze=ze, ext=[cloud, gas], ssa=[ssa1, np.full_like(gas, f32(0.6))],
+                pf=[pf1, np.ones(gas.shape, np.int32)])
