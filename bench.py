@@ -69,6 +69,7 @@ def main():
 
     import i3rc_monte_carlo_model_amd as M
     from i3rc_monte_carlo_model_amd import binding as B
+    from i3rc_monte_carlo_model_amd.multigpu import all_reduce_tallies, max_over_ranks
     from tests import cases
 
     if not torch.cuda.is_available():
@@ -101,8 +102,7 @@ def main():
         tally.zero_()
         integ.launch(M.new_RandomNumberSequence((iseed, batch)), M.new_PhotonStream(1.0, 0.0, a.photons),
                      firstPhoton=rank * a.photons, zero=False)
-        if dist is not None:
-            dist.all_reduce(tally)  # the single exchange step: sum of tallies over GPUs
+        all_reduce_tallies(tally, dist)  # the single exchange step: sum of tallies over GPUs (RCCL)
 
     def sync():
         if dist is not None:
@@ -117,10 +117,7 @@ def main():
         step(1 + k)
     sync()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, dist, device="cuda")
 
     # ---- kernel durations of the K timed launches (HIP events recorded on the launch stream, read now) ------
     kernel_ms = integ.kernel_ms_history(min(a.steps, 64))

@@ -1,0 +1,64 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the sharding + single all-reduce + normalisation
+logic that bench.py and the drivers use on GPUs (there with backend nccl = RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import i3rc_monte_carlo_model_amd as M
+from i3rc_monte_carlo_model_amd.multigpu import all_reduce_tallies, max_over_ranks, shard_photons
+
+
+def test_shards_partition_the_batch():
+    for n in (1, 7, 100, 10 ** 8 + 3):
+        for w in (1, 2, 3, 8):
+            parts = [shard_photons(n, w, r) for r in range(w)]
+            assert parts[0][0] == 0
+            for (f0, n0), (f1, _) in zip(parts, parts[1:]):
+                assert f0 + n0 == f1
+            assert parts[-1][0] + parts[-1][1] == n
+            assert max(p[1] for p in parts) - min(p[1] for p in parts) <= 1
+    with pytest.raises(ValueError):
+        shard_photons(10, 2, 2)
+
+
+def _fake_trace(first, n, ncol):
+    """Deterministic stand-in for a rank's raw tallies: photon i adds to column i % ncol, weight from i."""
+    idx = np.arange(first, first + n, dtype=np.int64)
+    t = np.zeros(3 * ncol + 16, np.float64)
+    np.add.at(t, idx % ncol, 1.0)                       # fluxUp
+    np.add.at(t, ncol + (idx * 7) % ncol, 0.5)          # fluxDown
+    t[3 * ncol + 0] = n                                 # photons counter
+    return t
+
+
+def _worker(rank, world, port, n_total, ncol, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, n = shard_photons(n_total, world, rank)
+    t = torch.from_numpy(_fake_trace(first, n, ncol))
+    all_reduce_tallies(t, dist)
+    m = max_over_ranks(float(rank + 1), dist)
+    if rank == 0:
+        np.save(out, np.concatenate([t.numpy(), [m]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_allreduce_equals_single_rank(tmp_path):
+    n_total, ncol = 100003, 32
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "reduced.npy")
+    mp.spawn(_worker, args=(2, port, n_total, ncol, out), nprocs=2, join=True)
+    got = np.load(out)
+    want = _fake_trace(0, n_total, ncol)
+    assert np.array_equal(got[:-1], want)      # sums of counts are exact in float64
+    assert got[-1] == 2.0                      # max over ranks
+    assert got[3 * ncol] == n_total
