@@ -128,6 +128,15 @@ class PhaseFunction:
                 raise ValueError("new_PhaseFunction: scattering angles must be increasing, unique")
             if np.any(self.angles < 0) or np.any(self.angles > PI_SPF):
                 raise ValueError("new_PhaseFunction: scattering angle out of bounds")
+            if np.any(self.values_ < 0):
+                raise ValueError("newPhaseFunction: Negative phase function values supplied.")
+            # normalizePhaseFunction (:1329-1345): integral over cos(angle) = 2, as the constructors do (:145)
+            cosa = np.cos(self.angles).astype(np.float32)
+            terms = (cosa[1:] - cosa[:-1]) * (f32(0.5) * (self.values_[1:] + self.values_[:-1]))
+            dot = f32(0.0)
+            for t in terms:
+                dot = f32(dot + t)
+            self.values_ = ((-self.values_ * f32(2.0)) / dot).astype(np.float32)
 
     @property
     def stored_as_legendre(self):

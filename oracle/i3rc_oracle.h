@@ -48,6 +48,8 @@ void orc_phase_values_legendre(const float *coef, int nCoef, const float *angles
 /* Tabulated phase function, interpolated linearly in cos(angle). :497-524 */
 void orc_phase_values_tabulated(const float *tabAngles, const float *tabValues, int nTab,
                                 const float *angles, int nAngles, float *values);
+/* normalizePhaseFunction :1329-1345 (what new_PhaseFunction / new_PhaseFunctionTable do to tabulated values) */
+void orc_normalize_tabulated(const float *tabAngles, const float *tabValues, int nTab, float *normalized);
 /* Inverse (CDF -> angle) tables. inversePhaseFunctions.f95:68-176 */
 void orc_inverse_table_legendre(const float *coef, int nCoef, int nSteps, float *table);
 void orc_inverse_table_tabulated(const float *tabAngles, const float *tabValues, int nTab, int nSteps, float *table);

@@ -238,6 +238,15 @@ void orc_phase_values_tabulated(const float *tabAngles, const float *tabValues, 
   }
 }
 
+/* normalizePhaseFunction :1329-1345: scale so that the trapezoid integral over cos(angle) equals 2
+ * (applied by the constructors of tabulated phase functions :145, :300-303) */
+void orc_normalize_tabulated(const float *tabAngles, const float *tabValues, int nTab, float *normalized) {
+  float dot = 0.0f;
+  for (int i = 0; i + 1 < nTab; i++)
+    dot += (cosf(tabAngles[i + 1]) - cosf(tabAngles[i])) * (0.5f * (tabValues[i + 1] + tabValues[i]));
+  for (int i = 0; i < nTab; i++) normalized[i] = (-tabValues[i] * 2.0f) / dot;
+}
+
 /* ===================================================================================================
  * Code/inversePhaseFunctions.f95 : computeInversePhaseFunction :68-176
  * =================================================================================================== */

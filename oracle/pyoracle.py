@@ -169,6 +169,13 @@ def forward_table_tabulated(angles, values, n_steps):
     return out
 
 
+def normalize_tabulated(angles, values):
+    angles, values = _f(angles), _f(values)
+    out = np.zeros_like(values)
+    lib().orc_normalize_tabulated(_pf(angles), _pf(values), len(angles), _pf(out))
+    return out
+
+
 def hybrid_tables(values, width_deg):
     values = _f(values)
     if values.ndim == 1:

@@ -120,7 +120,7 @@ def test_radar_cloud_c1_tabulated_flux_and_nadir_radiance(oracle):
     # nadir radiance with Iwabuchi roulette (driver defaults: zetaMin 0.3)
     d = cases.radar_cloud()
     ang, val = cases.c1_phase_function()
-    tab = M.PhaseFunctionTable([M.PhaseFunction(angles=ang, values=val)])
+    tab = M.PhaseFunctionTable([M.PhaseFunction(angles=ang, values=val)])   # normalised on construction (:1329-1345)
     gp = dict(useRussianRouletteForIntensity=True, zetaMin=0.3, minInverseTableSize=10001, minForwardTableSize=10001)
     op = dict(useRRForIntensity=1, zetaMin=0.3)
     g, o = _intensity_pair(oracle, d, tab, n_table=10001, gpu_params=gp, oracle_params=op, mus=[1.0], phis=[0.0])
