@@ -1,0 +1,142 @@
+"""The Fortran-95 shell (i3rc-monte-carlo-model_amd/fortran): same module API as the reference, over the C ABI.
+
+CPU: the shell builds with amdflang; its host-side numerics reproduce the pinned reference numbers; the minimal
+netCDF classic module round-trips a domain and is readable by an independent reader (scipy); where the reference
+tree is present, its own drivers compile and link UNCHANGED against the shell (drop-in boundary).
+GPU: the shell's integrator and the reference's unchanged drivers run on the device."""
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FDIR = os.path.join(ROOT, "i3rc-monte-carlo-model_amd", "fortran")
+BUILD = os.path.join(FDIR, "build")
+HAVE_FLANG = os.path.exists("/opt/rocm/bin/amdflang")
+HAVE_REF = os.path.isdir("/root/reference/Example-Drivers")
+
+
+def _run(cmd, **kw):
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=600, **kw)
+
+
+@pytest.fixture(scope="module")
+def shell_built():
+    if not HAVE_FLANG:
+        pytest.skip("amdflang not available")
+    import i3rc_monte_carlo_model_amd as M
+
+    M.build.build()  # the shell links against csrc/libi3rc_hip.so
+    r = _run(["make", "-C", FDIR, "-s", "all"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    return BUILD
+
+
+def _fields(out, key):
+    for line in out.splitlines():
+        if line.startswith(key):
+            return line[len(key):].split()
+    raise AssertionError(f"{key} not in output:\n{out}")
+
+
+def test_shell_host_numerics_match_reference_pins(shell_built):
+    r = _run([os.path.join(shell_built, "shellSelfTest"), "cpu"])
+    assert r.returncode == 0 and "cpu checks done" in r.stdout, r.stdout + r.stderr
+    # MT19937 known answers
+    assert _fields(r.stdout, "mt_scalar") == ["0.543404937", "0.671155632", "0.278369397", "0.412046403", "0.424517602"]
+    assert _fields(r.stdout, "mt_vector") == ["168774779", "197189863", "1009846582", "-287080014", "-590412790"]
+    # inverse table HG g=.85, 64 moments, 10001 steps; forward P(0), P(pi)
+    assert _fields(r.stdout, "inverse") == ["3.141593", "3.045351", "0.497639", "0.252000", "0.134744", "0.002211", "0.000000"]
+    fwd = [float(v) for v in _fields(r.stdout, "forward")]
+    assert f"{fwd[0]:.4f}" == "82.1977" and f"{fwd[2]:.7f}" == "0.0456438"
+    # domain: 3-D + horizontally uniform partial-height component, written and read back through netCDF classic
+    assert _fields(r.stdout, "domain") == ["3", "2", "4", "2", "cloud", "gas"]
+    rt = _fields(r.stdout, "roundtrip")
+    assert float(rt[0]) == 0.0 and float(rt[1]) == 0.0 and rt[2] == "F"
+    lay = [float(v) for v in _fields(r.stdout, "layers")]
+    assert lay == [0.01, 0.021, pytest.approx(0.02 / 0.021, abs=1e-6)]
+
+
+def test_netcdf_classic_files_are_readable_by_an_independent_reader(shell_built, tmp_path):
+    from scipy.io import netcdf_file
+
+    dom = str(tmp_path / "step.dom")
+    r = _run([os.path.join(shell_built, "makeStepCloudDomain"), dom, "16", "0.99"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    f = netcdf_file(dom, "r", mmap=False)
+    assert f.dimensions["x-Edges"] == 33 and f.dimensions["z-Grid"] == 16 and f.numberOfComponents == 1
+    assert f.Component1_Name == b"cloud" and f.Component1_zLevelBase == 1
+    ext = f.variables["Component1_Extinction"].data
+    assert ext.shape == (16, 1, 32)   # file order is slowest first: (z, y, x)
+    assert np.allclose(ext[:, 0, :16], 2 / 250) and np.allclose(ext[:, 0, 16:], 18 / 250)
+    assert np.allclose(f.variables["Component1_SingleScatteringAlbedo"].data, 0.99)
+    assert f.variables["Component1_PhaseFunctionIndex"].data.dtype.kind == "i"
+    assert f.Component1_phaseFunctionStorageType == b"LegendreCoefficients"
+    coef = f.variables["Component1_legendreCoefficients"].data
+    assert coef.shape == (64,) and abs(coef[0] - 0.85) < 1e-7 and abs(coef[1] - 0.7225) < 1e-6
+    assert np.allclose(f.variables["x-Edges"].data, np.arange(33) * 15.625)
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="reference tree not present (GPU box)")
+def test_reference_drivers_link_unchanged(shell_built):
+    # drop-in boundary: the reference's own driver sources, compiled in place, link against the shell
+    r = _run(["make", "-C", FDIR, "linkcheck"])
+    assert r.returncode == 0 and "compiled and linked unchanged" in r.stdout, r.stdout + r.stderr
+    for exe in ("monteCarloDriver_ref", "planeParallel_ref"):
+        assert os.access(os.path.join(shell_built, exe), os.X_OK)
+    # nothing of the reference's source is kept in the repository
+    tracked = _run(["git", "-C", ROOT, "ls-files"]).stdout.split()
+    assert not any(os.path.basename(t) in ("monteCarloDriver.f95", "planeParallel.f95") for t in tracked)
+
+
+# ---- GPU --------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_shell_integrator_on_gpu():
+    exe = os.path.join(BUILD, "shellSelfTest")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran shell not built")
+    r = _run([exe, "gpu"], cwd=ROOT)
+    assert r.returncode == 0 and "gpu checks done" in r.stdout, r.stdout + r.stderr
+    up, down, more = _fields(r.stdout, "slab")
+    # planeParallel.nml values: reference 0.16420 / 0.83580 (4e4 photons, +-0.0036); here 8e5 photons
+    assert abs(float(up) - 0.1642) < 0.004 and abs(float(down) - 0.8358) < 0.004 and more == "F"
+    assert abs(float(up) + float(down) - 1.0) < 1e-4
+    s = _fields(r.stdout, "surface")
+    assert float(s[0]) > float(up) and 0 < float(s[2]) < 1 and 0 < float(s[3]) < 1 and s[4] == "F"
+
+
+@pytest.mark.gpu
+def test_reference_drivers_run_unchanged_on_gpu(tmp_path):
+    pp = os.path.join(BUILD, "planeParallel_ref")
+    mc = os.path.join(BUILD, "monteCarloDriver_ref")
+    mk = os.path.join(BUILD, "makeStepCloudDomain")
+    if not (os.path.exists(pp) and os.path.exists(mc) and os.path.exists(mk)):
+        pytest.skip("reference drivers were not built in this tree (needs /root/reference at build time)")
+    r = _run([pp, os.path.join(FDIR, "examples", "planeParallel.nml")], cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    nums = [float(v) for v in r.stdout.strip().splitlines()[-1].split()]
+    # columns: tau omega g theta0 Fup Fdn errUp errDn Fabs errAbs  (reference result 0.16420 / 0.83580 +- 0.0036)
+    assert nums[:4] == [1.0, 1.0, 0.85, 60.0]
+    assert abs(nums[4] - 0.1642) < 4 * 0.0036 and abs(nums[5] - 0.8358) < 4 * 0.0036 and abs(nums[4] + nums[5] - 1) < 1e-3
+    # monteCarloDriver: domain file -> read_Domain -> 10 batches -> ASCII + netCDF output
+    out = tmp_path
+    dom = str(out / "stepCloud.dom")
+    assert _run([mk, dom, "32", "1.0"]).returncode == 0
+    nml = open(os.path.join(FDIR, "examples", "stepCloud.nml")).read().replace("gpurun_out/fortran/", str(out) + "/")
+    nml_path = str(out / "stepCloud.nml")
+    open(nml_path, "w").write(nml)
+    r = _run([mc, nml_path], cwd=ROOT)
+    assert r.returncode == 0 and "Wrote ASCII results" in r.stdout and "Wrote netcdf results" in r.stdout, r.stdout + r.stderr
+    flux = open(str(out / "stepCloud_flux.txt")).read()
+    m = re.search(r"Average:\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)", flux)
+    fup, eup, fdn, edn = map(float, m.groups())
+    # Fup 0.3254, Fdn 0.6746 at 1e6 photons
+    assert abs(fup - 0.3254) < 4 * max(eup, 4e-4) and abs(fdn - 0.6746) < 4 * max(edn, 4e-4)
+    from scipy.io import netcdf_file
+
+    f = netcdf_file(str(out / "stepCloud_results.nc"), "r", mmap=False)
+    assert f.variables["fluxUp"].data.shape == (1, 32) and f.variables["intensity"].data.shape == (1, 1, 32)
+    assert abs(f.variables["fluxUp"].data.mean() - fup) < 1e-3
