@@ -44,7 +44,7 @@ struct i3rc_hip_integrator {
   int nx = 0, ny = 0, nz = 0, ncomp = 0;
   std::vector<float> xE, yE, zE;  // host copies (normalisation, checks)
   DevBuf dxE, dyE, dzE, dExt, dCum, dSsa, dPf;
-  DevBuf dInv[I3RC_MAX_COMPONENTS], dFwd[I3RC_MAX_COMPONENTS], dFwdOrig[I3RC_MAX_COMPONENTS];
+  DevBuf dInv[I3RC_MAX_COMPONENTS], dInvCos[I3RC_MAX_COMPONENTS], dFwd[I3RC_MAX_COMPONENTS], dFwdOrig[I3RC_MAX_COMPONENTS];
   CompTables comp[I3RC_MAX_COMPONENTS] = {};
   int nInvEntries[I3RC_MAX_COMPONENTS] = {}, nFwdEntries[I3RC_MAX_COMPONENTS] = {};
   DevBuf dComp;
@@ -68,7 +68,7 @@ struct i3rc_hip_integrator {
   hipEvent_t evStart[kEventRing] = {}, evStop[kEventRing] = {};
   long long timedLaunches = 0;
   int numCU = 256;
-  int evThreshold = 64;
+  int evThreshold = 40;
   int blocksPerCU = 0;  // 0 = from occupancy query
   std::string err;
 
@@ -231,7 +231,12 @@ int i3rc_hip_set_inverse_table(i3rc_hip_integrator *h, int comp, int nSteps, int
   if (nEntries < h->maxPfIndex[comp - 1]) return h->fail("i3rc_hip_set_inverse_table: phaseFunctionIndex refers to a missing table entry");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, h->dInv[comp - 1].upload(t, sizeof(float) * (size_t)nSteps * nEntries));
+  // cos of every tabulated angle, in float64, rounded once (see scattering_cosine in tracer.hpp)
+  std::vector<float> cosTab((size_t)nSteps * nEntries);
+  for (size_t i = 0; i < cosTab.size(); ++i) cosTab[i] = (float)std::cos((double)t[i]);
+  HIPCHK(h, h->dInvCos[comp - 1].upload(cosTab.data(), sizeof(float) * cosTab.size()));
   h->comp[comp - 1].inv = (const float *)h->dInv[comp - 1].p;
+  h->comp[comp - 1].invCos = (const float *)h->dInvCos[comp - 1].p;
   h->comp[comp - 1].nInv = nSteps;
   h->nInvEntries[comp - 1] = nEntries;
   return 0;
@@ -396,6 +401,11 @@ int upload_source(i3rc_hip_integrator *h, const i3rc_source *src, int64_t n, Run
     if (src->solarAzimuth < 0.f || src->solarAzimuth > 360.f) return h->fail("setIllumination: solarAzimuth out of bounds");
     A.solarMu = -std::fabs(src->solarMu);                      // Code/monteCarloIllumination.f95:98
     A.solarPhi = src->solarAzimuth * std::acos(-1.0f) / 180.f; // :99
+    // makeDirectionCosines (:2041-2059) once on the host: the same libm float32 calls the reference makes
+    const float sinTheta = std::sqrt(1.0f - A.solarMu * A.solarMu);
+    A.solarDx = sinTheta * std::cos(A.solarPhi);
+    A.solarDy = sinTheta * std::sin(A.solarPhi);
+    A.solarDz = A.solarMu;
     return 0;
   }
   if (src->kind != 1) return h->fail("unknown photon source kind");
@@ -423,10 +433,12 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
   long long blocks = (long long)h->numCU * perCU;
   const long long need = (A.nPhotons + 255) / 256;
   if (blocks > need) blocks = std::max(1ll, need);
+  RunArgs B = A;   // photon indices are handed to waves in chunks (one returning atomic per chunk)
+  B.chunk = (int)std::min<long long>(1024, std::max<long long>(64, A.nPhotons / (blocks * 4 * 8)));
   HIPCHK(h, hipMemsetAsync(A.workCounter, 0, sizeof(unsigned long long), h->stream));
   const int slot = (int)(h->timedLaunches % i3rc_hip_integrator::kEventRing);
   if (timeIt) HIPCHK(h, hipEventRecord(h->evStart[slot], h->stream));
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), plan.ldsBytes, h->stream, plan.P, A, h->evThreshold);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), plan.ldsBytes, h->stream, plan.P, B, h->evThreshold);
   HIPCHK(h, hipGetLastError());
   if (timeIt) { HIPCHK(h, hipEventRecord(h->evStop[slot], h->stream)); h->timedLaunches++; }
   return 0;
@@ -544,6 +556,26 @@ int i3rc_hip_philox_blocks(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(out, d.p, cnt * 4, hipMemcpyDeviceToHost));
   HIPCHK(h, hipMemcpy(outf, df.p, cnt * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+/* Test hook: counts, over n pairs, where the kernel's exact_div / exact_sqrt differ from IEEE `/` and sqrtf. */
+int i3rc_hip_arith_check(i3rc_hip_integrator *h, int64_t n, const float *num, const float *den, int64_t *divMismatch,
+                         int64_t *sqrtMismatch) {
+  if (!h) return 1;
+  if (n <= 0 || !num || !den || !divMismatch || !sqrtMismatch) return h->fail("i3rc_hip_arith_check: bad arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  DevBuf dn, dd, dc;
+  HIPCHK(h, dn.upload(num, sizeof(float) * n)); HIPCHK(h, dd.upload(den, sizeof(float) * n));
+  HIPCHK(h, dc.alloc(2 * sizeof(unsigned long long)));
+  HIPCHK(h, hipMemset(dc.p, 0, 2 * sizeof(unsigned long long)));
+  hipLaunchKernelGGL(arith_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (long long)n,
+                     (const float *)dn.p, (const float *)dd.p, (unsigned long long *)dc.p);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  unsigned long long c[2];
+  HIPCHK(h, hipMemcpy(c, dc.p, sizeof(c), hipMemcpyDeviceToHost));
+  *divMismatch = (int64_t)c[0]; *sqrtMismatch = (int64_t)c[1];
   return 0;
 }
 

@@ -75,6 +75,7 @@ __device__ __forceinline__ void intensity_contribution(const DevProblem &P, cons
     }
     Ray r;
     r.x = x; r.y = y; r.z = z; r.ix = ix; r.iy = iy; r.iz = iz; r.dx = ux; r.dy = uy; r.dz = uz;
+    r.set_direction();
     float con;
     auto run = [&](bool hasTarget, float target) {
       r.acc = 0.0f; r.target = target;
@@ -126,6 +127,19 @@ struct RngInit<ReplayStream> {
   }
 };
 
+// Wave-private reservoir of photon indices: one returning atomic per `chunk` photons instead of one per respawn
+// round (the returning atomic costs microseconds; every wave would pay it in ~97 % of its event phases).
+struct Reservoir {
+  long long next, end;   // wave-uniform
+  __device__ __forceinline__ void refill(const RunArgs &A) {
+    long long base = 0;
+    if ((threadIdx.x & 63) == 0) base = (long long)atomicAdd(A.workCounter, (unsigned long long)A.chunk);
+    base = __shfl(base, 0, 64);
+    next = base < A.nPhotons ? base : A.nPhotons;
+    end = base + A.chunk < A.nPhotons ? base + A.chunk : A.nPhotons;
+  }
+};
+
 template <class Rng, bool INTENSITY>
 __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -157,17 +171,21 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
   const Tally tally{P, L};
   const size_t ncell = (size_t)P.nx * P.ny * P.nz;
   const float surfaceZ = P.z0 + spacingf(P.z0);
+  const unsigned long long laneBit = 1ull << (threadIdx.x & 63);
 
   LaneCounters cnt;
   Rng rng;
   Ray r;
   r.x = r.y = r.z = 0.0f; r.dx = r.dy = 0.0f; r.dz = -1.0f; r.ix = r.iy = r.iz = 1; r.acc = 0.0f; r.target = 0.0f;
+  r.rx = r.ry = r.rz = 0.0f; r.slow = 1;
   float w = 0.0f;
   int order = 0;
   int st = ST_NEW;
   long long pid = -1;
   int fate = -1, fateCol = -1;
   float fateW = 0.0f;
+  Reservoir res;
+  res.refill(A);
 
   for (;;) {
     // ---------------------------------------------------------------- EVENT phase
@@ -176,10 +194,10 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
     const unsigned long long trMask = __ballot(st == ST_TRACE);
     if (evMask == 0ull && trMask == 0ull) break;
     if (__popcll(evMask) >= evThreshold || trMask == 0ull) {
+      // ---- part 1: what ended the trace
       if (wantEvent) {
         if (st == ST_DROPPED) { cnt.dropped++; fate = 3; st = ST_NEW; }   // :488-489
         if (st == ST_EVENT) {
-          const int col = (r.iy - 1) * P.nx + (r.ix - 1);
           if (r.z >= P.zMax) {                                            // :499-514
             if (!P.useRayTracing) {
               r.x = make_periodic(r.x - r.dx * fabsf((r.z - P.zMax) / r.dz), P.x0, P.xMax);
@@ -205,7 +223,7 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
             cnt.surf++;
             fateCol = c2; fateW = w;
             float mu;
-            do { mu = sqrtf(rng.next()); } while (!(fabsf(mu) > 2.0f * kTiny));
+            do { mu = exact_sqrt(rng.next()); } while (!(fabsf(mu) > 2.0f * kTiny));
             const float phi = (2.0f * kPi) * rng.next();
             if (P.useBDRF) w = w * surface_reflectance(P, r.x, r.y);
             else w = w * P.albedo;
@@ -214,17 +232,17 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
               make_dircos(mu, phi, r.dx, r.dy, r.dz);
               if (INTENSITY)
                 intensity_contribution(P, L, rng, cnt, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, 0, order);
-              st = ST_TRACE;  // provisional: a new optical depth is drawn below
+              st = ST_TRACE;  // provisional: a new optical depth is drawn in part 3
             }
           } else {                                                        // :581-689
-            (void)col;
             bool scatterThis = true;
             size_t cell = cell_index(P, r.ix, r.iy, r.iz);
             if (!P.useRayTracing) scatterThis = rng.next() < P.totalExt[cell] / P.maxExt;
             if (scatterThis) {
               order++;
               cnt.scat++;
-              if (P.totalExt[cell] <= 0.0f) {                             // :606-632 (quirk Q2 kept)
+              const float extHere = P.ldsGrid ? L.ext[cell] : P.totalExt[cell];
+              if (extHere <= 0.0f) {                                      // :606-632 (quirk Q2 kept)
                 if (r.x - L.xE[r.ix - 1] <= 0.0f && r.dx > 0.0f) {
                   r.x = r.x - spacingf(r.x);
                   r.ix = r.ix - 1;
@@ -238,12 +256,14 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
                 if (r.z - L.zE[r.iz - 1] <= 0.0f && r.dz > 0.0f) { r.z = r.z - spacingf(r.z); r.iz = r.iz - 1; }
                 cell = cell_index(P, r.ix, r.iy, r.iz);
               }
-              const float rc = rng.next();                                // :637-638
-              int comp = 1;
-              if (P.ncomp > 1) {
-                const float *cum = P.cumExt + cell;
-                comp = find_index(rc, [cum, ncell](int k) { return k == 1 ? 0.0f : cum[(size_t)(k - 2) * ncell]; },
-                                  P.ncomp + 1, 0);
+              int comp = 1;                                               // :637-638
+              if (P.ncomp > 1 || Rng::kReplay) {
+                const float rc = rng.next();
+                if (P.ncomp > 1) {
+                  const float *cum = P.cumExt + cell;
+                  comp = find_index(rc, [cum, ncell](int k) { return k == 1 ? 0.0f : cum[(size_t)(k - 2) * ncell]; },
+                                    P.ncomp + 1, 0);
+                }
               }
               const float ssa = P.ssa[(size_t)(comp - 1) * ncell + cell];
               if (ssa < 1.0f) {                                           // :642-649
@@ -259,9 +279,10 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
               if (w <= kTiny) { fate = 2; st = ST_NEW; }
               else {
                 const int pfi = P.pfIndex[(size_t)(comp - 1) * ncell + cell];
-                const int n = P.comp[comp - 1].nInv;
-                const float theta = scattering_angle(rng.next(), P.comp[comp - 1].inv + (size_t)(pfi - 1) * n, n);
-                next_direct(rng, cosf(theta), r.dx, r.dy, r.dz);          // :684-687
+                const CompTables ct = P.comp[comp - 1];
+                const float cosS = scattering_cosine(rng.next(), ct.invCos + (size_t)(pfi - 1) * ct.nInv, ct.nInv,
+                                                     refined_rcp((float)ct.nInv));
+                next_direct(rng, cosS, r.dx, r.dy, r.dz);                 // :684-687
                 st = ST_TRACE;
               }
             } else {
@@ -269,42 +290,63 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
             }
           }
         }
-        if (st == ST_NEW) {
-          if (pid >= 0 && A.fate) {
+        if (st == ST_NEW && pid >= 0) {
+          if (A.fate) {
             A.fate[pid] = fate; A.fateColumn[pid] = fateCol; A.fateWeight[pid] = fateW; A.fateOrder[pid] = order;
             A.drawsUsed[pid] = (int32_t)rng.draws;
           }
-          if (pid >= 0) cnt.draws += rng.draws;
-          const long long next = (long long)atomicAdd(A.workCounter, 1ull);
-          if (next >= A.nPhotons) { st = ST_DONE; pid = -1; }
-          else {                                                          // :453-470
-            pid = next;
-            RngInit<Rng>::start(rng, A, pid);
-            float px, py, pz, mu, phi;
-            if (A.srcKind == 0) {   // newPhotonStream_Directional, Code/monteCarloIllumination.f95:91-99
-              px = rng.next(); py = rng.next();
-              pz = 1.0f - spacingf(1.0f);
-              mu = A.solarMu; phi = A.solarPhi;
-            } else {
-              px = A.sx[pid]; py = A.sy[pid]; pz = A.sz[pid]; mu = A.smu[pid]; phi = A.sphi[pid];
-            }
-            order = 0; fate = -1; fateCol = -1; fateW = 0.0f;
-            make_dircos(mu, phi, r.dx, r.dy, r.dz);
-            w = 1.0f;
-            cnt.photons++;
-            r.x = P.x0 + px * (P.xMax - P.x0);
-            r.y = P.y0 + py * (P.yMax - P.y0);
-            r.z = P.z0 + pz * (P.zMax - P.z0);
-            r.ix = 1; r.iy = 1; r.iz = 1;
-            find_xy(P, L, r.x, r.y, r.ix, r.iy);
-            find_z(P, L, r.z, r.iz);
-            st = ST_TRACE;
+          cnt.draws += rng.draws;
+          pid = -1;
+        }
+      }
+      // ---- part 2 (converged): hand out photon indices from the wave's reservoir
+      const unsigned long long newMask = __ballot(wantEvent && st == ST_NEW);
+      if (newMask != 0ull) {
+        int need = __popcll(newMask);
+        int rank = __popcll(newMask & (laneBit - 1ull));
+        const bool isNew = (newMask & laneBit) != 0ull;
+        for (int round = 0; round < 2 && need > 0; ++round) {   // at most one refill per visit (chunk >= 64)
+          const long long avail = res.end - res.next;
+          if (isNew && pid < 0 && rank < avail) pid = res.next + rank;
+          const long long taken = avail < need ? avail : need;
+          res.next += taken;
+          need -= (int)taken;
+          rank -= (int)taken;
+          if (need > 0) {
+            if (res.end >= A.nPhotons) break;                   // batch exhausted
+            res.refill(A);
           }
+        }
+        if (isNew && pid < 0) st = ST_DONE;
+      }
+      // ---- part 3: new photons start, every live lane draws its next optical depth
+      if (wantEvent && st != ST_DONE) {
+        if (st == ST_NEW) {                                               // :453-470
+          RngInit<Rng>::start(rng, A, pid);
+          float px, py, pz;
+          if (A.srcKind == 0) {   // newPhotonStream_Directional, Code/monteCarloIllumination.f95:91-99
+            px = rng.next(); py = rng.next();
+            pz = 1.0f - spacingf(1.0f);
+            r.dx = A.solarDx; r.dy = A.solarDy; r.dz = A.solarDz;
+          } else {
+            px = A.sx[pid]; py = A.sy[pid]; pz = A.sz[pid];
+            make_dircos(A.smu[pid], A.sphi[pid], r.dx, r.dy, r.dz);
+          }
+          order = 0; fate = -1; fateCol = -1; fateW = 0.0f;
+          w = 1.0f;
+          cnt.photons++;
+          r.x = P.x0 + px * (P.xMax - P.x0);
+          r.y = P.y0 + py * (P.yMax - P.y0);
+          r.z = P.z0 + pz * (P.zMax - P.z0);
+          r.ix = 1; r.iy = 1; r.iz = 1;
+          find_xy(P, L, r.x, r.y, r.ix, r.iy);
+          find_z(P, L, r.z, r.iz);
+          st = ST_TRACE;
         }
         if (st == ST_TRACE) {                                             // :480
           const float tau = -logf(fmaxf(kTiny, rng.next()));
           r.acc = 0.0f; r.target = tau;
-          if (P.useRayTracing) cnt.calls++;
+          if (P.useRayTracing) { cnt.calls++; r.set_direction(); }
           else {                                                          // :494-496 max cross-section move
             r.x = make_periodic(r.x + r.dx * tau / P.maxExt, P.x0, P.xMax);
             r.y = make_periodic(r.y + r.dy * tau / P.maxExt, P.y0, P.yMax);
@@ -360,6 +402,7 @@ __global__ void __launch_bounds__(256) trace_rays_kernel(const DevProblem P, lon
   r.x = pos[3 * i]; r.y = pos[3 * i + 1]; r.z = pos[3 * i + 2];
   r.dx = dir[3 * i]; r.dy = dir[3 * i + 1]; r.dz = dir[3 * i + 2];
   r.ix = idx[3 * i]; r.iy = idx[3 * i + 1]; r.iz = idx[3 * i + 2];
+  r.set_direction();
   r.acc = 0.0f;
   const bool hasTarget = target[i] >= 0.0f;
   r.target = target[i];
@@ -370,6 +413,17 @@ __global__ void __launch_bounds__(256) trace_rays_kernel(const DevProblem P, lon
   idx[3 * i] = r.ix; idx[3 * i + 1] = r.iy; idx[3 * i + 2] = r.iz;
   tau[i] = r.acc;
   steps[i] = ns;
+}
+
+// Test hook: exact_div / exact_sqrt against the IEEE operations they replace.
+__global__ void arith_check_kernel(long long n, const float *num, const float *den, unsigned long long *mismatch) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = num[i], b = den[i];
+  const float q = exact_div(a, b, refined_rcp(b)), qRef = a / b;
+  if (__float_as_uint(q) != __float_as_uint(qRef)) atomicAdd(&mismatch[0], 1ull);
+  const float x = fabsf(a);
+  if (__float_as_uint(exact_sqrt(x)) != __float_as_uint(sqrtf(x))) atomicAdd(&mismatch[1], 1ull);
 }
 
 // Test hook: raw Philox blocks as the photon streams see them.

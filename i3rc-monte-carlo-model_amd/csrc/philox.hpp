@@ -40,6 +40,7 @@ __host__ __device__ inline float u32_to_unit_float(uint32_t u) {
 
 // Per-lane stream with a 4-deep buffer held in registers (no dynamic register indexing).
 struct PhiloxStream {
+  static constexpr bool kReplay = false;
   uint32_t k0, k1, id_lo, id_hi, block;
   uint32_t b1, b2, b3;  // buffered outputs 1..3 of the current block
   int have;             // how many of b1..b3 are still unused (3,2,1,0)
@@ -64,10 +65,21 @@ struct PhiloxStream {
     draws++;
     return u32_to_unit_float(u);
   }
+  // Azimuth for next_direct (:2099-2103).  The reference rejection-samples a point of the unit disc (2 deviates per
+  // try, 21 % retries) only to get a uniformly distributed azimuth without trigonometry.  On the GPU one deviate and
+  // the hardware sin/cos (arguments in revolutions) give the same distribution with no divergent retry loop; d
+  // carries the actual squared radius so next_direct's normalisation stays exact.
+  __device__ inline void disc_point(float &ax, float &ay, float &d) {
+    const float turn = next();
+    ax = __builtin_amdgcn_cosf(turn);
+    ay = __builtin_amdgcn_sinf(turn);
+    d = ax * ax + ay * ay;
+  }
 };
 
 // Test stream: deviates come from a buffer (the reference's MT19937 floats); see i3rc_hip_run_replay.
 struct ReplayStream {
+  static constexpr bool kReplay = true;   // consume deviates exactly where the reference does
   const float *buf;
   int64_t pos, end;
   uint32_t draws;
@@ -76,6 +88,15 @@ struct ReplayStream {
     float r = pos < end ? buf[pos] : 0.5f;
     pos++; draws++;
     return r;
+  }
+  // the reference's own rejection sampling, deviate for deviate (next_direct :2098-2103)
+  __device__ inline void disc_point(float &ax, float &ay, float &d) {
+    d = 2.0f;
+    while (d > 1.0f) {
+      ax = 1.0f - 2.0f * next();
+      ay = 1.0f - 2.0f * next();
+      d = ax * ax + ay * ay;
+    }
   }
 };
 

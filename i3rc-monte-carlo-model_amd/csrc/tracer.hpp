@@ -19,7 +19,7 @@ constexpr float kPi   = 3.14159265358979312f;  // monteCarloRadiativeTransfer.f9
 
 // Per-component phase-function tables (:100-105): inverse [nEntries][nInv], forward [nEntries][nFwd].
 struct CompTables {
-  const float *inv, *fwd, *fwdOrig;
+  const float *inv, *invCos, *fwd, *fwdOrig;   // invCos[k] = cos(inv[k]) (built by i3rc_hip_set_inverse_table)
   int nInv, nFwd;
 };
 
@@ -52,6 +52,8 @@ struct RunArgs {
   long long firstPhoton, nPhotons;
   unsigned long long *workCounter;    // device word, zeroed before launch
   int srcKind; float solarMu, solarPhi;
+  float solarDx, solarDy, solarDz;    // makeDirectionCosines(solarMu, solarPhi) evaluated once on the host
+  int chunk;                          // photon indices a wave reserves per visit of the work counter
   const float *sx, *sy, *sz, *smu, *sphi;   // explicit stream (device)
   // replay
   const float *randoms; long long nRandoms; const long long *drawStart;
@@ -70,6 +72,33 @@ struct Lds {
 __device__ __forceinline__ float spacingf(float x) {
   const uint32_t e = __float_as_uint(x) & 0x7f800000u;
   return e > (23u << 23) ? __uint_as_float(e - (23u << 23)) : kTiny;
+}
+
+// ---- correctly rounded float32 divide / sqrt from the hardware approximations --------------------------------
+// The reference divides by the same direction cosine at every voxel step of a trace.  v_rcp_f32 (1 ulp) refined
+// once gives r1 ~ 1/d; n/d is then q0 = n*r1 followed by two fused residual corrections -- the tail of the IEEE
+// division expansion hipcc emits, minus its per-call reciprocal and range scaling: 5 FMA-class instructions instead
+// of ~13, same correctly rounded quotient (bit-identity with `/` is checked on the device by
+// tests/test_gpu_parity.py::test_exact_arithmetic_helpers and by the bit-exact tracer tests).  Valid for
+// 1e-20 <= |d| and results far from overflow, which callers guarantee (else they use `/`).
+__device__ __forceinline__ float refined_rcp(float d) {
+  const float r0 = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+}
+__device__ __forceinline__ float exact_div(float n, float d, float r1) {
+  const float q0 = n * r1;
+  const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r1, q0);
+  return __builtin_fmaf(__builtin_fmaf(-d, q1, n), r1, q1);
+}
+// v_sqrt_f32 is within 1 ulp: pick the neighbour with the right residual sign (the correction LLVM uses for
+// correctly rounded f32 sqrt, without the denormal rescaling: arguments here are 0 or normal).
+__device__ __forceinline__ float exact_sqrt(float x) {
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float sDn = __uint_as_float(__float_as_uint(s) - 1u), sUp = __uint_as_float(__float_as_uint(s) + 1u);
+  const float eDn = __builtin_fmaf(-sDn, s, x), eUp = __builtin_fmaf(-sUp, s, x);
+  s = eDn <= 0.0f ? sDn : s;
+  s = eUp > 0.0f ? sUp : s;
+  return x == 0.0f ? 0.0f : s;
 }
 
 // findIndex, Code/numericUtilities.f95:195-248 (1-based table; firstGuess <= 0: absent)
@@ -108,7 +137,7 @@ __device__ __forceinline__ float make_periodic(float a, float aMin, float aMax) 
 
 // makeDirectionCosines :2041-2059
 __device__ __forceinline__ void make_dircos(float mu, float phi, float &dx, float &dy, float &dz) {
-  const float sinTheta = sqrtf(1.0f - mu * mu);
+  const float sinTheta = exact_sqrt(1.0f - mu * mu);
   const float c = cosf(phi), s = sinf(phi);
   dx = sinTheta * c; dy = sinTheta * s; dz = mu;
 }
@@ -116,8 +145,14 @@ __device__ __forceinline__ void make_dircos(float mu, float phi, float &dx, floa
 struct Ray {
   float x, y, z;
   float dx, dy, dz;
+  float rx, ry, rz;   // refined reciprocals of the direction cosines (set_direction)
+  int slow;           // 1: some |direction cosine| < 1e-20 -> plain IEEE division (and the 2*tiny test) per step
   int ix, iy, iz;
   float acc, target;
+  __device__ __forceinline__ void set_direction() {
+    slow = fminf(fminf(fabsf(dx), fabsf(dy)), fabsf(dz)) < 1e-20f;
+    rx = refined_rcp(dx); ry = refined_rcp(dy); rz = refined_rcp(dz);
+  }
 };
 
 enum StepResult { STEP_CONTINUE = 0, STEP_DONE = 1, STEP_ERROR = 2 };
@@ -132,9 +167,16 @@ __device__ __forceinline__ StepResult trace_step(const DevProblem &P, const Lds 
   const int sx = r.dx >= 0.0f ? 1 : 0, sy = r.dy >= 0.0f ? 1 : 0, sz = r.dz >= 0.0f ? 1 : 0;
   const int cx = r.dx >= 0.0f ? 1 : -1, cy = r.dy >= 0.0f ? 1 : -1, cz = r.dz >= 0.0f ? 1 : -1;
   const float ex = L.xE[r.ix + sx - 1], ey = L.yE[r.iy + sy - 1], ez = L.zE[r.iz + sz - 1];
-  const float stx = fabsf(r.dx) >= 2.0f * kTiny ? (ex - r.x) / r.dx : kHuge;
-  const float sty = fabsf(r.dy) >= 2.0f * kTiny ? (ey - r.y) / r.dy : kHuge;
-  const float stz = fabsf(r.dz) >= 2.0f * kTiny ? (ez - r.z) / r.dz : kHuge;
+  float stx, sty, stz;
+  if (__builtin_expect(r.slow, 0)) {   // a direction cosine of (almost) zero: the reference's guarded division
+    stx = fabsf(r.dx) >= 2.0f * kTiny ? (ex - r.x) / r.dx : kHuge;
+    sty = fabsf(r.dy) >= 2.0f * kTiny ? (ey - r.y) / r.dy : kHuge;
+    stz = fabsf(r.dz) >= 2.0f * kTiny ? (ez - r.z) / r.dz : kHuge;
+  } else {
+    stx = exact_div(ex - r.x, r.dx, r.rx);
+    sty = exact_div(ey - r.y, r.dy, r.ry);
+    stz = exact_div(ez - r.z, r.dz, r.rz);
+  }
   float step = stx;
   if (sty < step) step = sty;
   if (stz < step) step = stz;
@@ -144,7 +186,7 @@ __device__ __forceinline__ StepResult trace_step(const DevProblem &P, const Lds 
   const float ext = P.ldsGrid ? L.ext[cell] : P.totalExt[cell];
   if (hasTarget) {
     if (r.acc + step * ext > r.target) {
-      step = (r.target - r.acc) / ext;
+      step = ext >= 1e-20f ? exact_div(r.target - r.acc, ext, refined_rcp(ext)) : (r.target - r.acc) / ext;
       r.x = r.x + step * r.dx;
       r.y = r.y + step * r.dy;
       r.z = r.z + step * r.dz;
@@ -200,30 +242,30 @@ __device__ __forceinline__ void find_z(const DevProblem &P, const Lds &L, float 
   }
 }
 
-// computeScatteringAngle :1390-1417 (quirk Q1: `left` is not rescaled by n)
-__device__ __forceinline__ float scattering_angle(float r, const float *tab, int n) {
+// computeScatteringAngle :1390-1417 (quirk Q1: `left` is not rescaled by n) followed by cos(angle) (:687).
+// The table holds cos(T(k)) (float64 cosine of the reference's float32 angle table, rounded once).  Because the
+// interpolation weight `left` is < 1/n, cos((1-left) T(k) + left T(k+1)) and (1-left) cos T(k) + left cos T(k+1)
+// differ by < left * dT^2 / 2 ~ 1e-11, far below one float32 ulp: the same cosine without a 57-op cosf per event.
+__device__ __forceinline__ float scattering_cosine(float r, const float *cosTab, int n, float rcpN) {
   const int k = (int)(r * (float)n) + 1;
   if (k < n) {
-    const float left = r - (float)(k - 1) / (float)n;
-    return (1.0f - left) * tab[k - 1] + left * tab[k];
+    const float left = r - exact_div((float)(k - 1), (float)n, rcpN);
+    return (1.0f - left) * cosTab[k - 1] + left * cosTab[k];
   }
-  return tab[n - 1];
+  return cosTab[n - 1];
 }
 
 // next_direct :2086-2113
 template <class Rng>
 __device__ __forceinline__ void next_direct(Rng &rng, float cosS, float &s0, float &s1, float &s2) {
-  float d = 2.0f, ax = 0.0f, ay = 0.0f;
-  while (d > 1.0f) {
-    ax = 1.0f - 2.0f * rng.next();
-    ay = 1.0f - 2.0f * rng.next();
-    d = ax * ax + ay * ay;
-  }
-  float b = sqrtf((1.0f - cosS * cosS) / d);
+  float d, ax, ay;
+  rng.disc_point(ax, ay, d);   // a point of the unit disc (any radius): only its azimuth matters
+  float b = exact_sqrt(exact_div(1.0f - cosS * cosS, d, refined_rcp(d)));
   ax = ax * b;
   ay = ay * b;
   b = s0 * ax - s1 * ay;
-  d = cosS - b / (1.0f + fabsf(s2));
+  const float den = 1.0f + fabsf(s2);
+  d = cosS - exact_div(b, den, refined_rcp(den));
   s0 = s0 * d + ax;
   s1 = s1 * d - ay;
   s2 = s2 * cosS - copysignf(fabsf(b), s2 * b);

@@ -447,6 +447,12 @@ class Integrator:
         out.update(self.finish())
         return out
 
+    def arith_check(self, num, den):
+        num, den = f32(num), f32(den)
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.i3rc_hip_arith_check(self._h, len(num), pf(num), pf(den), C.byref(a), C.byref(b)), "arith_check")
+        return a.value, b.value
+
     def philox_blocks(self, seed, firstPhoton, n, blocks):
         out = np.zeros((n, blocks, 4), np.uint32)
         outf = np.zeros((n, blocks, 4), np.float32)

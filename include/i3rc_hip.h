@@ -176,13 +176,18 @@ int i3rc_hip_last_kernel_ms(i3rc_hip_integrator *h, float *ms);
 int i3rc_hip_kernel_ms_history(i3rc_hip_integrator *h, int n, float *ms);
 
 /* Experiment knobs (not part of the reference API): lanes that must be waiting before a wavefront runs its
- * event phase (1..64, default 64) and workgroups per CU (0 = occupancy query). */
+ * event phase (1..64, default 40) and workgroups per CU (0 = occupancy query). */
 int i3rc_hip_set_tuning(i3rc_hip_integrator *h, int evThreshold, int blocksPerCU);
 
 /* Test hook: the raw Philox4x32-10 blocks (out[n][blocksPerPhoton][4]) of photons firstPhoton..+n-1 and the
  * float32 deviates the photon streams derive from them (outf, same shape). */
 int i3rc_hip_philox_blocks(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int64_t firstPhoton, int64_t n,
                            int blocksPerPhoton, uint32_t *out, float *outf);
+
+/* Test hook: over n pairs (num[i], den[i]) counts where the kernels' reciprocal-based correctly rounded division
+ * differs from IEEE num/den, and where their corrected hardware sqrt differs from sqrtf(|num|). */
+int i3rc_hip_arith_check(i3rc_hip_integrator *h, int64_t n, const float *num, const float *den, int64_t *divMismatch,
+                         int64_t *sqrtMismatch);
 
 /* Library / device probe that needs no GPU work: returns the number of HIP devices (or -1). */
 int i3rc_hip_device_count(void);

@@ -62,6 +62,25 @@ def test_philox_device_matches_reference_implementation():
     assert outf.min() >= 0.0 and outf.max() <= 1.0
 
 
+def test_exact_arithmetic_helpers():
+    """The kernels replace IEEE `/` (by a direction cosine that is constant along a trace) and sqrtf by hardware
+    approximations plus fused corrections; the results must be the correctly rounded ones, bit for bit."""
+    g = make_gpu(cases.plane_parallel(), hg_table())
+    rng = np.random.default_rng(7)
+    n = 4_000_000
+    # numerators: distances to cell faces (incl. 0 and tiny), denominators: direction cosines / extinctions
+    num = (rng.uniform(-1, 1, n) * 10.0 ** rng.uniform(-6, 4, n)).astype(np.float32)
+    num[:1000] = 0.0
+    den = (rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(-19, 0, n)).astype(np.float32)
+    den[1000:2000] = rng.uniform(0.5, 1.0, 1000).astype(np.float32)
+    bad_div, bad_sqrt = g.arith_check(num, den)
+    assert bad_div == 0 and bad_sqrt == 0, (bad_div, bad_sqrt)
+    # unit-interval arguments as they occur in makeDirectionCosines / next_direct / the Lambertian surface
+    u = rng.random(n).astype(np.float32)
+    bad_div, bad_sqrt = g.arith_check(u, (1.0 + u).astype(np.float32))
+    assert bad_div == 0 and bad_sqrt == 0, (bad_div, bad_sqrt)
+
+
 def _random_rays(rng, d, n, oracle_integ):
     nz, ny, nx = d["ext"].shape
     ix = rng.integers(1, nx + 1, n)
