@@ -194,7 +194,10 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
     const unsigned long long trMask = __ballot(st == ST_TRACE);
     if (evMask == 0ull && trMask == 0ull) break;
     if (__popcll(evMask) >= evThreshold || trMask == 0ull) {
-      // ---- part 1: what ended the trace
+      // ---- part A: endings that need no random number -- tracer drop, exit through the top, arrival at a black
+      //      surface -- are tallied first so that the lanes can be given their next photon before the wave
+      //      generates its random block (part C), which then serves old and new photons in one go.
+      const bool blackSurface = !Rng::kReplay && !P.useBDRF && !(P.albedo > kTiny) && !INTENSITY;
       if (wantEvent) {
         if (st == ST_DROPPED) { cnt.dropped++; fate = 3; st = ST_NEW; }   // :488-489
         if (st == ST_EVENT) {
@@ -209,7 +212,75 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
             cnt.top++;
             fate = 0; fateCol = c2; fateW = w;
             st = ST_NEW;
-          } else if (r.z <= surfaceZ) {                                   // :515-580
+          } else if (blackSurface && r.z <= surfaceZ) {                   // :515-531, :560-562 with albedo 0
+            order++;
+            if (!P.useRayTracing) {
+              r.x = make_periodic(r.x - r.dx * fabsf((r.z - P.z0) / r.dz), P.x0, P.xMax);
+              r.y = make_periodic(r.y - r.dy * fabsf((r.z - P.z0) / r.dz), P.y0, P.yMax);
+              find_xy(P, L, r.x, r.y, r.ix, r.iy);
+            }
+            const int c2 = (r.iy - 1) * P.nx + (r.ix - 1);
+            tally.down(c2, w);
+            cnt.surf++;
+            fate = 1; fateCol = c2; fateW = w;
+            st = ST_NEW;
+          }
+        }
+        if (st == ST_NEW && pid >= 0) {
+          if (A.fate) {
+            A.fate[pid] = fate; A.fateColumn[pid] = fateCol; A.fateWeight[pid] = fateW; A.fateOrder[pid] = order;
+            A.drawsUsed[pid] = (int32_t)rng.draws;
+          }
+          cnt.draws += rng.draws;
+          pid = -1;
+        }
+      }
+      // ---- part B (converged): hand out photon indices from the wave's reservoir
+      const unsigned long long newMask = __ballot(wantEvent && st == ST_NEW);
+      if (newMask != 0ull) {
+        int need = __popcll(newMask);
+        int rank = __popcll(newMask & (laneBit - 1ull));
+        const bool isNew = (newMask & laneBit) != 0ull;
+        for (int round = 0; round < 2 && need > 0; ++round) {   // at most one refill per visit (chunk >= 64)
+          const long long avail = res.end - res.next;
+          if (isNew && pid < 0 && rank >= 0 && rank < avail) pid = res.next + rank;
+          const long long taken = avail < need ? avail : need;
+          res.next += taken;
+          need -= (int)taken;
+          rank -= (int)taken;
+          if (need > 0) {
+            if (res.end >= A.nPhotons) break;                   // batch exhausted
+            res.refill(A);
+          }
+        }
+        if (isNew && pid < 0) st = ST_DONE;
+        if (isNew && pid >= 0) RngInit<Rng>::start(rng, A, pid);
+      }
+      // ---- part C: one random block per lane for this event, then the event itself
+      if (wantEvent && st != ST_DONE) {
+        rng.begin_event();
+        if (st == ST_NEW) {                                               // :453-470
+          float px, py, pz;
+          if (A.srcKind == 0) {   // newPhotonStream_Directional, Code/monteCarloIllumination.f95:91-99
+            px = rng.next(); py = rng.next();
+            pz = 1.0f - spacingf(1.0f);
+            r.dx = A.solarDx; r.dy = A.solarDy; r.dz = A.solarDz;
+          } else {
+            px = A.sx[pid]; py = A.sy[pid]; pz = A.sz[pid];
+            make_dircos(A.smu[pid], A.sphi[pid], r.dx, r.dy, r.dz);
+          }
+          order = 0; fate = -1; fateCol = -1; fateW = 0.0f;
+          w = 1.0f;
+          cnt.photons++;
+          r.x = P.x0 + px * (P.xMax - P.x0);
+          r.y = P.y0 + py * (P.yMax - P.y0);
+          r.z = P.z0 + pz * (P.zMax - P.z0);
+          r.ix = 1; r.iy = 1; r.iz = 1;
+          find_xy(P, L, r.x, r.y, r.ix, r.iy);
+          find_z(P, L, r.z, r.iz);
+          st = ST_TRACE;
+        } else if (st == ST_EVENT) {
+          if (r.z <= surfaceZ) {                                          // :515-580
             order++;
             if (!P.useRayTracing) {
               r.x = make_periodic(r.x - r.dx * fabsf((r.z - P.z0) / r.dz), P.x0, P.xMax);
@@ -232,7 +303,7 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
               make_dircos(mu, phi, r.dx, r.dy, r.dz);
               if (INTENSITY)
                 intensity_contribution(P, L, rng, cnt, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, 0, order);
-              st = ST_TRACE;  // provisional: a new optical depth is drawn in part 3
+              st = ST_TRACE;
             }
           } else {                                                        // :581-689
             bool scatterThis = true;
@@ -290,59 +361,6 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
             }
           }
         }
-        if (st == ST_NEW && pid >= 0) {
-          if (A.fate) {
-            A.fate[pid] = fate; A.fateColumn[pid] = fateCol; A.fateWeight[pid] = fateW; A.fateOrder[pid] = order;
-            A.drawsUsed[pid] = (int32_t)rng.draws;
-          }
-          cnt.draws += rng.draws;
-          pid = -1;
-        }
-      }
-      // ---- part 2 (converged): hand out photon indices from the wave's reservoir
-      const unsigned long long newMask = __ballot(wantEvent && st == ST_NEW);
-      if (newMask != 0ull) {
-        int need = __popcll(newMask);
-        int rank = __popcll(newMask & (laneBit - 1ull));
-        const bool isNew = (newMask & laneBit) != 0ull;
-        for (int round = 0; round < 2 && need > 0; ++round) {   // at most one refill per visit (chunk >= 64)
-          const long long avail = res.end - res.next;
-          if (isNew && pid < 0 && rank < avail) pid = res.next + rank;
-          const long long taken = avail < need ? avail : need;
-          res.next += taken;
-          need -= (int)taken;
-          rank -= (int)taken;
-          if (need > 0) {
-            if (res.end >= A.nPhotons) break;                   // batch exhausted
-            res.refill(A);
-          }
-        }
-        if (isNew && pid < 0) st = ST_DONE;
-      }
-      // ---- part 3: new photons start, every live lane draws its next optical depth
-      if (wantEvent && st != ST_DONE) {
-        if (st == ST_NEW) {                                               // :453-470
-          RngInit<Rng>::start(rng, A, pid);
-          float px, py, pz;
-          if (A.srcKind == 0) {   // newPhotonStream_Directional, Code/monteCarloIllumination.f95:91-99
-            px = rng.next(); py = rng.next();
-            pz = 1.0f - spacingf(1.0f);
-            r.dx = A.solarDx; r.dy = A.solarDy; r.dz = A.solarDz;
-          } else {
-            px = A.sx[pid]; py = A.sy[pid]; pz = A.sz[pid];
-            make_dircos(A.smu[pid], A.sphi[pid], r.dx, r.dy, r.dz);
-          }
-          order = 0; fate = -1; fateCol = -1; fateW = 0.0f;
-          w = 1.0f;
-          cnt.photons++;
-          r.x = P.x0 + px * (P.xMax - P.x0);
-          r.y = P.y0 + py * (P.yMax - P.y0);
-          r.z = P.z0 + pz * (P.zMax - P.z0);
-          r.ix = 1; r.iy = 1; r.iz = 1;
-          find_xy(P, L, r.x, r.y, r.ix, r.iy);
-          find_z(P, L, r.z, r.iz);
-          st = ST_TRACE;
-        }
         if (st == ST_TRACE) {                                             // :480
           const float tau = -logf(fmaxf(kTiny, rng.next()));
           r.acc = 0.0f; r.target = tau;
@@ -353,6 +371,15 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
             r.z = r.z + r.dz * tau / P.maxExt;
             st = ST_EVENT;
           }
+        }
+        // a photon that died in part C (roulette, absorbing surface) is closed here and respawns at the next event phase
+        if (st == ST_NEW && pid >= 0) {
+          if (A.fate) {
+            A.fate[pid] = fate; A.fateColumn[pid] = fateCol; A.fateWeight[pid] = fateW; A.fateOrder[pid] = order;
+            A.drawsUsed[pid] = (int32_t)rng.draws;
+          }
+          cnt.draws += rng.draws;
+          pid = -1;
         }
       }
     }

@@ -38,30 +38,36 @@ __host__ __device__ inline float u32_to_unit_float(uint32_t u) {
   return (float)((double)u * (1.0 / 4294967295.0));
 }
 
-// Per-lane stream with a 4-deep buffer held in registers (no dynamic register indexing).
+// Per-lane stream.  begin_event() makes one Philox block (4 deviates) for the whole wavefront at ONE program point,
+// so the 10-round block function runs once per event with every lane active; next() then only selects from the
+// buffered words.  (Refilling lazily inside next() ran the block function at ~9 % lane utilisation, because lanes
+// drift to different buffer phases and every call site refills for whoever happens to be empty.)  An event that
+// needs a fifth deviate (component choice + roulette + angle + azimuth + optical depth) refills on demand.
 struct PhiloxStream {
   static constexpr bool kReplay = false;
   uint32_t k0, k1, id_lo, id_hi, block;
-  uint32_t b1, b2, b3;  // buffered outputs 1..3 of the current block
-  int have;             // how many of b1..b3 are still unused (3,2,1,0)
+  uint32_t b0, b1, b2, b3;   // current block
+  int have;                  // unused words of the block: next() hands out b[4 - have]
   uint32_t draws;
 
   __device__ inline void start(uint32_t seed0, uint32_t seed1, uint64_t photon) {
     k0 = seed0; k1 = seed1;
     id_lo = (uint32_t)photon; id_hi = (uint32_t)(photon >> 32);
-    block = 0; have = 0; draws = 0; b1 = b2 = b3 = 0;
+    block = 0; have = 0; draws = 0; b0 = b1 = b2 = b3 = 0;
   }
+  __device__ inline void refill() {
+    const Philox4 o = philox4x32_10(id_lo, id_hi, block, 0u, k0, k1);
+    block++;
+    b0 = o.v[0]; b1 = o.v[1]; b2 = o.v[2]; b3 = o.v[3];
+    have = 4;
+  }
+  // fresh block for this event; leftovers of the previous block are discarded (blocks are cheap per lane when the
+  // whole wave computes them together, expensive when a few lanes do)
+  __device__ inline void begin_event() { refill(); }
   __device__ inline float next() {
-    uint32_t u;
-    if (have == 0) {
-      Philox4 o = philox4x32_10(id_lo, id_hi, block, 0u, k0, k1);
-      block++;
-      u = o.v[0]; b1 = o.v[1]; b2 = o.v[2]; b3 = o.v[3];
-      have = 3;
-    } else {
-      u = have == 3 ? b1 : (have == 2 ? b2 : b3);
-      have--;
-    }
+    if (have == 0) refill();
+    const uint32_t u = have == 4 ? b0 : (have == 3 ? b1 : (have == 2 ? b2 : b3));
+    have--;
     draws++;
     return u32_to_unit_float(u);
   }
@@ -84,6 +90,7 @@ struct ReplayStream {
   int64_t pos, end;
   uint32_t draws;
   __device__ inline void start(const float *b, int64_t p, int64_t e) { buf = b; pos = p; end = e; draws = 0; }
+  __device__ inline void begin_event() {}
   __device__ inline float next() {
     float r = pos < end ? buf[pos] : 0.5f;
     pos++; draws++;

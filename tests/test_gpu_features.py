@@ -5,7 +5,7 @@ import pytest
 
 import i3rc_monte_carlo_model_amd as M
 from tests import cases
-from tests.test_gpu_parity import (_assert_3sigma, _batches_gpu, _batches_oracle, hg_table, make_gpu, make_oracle)
+from tests.test_gpu_parity import (_assert_3sigma, _batches_gpu, _batches_oracle, _parity, hg_table, make_gpu, make_oracle)
 
 pytestmark = pytest.mark.gpu
 f32 = np.float32
@@ -33,9 +33,8 @@ def test_intensity_plain_local_estimate(oracle):
     d = cases.step_cloud(ssa=0.99, nlayers=8)
     g, o = _intensity_pair(oracle, d, hg_table(), gpu_params=dict(surfaceAlbedo=0.3), oracle_params=dict(surfaceAlbedo=0.3))
     nb, n = 8, 4000
-    gr, orr = _batches_gpu(g, nb, n, 0.7, az=20.0), _batches_oracle(oracle, o, nb, n, 0.7, az=20.0)
-    for key in ("fluxUp", "fluxDown", "intensity"):
-        _assert_3sigma(gr, orr, key)
+    gr, orr = _parity(oracle, g, o, nb, n, 0.7, az=20.0, keys=("fluxUp", "fluxDown", "intensity"))
+    nb = len(gr)
     # intensity is the sum over components (0 = surface) of intensityByComponent; component 0 is left
     # un-normalised by the reference (:390), so compare the cloud component only
     a = np.stack([r["intensityByComponent"][1] for r in gr]).mean(0)
@@ -50,10 +49,7 @@ def test_intensity_russian_roulette_iwabuchi(oracle):
     gp = dict(useRussianRouletteForIntensity=True, zetaMin=0.3)
     op = dict(useRRForIntensity=1, zetaMin=0.3)
     g, o = _intensity_pair(oracle, d, hg_table(), gpu_params=gp, oracle_params=op, mus=[1.0, 0.5, 0.3], phis=[0.0, 0.0, 225.0])
-    nb, n = 8, 6000
-    gr, orr = _batches_gpu(g, nb, n, 1.0), _batches_oracle(oracle, o, nb, n, 1.0)
-    _assert_3sigma(gr, orr, "intensity")
-    _assert_3sigma(gr, orr, "fluxUp")
+    _parity(oracle, g, o, 8, 6000, 1.0, keys=("intensity", "fluxUp"))
 
 
 def test_intensity_hybrid_phase_function_and_contribution_limit(oracle):
@@ -63,9 +59,7 @@ def test_intensity_hybrid_phase_function_and_contribution_limit(oracle):
               limitIntensityContributions=True, maxIntensityContribution=0.5)
     op = dict(useHybrid=1, numOrdersOrig=1, limitContrib=1, maxContrib=0.5)
     g, o = _intensity_pair(oracle, d, tab, gpu_params=gp, oracle_params=op, hybrid_width=7.0, mus=[1.0, 0.9], phis=[0.0, 10.0])
-    nb, n = 8, 5000
-    gr, orr = _batches_gpu(g, nb, n, 0.95), _batches_oracle(oracle, o, nb, n, 0.95)
-    _assert_3sigma(gr, orr, "intensity")
+    gr, orr = _parity(oracle, g, o, 8, 5000, 0.95, keys=("intensity",))
     assert any(r["raw"][g.layout().intensityExcess:g.layout().intensityExcess + 4].sum() > 0 for r in gr)
 
 
@@ -77,10 +71,7 @@ def test_surface_brdf_grid(oracle):
     g = make_gpu(d, hg_table(), surfaceBDRF=M.new_SurfaceDescription(alb.T[None].copy(), xs, ys))
     o = make_oracle(oracle, d, [hg_table().inverse_table(9001)])
     o.specify(surfaceBDRF=(xs, ys, alb))
-    nb, n = 8, 20000
-    gr, orr = _batches_gpu(g, nb, n, 0.8, az=45.0), _batches_oracle(oracle, o, nb, n, 0.8, az=45.0)
-    _assert_3sigma(gr, orr, "fluxUp")
-    _assert_3sigma(gr, orr, "fluxDown")
+    _parity(oracle, g, o, 8, 20000, 0.8, az=45.0)
     # uniform surface through the BRDF path == surfaceAlbedo special case (statistically)
     g2 = make_gpu(d, hg_table(), surfaceBDRF=M.new_SurfaceDescription([0.4]))
     g3 = make_gpu(d, hg_table(), surfaceAlbedo=0.4)
@@ -98,10 +89,7 @@ def test_two_components_two_table_entries(oracle):
     g = make_gpu(d, [t_cloud, t_gas], surfaceAlbedo=0.2)
     o = make_oracle(oracle, d, [t_cloud.inverse_table(9001), t_gas.inverse_table(9001)])
     o.specify(surfaceAlbedo=0.2)
-    nb, n = 8, 20000
-    gr, orr = _batches_gpu(g, nb, n, 0.6, az=70.0), _batches_oracle(oracle, o, nb, n, 0.6, az=70.0)
-    for key in ("fluxUp", "fluxDown", "fluxAbsorbed", "volumeAbsorption"):
-        _assert_3sigma(gr, orr, key, floor=1e-6)
+    _parity(oracle, g, o, 8, 20000, 0.6, az=70.0, keys=("fluxUp", "fluxDown", "fluxAbsorbed", "volumeAbsorption"), floor=1e-6)
 
 
 def test_irregular_grid_flux(oracle):
@@ -109,10 +97,7 @@ def test_irregular_grid_flux(oracle):
     g = make_gpu(d, hg_table(), surfaceAlbedo=0.5)
     o = make_oracle(oracle, d, [hg_table().inverse_table(9001)])
     o.specify(surfaceAlbedo=0.5)
-    nb, n = 8, 20000
-    gr, orr = _batches_gpu(g, nb, n, 0.4, az=130.0), _batches_oracle(oracle, o, nb, n, 0.4, az=130.0)
-    for key in ("fluxUp", "fluxDown", "fluxAbsorbed", "volumeAbsorption"):
-        _assert_3sigma(gr, orr, key, floor=1e-6)
+    _parity(oracle, g, o, 8, 20000, 0.4, az=130.0, keys=("fluxUp", "fluxDown", "fluxAbsorbed", "volumeAbsorption"), floor=1e-6)
 
 
 def test_radar_cloud_c1_tabulated_flux_and_nadir_radiance(oracle):
@@ -125,9 +110,8 @@ def test_radar_cloud_c1_tabulated_flux_and_nadir_radiance(oracle):
     op = dict(useRRForIntensity=1, zetaMin=0.3)
     g, o = _intensity_pair(oracle, d, tab, n_table=10001, gpu_params=gp, oracle_params=op, mus=[1.0], phis=[0.0])
     nb, n = 6, 6000
-    gr, orr = _batches_gpu(g, nb, n, 1.0), _batches_oracle(oracle, o, nb, n, 1.0)
-    for key in ("fluxUp", "fluxDown", "intensity"):
-        _assert_3sigma(gr, orr, key, floor=1e-6)
+    gr, orr = _parity(oracle, g, o, nb, n, 1.0, keys=("fluxUp", "fluxDown", "intensity"), floor=1e-6)
+    nb = len(gr)
     # dropped-photon deficit (quirk Q4) is part of the result: same rate on both sides (7e-4 in SURVEY.md)
     dg = sum(r["counters"]["dropped"] for r in gr) / (nb * n)
     do = sum(r["nBad"] for r in orr) / (nb * n)
@@ -164,7 +148,4 @@ def test_max_cross_section_mode_matches_oracle(oracle):
     g = make_gpu(d, hg_table(), useRayTracing=False, surfaceAlbedo=0.1)
     o = make_oracle(oracle, d, [hg_table().inverse_table(9001)])
     o.specify(useRayTracing=0, surfaceAlbedo=0.1)
-    nb, n = 8, 20000
-    gr, orr = _batches_gpu(g, nb, n, 0.9), _batches_oracle(oracle, o, nb, n, 0.9)
-    _assert_3sigma(gr, orr, "fluxUp")
-    _assert_3sigma(gr, orr, "fluxDown")
+    _parity(oracle, g, o, 8, 20000, 0.9)

@@ -222,6 +222,27 @@ def _assert_3sigma(gpu, ref, key, floor=1e-9, frac_ok=None):
     assert abs(dg.mean() - dr.mean()) <= t, (key, dg.mean(), dr.mean(), t)
 
 
+def _parity(oracle, g, o, nb, n, mu0, az=0.0, keys=("fluxUp", "fluxDown"), floor=1e-9):
+    """Two-stage 3-sigma test.  Stage 1: nb batches of n photons on both sides (seeds (10, b)).  A suite of ~60
+    such assertions would raise a false alarm every few runs (P(|t| > 3) ~ 1 % at these batch counts), so a
+    failure is re-examined once with an independent, twice as large sample (seeds (11, b)); a real bias fails both
+    stages, a fluctuation passes the second with probability > 99 %.  Returns the batches that were accepted."""
+    try:
+        gr, orr = _batches_gpu(g, nb, n, mu0, az), _batches_oracle(oracle, o, nb, n, mu0, az)
+        for key in keys:
+            _assert_3sigma(gr, orr, key, floor=floor)
+        return gr, orr
+    except AssertionError as first:
+        gr = _batches_gpu(g, 2 * nb, n, mu0, az, iseed=11)
+        orr = _batches_oracle(oracle, o, 2 * nb, n, mu0, az, iseed=11)
+        try:
+            for key in keys:
+                _assert_3sigma(gr, orr, key, floor=floor)
+        except AssertionError as second:
+            raise AssertionError(f"failed twice: {first.args} then {second.args}")
+        return gr, orr
+
+
 @pytest.mark.parametrize("mu0,ssa,albedo", [(1.0, 1.0, 0.0), (0.5, 0.99, 0.2)])
 def test_step_cloud_flux_parity(oracle, mu0, ssa, albedo):
     d = cases.step_cloud(ssa=ssa)
@@ -230,13 +251,9 @@ def test_step_cloud_flux_parity(oracle, mu0, ssa, albedo):
     o = make_oracle(oracle, d, [tab.inverse_table(10001)])
     o.specify(surfaceAlbedo=albedo)
     nb, n = 10, 40000
-    gr = _batches_gpu(g, nb, n, mu0)
-    orr = _batches_oracle(oracle, o, nb, n, mu0)
-    for key in ("fluxUp", "fluxDown"):
-        _assert_3sigma(gr, orr, key)
-    if ssa < 1:
-        _assert_3sigma(gr, orr, "fluxAbsorbed")
-        _assert_3sigma(gr, orr, "volumeAbsorption")
+    keys = ("fluxUp", "fluxDown") + (("fluxAbsorbed", "volumeAbsorption") if ssa < 1 else ())
+    gr, orr = _parity(oracle, g, o, nb, n, mu0, keys=keys)
+    nb = len(gr)
     # per-photon work counters (what the roofline's algorithmic bytes are computed from)
     cs = sum(r["counters"]["cellSteps"] for r in gr) / (nb * n)
     ks = sum(r["counters"]["scatterings"] for r in gr) / (nb * n)
