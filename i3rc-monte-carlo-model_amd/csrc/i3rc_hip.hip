@@ -70,6 +70,7 @@ struct i3rc_hip_integrator {
   int numCU = 256;
   int evThreshold = 40;
   int blocksPerCU = 0;  // 0 = from occupancy query
+  bool forceGeneral = false;  // test knob: run the general kernel even when the specialisation applies
   std::string err;
 
   int fail(const std::string &m) { err = m; return 1; }
@@ -136,7 +137,10 @@ int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int n
     g_createError = "i3rc_hip_create: bad dimensions (need nx,ny,nz >= 1 and 1 <= ncomp <= 8)";
     return 1;
   }
-  if ((int64_t)nx * ny * nz > (int64_t)1 << 30) { g_createError = "i3rc_hip_create: domain too large"; return 1; }
+  if ((int64_t)nx * ny * nz > (int64_t)1 << 30 || (int64_t)nx * ny >= (int64_t)1 << 24 || nz >= 1 << 24) {
+    g_createError = "i3rc_hip_create: domain too large (need nx*ny < 2^24, nx*ny*nz <= 2^30)";
+    return 1;
+  }
   if (!xEdges || !yEdges || !zEdges || !totalExt || !cumExt || !ssa || !pfIndex) {
     g_createError = "i3rc_hip_create: null array";
     return 1;
@@ -337,6 +341,13 @@ int i3rc_hip_set_tuning(i3rc_hip_integrator *h, int evThreshold, int blocksPerCU
   return 0;
 }
 
+/* Test knob: 1 = always run the general kernel, even when the specialised one applies. */
+int i3rc_hip_force_general_kernel(i3rc_hip_integrator *h, int on) {
+  if (!h) return 1;
+  h->forceGeneral = on != 0;
+  return 0;
+}
+
 }  // extern "C"
 
 namespace {
@@ -421,7 +432,11 @@ int upload_source(i3rc_hip_integrator *h, const i3rc_source *src, int64_t n, Run
 
 template <class Rng>
 int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, bool timeIt) {
-  auto kern = plan.intensity ? photon_kernel<Rng, true> : photon_kernel<Rng, false>;
+  // fast specialisation when the problem is in the common class (see photon_kernel), else the general kernel
+  const bool simple = !Rng::kReplay && plan.P.xyRegular && plan.P.zRegular && plan.P.useRayTracing && !plan.P.useBDRF &&
+                      plan.P.ncomp == 1 && A.srcKind == 0 && !h->forceGeneral;
+  auto kern = plan.intensity ? (simple ? photon_kernel<Rng, true, false> : photon_kernel<Rng, true, true>)
+                             : (simple ? photon_kernel<Rng, false, false> : photon_kernel<Rng, false, true>);
   int perCU = h->blocksPerCU;
   if (perCU <= 0) {
     int occ = 0;

@@ -43,7 +43,7 @@ struct Tally {
   __device__ __forceinline__ void down(int col, float w) const {
     if (P.ldsTallies) atomicAdd(&L.tDown[col], w); else add_global(P.tally + P.oDown + col, w);
   }
-  __device__ __forceinline__ void absorbed(int col, size_t cell, float w) const {
+  __device__ __forceinline__ void absorbed(int col, int cell, float w) const {
     if (P.ldsTallies) atomicAdd(&L.tAbs[col], w); else add_global(P.tally + P.oAbs + col, w);
     add_global(P.tally + P.oVol + cell, w);
   }
@@ -140,8 +140,15 @@ struct Reservoir {
   }
 };
 
-template <class Rng, bool INTENSITY>
-__global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold) {
+#ifndef I3RC_MIN_WAVES
+#define I3RC_MIN_WAVES 5
+#endif
+// GENERAL = false is the specialisation for the common problem class -- regular grid, ray tracing, one component,
+// Lambertian albedo (no BRDF grid), Directional source, production RNG: the rare paths (grid searches, periodic
+// re-wrapping loops, max-cross-section moves, BRDF lookups, component selection) are compiled out, which shrinks the
+// loop's code and its scalar-register pressure.  GENERAL = true keeps every path behind run-time switches.
+template <class Rng, bool INTENSITY, bool GENERAL>
+__global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   {
@@ -170,6 +177,10 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
 
   const Tally tally{P, L};
   const size_t ncell = (size_t)P.nx * P.ny * P.nz;
+  const bool rayTracing = GENERAL ? (P.useRayTracing != 0) : true;
+  const bool useBDRF = GENERAL ? (P.useBDRF != 0) : false;
+  const bool multiComp = GENERAL ? (P.ncomp > 1) : false;
+  const bool directional = GENERAL ? (A.srcKind == 0) : true;
   const float surfaceZ = P.z0 + spacingf(P.z0);
   const unsigned long long laneBit = 1ull << (threadIdx.x & 63);
 
@@ -187,25 +198,42 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
   Reservoir res;
   res.refill(A);
 
+#ifdef I3RC_PROFILE_PHASES   // diagnostic build only (tools/phase_profile.sh): where do a wave's cycles go?
+  unsigned long long profEv = 0, profSt = 0, profNEv = 0, profNSt = 0, profLanesEv = 0, profLanesSt = 0, profNew = 0;
+  unsigned long long profSeg[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long profMark = 0;
+#define PROF_SEG(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); profSeg[k] += t_ - profMark; profMark = t_; } while (0)
+#else
+#define PROF_SEG(k) do {} while (0)
+#endif
+#ifdef I3RC_PROFILE_PHASES
+#define PROF_T() __builtin_amdgcn_s_memtime()
+#else
+#define PROF_T() 0ull
+#endif
   for (;;) {
     // ---------------------------------------------------------------- EVENT phase
     const bool wantEvent = (st != ST_TRACE) && (st != ST_DONE);
     const unsigned long long evMask = __ballot(wantEvent);
     const unsigned long long trMask = __ballot(st == ST_TRACE);
     if (evMask == 0ull && trMask == 0ull) break;
+    const unsigned long long profT0 = PROF_T();
     if (__popcll(evMask) >= evThreshold || trMask == 0ull) {
+#ifdef I3RC_PROFILE_PHASES
+      profNEv++; profLanesEv += __popcll(evMask);
+      profMark = __builtin_amdgcn_s_memtime();
+#endif
       // ---- part A: endings that need no random number -- tracer drop, exit through the top, arrival at a black
       //      surface -- are tallied first so that the lanes can be given their next photon before the wave
       //      generates its random block (part C), which then serves old and new photons in one go.
-      const bool blackSurface = !Rng::kReplay && !P.useBDRF && !(P.albedo > kTiny) && !INTENSITY;
+      const bool blackSurface = !Rng::kReplay && !useBDRF && !(P.albedo > kTiny) && !INTENSITY;
       if (wantEvent) {
         if (st == ST_DROPPED) { cnt.dropped++; fate = 3; st = ST_NEW; }   // :488-489
         if (st == ST_EVENT) {
           if (r.z >= P.zMax) {                                            // :499-514
-            if (!P.useRayTracing) {
+            if (!rayTracing) {
               r.x = make_periodic(r.x - r.dx * fabsf((r.z - P.zMax) / r.dz), P.x0, P.xMax);
               r.y = make_periodic(r.y - r.dy * fabsf((r.z - P.zMax) / r.dz), P.y0, P.yMax);
-              find_xy(P, L, r.x, r.y, r.ix, r.iy);
+              find_xy<GENERAL>(P, L, r.x, r.y, r.ix, r.iy);
             }
             const int c2 = (r.iy - 1) * P.nx + (r.ix - 1);
             tally.up(c2, w);
@@ -214,10 +242,10 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
             st = ST_NEW;
           } else if (blackSurface && r.z <= surfaceZ) {                   // :515-531, :560-562 with albedo 0
             order++;
-            if (!P.useRayTracing) {
+            if (!rayTracing) {
               r.x = make_periodic(r.x - r.dx * fabsf((r.z - P.z0) / r.dz), P.x0, P.xMax);
               r.y = make_periodic(r.y - r.dy * fabsf((r.z - P.z0) / r.dz), P.y0, P.yMax);
-              find_xy(P, L, r.x, r.y, r.ix, r.iy);
+              find_xy<GENERAL>(P, L, r.x, r.y, r.ix, r.iy);
             }
             const int c2 = (r.iy - 1) * P.nx + (r.ix - 1);
             tally.down(c2, w);
@@ -235,6 +263,7 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
           pid = -1;
         }
       }
+      PROF_SEG(0);
       // ---- part B (converged): hand out photon indices from the wave's reservoir
       const unsigned long long newMask = __ballot(wantEvent && st == ST_NEW);
       if (newMask != 0ull) {
@@ -256,12 +285,14 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
         if (isNew && pid < 0) st = ST_DONE;
         if (isNew && pid >= 0) RngInit<Rng>::start(rng, A, pid);
       }
+      PROF_SEG(1);
       // ---- part C: one random block per lane for this event, then the event itself
       if (wantEvent && st != ST_DONE) {
         rng.begin_event();
+        PROF_SEG(2);
         if (st == ST_NEW) {                                               // :453-470
           float px, py, pz;
-          if (A.srcKind == 0) {   // newPhotonStream_Directional, Code/monteCarloIllumination.f95:91-99
+          if (directional) {   // newPhotonStream_Directional, Code/monteCarloIllumination.f95:91-99
             px = rng.next(); py = rng.next();
             pz = 1.0f - spacingf(1.0f);
             r.dx = A.solarDx; r.dy = A.solarDy; r.dz = A.solarDz;
@@ -276,16 +307,18 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
           r.y = P.y0 + py * (P.yMax - P.y0);
           r.z = P.z0 + pz * (P.zMax - P.z0);
           r.ix = 1; r.iy = 1; r.iz = 1;
-          find_xy(P, L, r.x, r.y, r.ix, r.iy);
-          find_z(P, L, r.z, r.iz);
+          find_xy<GENERAL>(P, L, r.x, r.y, r.ix, r.iy);
+          find_z<GENERAL>(P, L, r.z, r.iz);
           st = ST_TRACE;
-        } else if (st == ST_EVENT) {
+        }
+        PROF_SEG(3);
+        if (st == ST_EVENT) {
           if (r.z <= surfaceZ) {                                          // :515-580
             order++;
-            if (!P.useRayTracing) {
+            if (!rayTracing) {
               r.x = make_periodic(r.x - r.dx * fabsf((r.z - P.z0) / r.dz), P.x0, P.xMax);
               r.y = make_periodic(r.y - r.dy * fabsf((r.z - P.z0) / r.dz), P.y0, P.yMax);
-              find_xy(P, L, r.x, r.y, r.ix, r.iy);
+              find_xy<GENERAL>(P, L, r.x, r.y, r.ix, r.iy);
             }
             r.iz = 1;
             r.z = surfaceZ;
@@ -296,7 +329,7 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
             float mu;
             do { mu = exact_sqrt(rng.next()); } while (!(fabsf(mu) > 2.0f * kTiny));
             const float phi = (2.0f * kPi) * rng.next();
-            if (P.useBDRF) w = w * surface_reflectance(P, r.x, r.y);
+            if (useBDRF) w = w * surface_reflectance(P, r.x, r.y);
             else w = w * P.albedo;
             if (w <= kTiny) { fate = 1; st = ST_NEW; }
             else {
@@ -307,8 +340,8 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
             }
           } else {                                                        // :581-689
             bool scatterThis = true;
-            size_t cell = cell_index(P, r.ix, r.iy, r.iz);
-            if (!P.useRayTracing) scatterThis = rng.next() < P.totalExt[cell] / P.maxExt;
+            int cell = cell_index(P, r.ix, r.iy, r.iz);
+            if (!rayTracing) scatterThis = rng.next() < P.totalExt[cell] / P.maxExt;
             if (scatterThis) {
               order++;
               cnt.scat++;
@@ -328,9 +361,9 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
                 cell = cell_index(P, r.ix, r.iy, r.iz);
               }
               int comp = 1;                                               // :637-638
-              if (P.ncomp > 1 || Rng::kReplay) {
+              if (multiComp || Rng::kReplay) {
                 const float rc = rng.next();
-                if (P.ncomp > 1) {
+                if (multiComp) {
                   const float *cum = P.cumExt + cell;
                   comp = find_index(rc, [cum, ncell](int k) { return k == 1 ? 0.0f : cum[(size_t)(k - 2) * ncell]; },
                                     P.ncomp + 1, 0);
@@ -361,10 +394,11 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
             }
           }
         }
+        PROF_SEG(4);
         if (st == ST_TRACE) {                                             // :480
-          const float tau = -logf(fmaxf(kTiny, rng.next()));
+          const float tau = -sample_log(fmaxf(kTiny, rng.next()));
           r.acc = 0.0f; r.target = tau;
-          if (P.useRayTracing) { cnt.calls++; r.set_direction(); }
+          if (rayTracing) { cnt.calls++; r.set_direction(); }
           else {                                                          // :494-496 max cross-section move
             r.x = make_periodic(r.x + r.dx * tau / P.maxExt, P.x0, P.xMax);
             r.y = make_periodic(r.y + r.dy * tau / P.maxExt, P.y0, P.yMax);
@@ -372,6 +406,7 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
             st = ST_EVENT;
           }
         }
+        PROF_SEG(5);
         // a photon that died in part C (roulette, absorbing surface) is closed here and respawns at the next event phase
         if (st == ST_NEW && pid >= 0) {
           if (A.fate) {
@@ -383,6 +418,11 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
         }
       }
     }
+    const unsigned long long profT1 = PROF_T();
+#ifdef I3RC_PROFILE_PHASES
+    profEv += profT1 - profT0;
+    profNSt++; profLanesSt += __popcll(__ballot(st == ST_TRACE));
+#endif
     // ---------------------------------------------------------------- VOXEL-STEP phase
     if (st == ST_TRACE) {
       cnt.steps++;
@@ -390,7 +430,22 @@ __global__ void __launch_bounds__(256) photon_kernel(const DevProblem P, const R
       if (s == STEP_DONE) st = ST_EVENT;
       else if (s == STEP_ERROR) st = ST_DROPPED;
     }
+#ifdef I3RC_PROFILE_PHASES
+    profSt += PROF_T() - profT1;
+#endif
   }
+#ifdef I3RC_PROFILE_PHASES
+  if ((threadIdx.x & 63) == 0) {
+    unsafeAtomicAdd(P.tally + P.oCnt + 10, (double)profEv);
+    unsafeAtomicAdd(P.tally + P.oCnt + 11, (double)profSt);
+    unsafeAtomicAdd(P.tally + P.oCnt + 12, (double)profNEv);
+    unsafeAtomicAdd(P.tally + P.oCnt + 13, (double)profNSt);
+    unsafeAtomicAdd(P.tally + P.oCnt + 14, (double)profLanesEv);
+    unsafeAtomicAdd(P.tally + P.oCnt + 15, (double)profLanesSt);
+    // segment shares are packed into the volume-absorption tally of cells 0..5 (diagnostic build only, omega = 1 runs)
+    for (int k = 0; k < 6; ++k) unsafeAtomicAdd(P.tally + P.oVol + k, (double)profSeg[k]);
+  }
+#endif
 
   // ------------------------------------------------------------------ epilogue: flush tallies + counters
   __syncthreads();

@@ -55,6 +55,11 @@ struct PhiloxStream {
     id_lo = (uint32_t)photon; id_hi = (uint32_t)(photon >> 32);
     block = 0; have = 0; draws = 0; b0 = b1 = b2 = b3 = 0;
   }
+#ifdef I3RC_INLINE_REFILL
+  __device__ inline void refill_cold() { refill(); }
+#else
+  __device__ __attribute__((noinline)) void refill_cold() { refill(); }
+#endif   // one shared copy for the rare mid-event refill
   __device__ inline void refill() {
     const Philox4 o = philox4x32_10(id_lo, id_hi, block, 0u, k0, k1);
     block++;
@@ -65,7 +70,7 @@ struct PhiloxStream {
   // whole wave computes them together, expensive when a few lanes do)
   __device__ inline void begin_event() { refill(); }
   __device__ inline float next() {
-    if (have == 0) refill();
+    if (__builtin_expect(have == 0, 0)) refill();   // inline: an out-of-line call costs scratch spills at every site (measured -13 %)
     const uint32_t u = have == 4 ? b0 : (have == 3 ? b1 : (have == 2 ? b2 : b3));
     have--;
     draws++;

@@ -101,6 +101,14 @@ __device__ __forceinline__ float exact_sqrt(float x) {
   return x == 0.0f ? 0.0f : s;
 }
 
+// log() of a deviate in (0, 1] for the optical depth to travel (:480).
+#ifdef I3RC_FAST_LOG
+// hardware log2 (1 ulp) times ln 2: within 2 ulp of the correctly rounded value, a fifth of the instructions
+__device__ __forceinline__ float sample_log(float u) { return __builtin_amdgcn_logf(u) * 0.693147180559945309f; }
+#else
+__device__ __forceinline__ float sample_log(float u) { return logf(u); }
+#endif
+
 // findIndex, Code/numericUtilities.f95:195-248 (1-based table; firstGuess <= 0: absent)
 template <class Tab>
 __device__ __forceinline__ int find_index(float value, Tab T, int n, int firstGuess) {
@@ -157,16 +165,20 @@ struct Ray {
 
 enum StepResult { STEP_CONTINUE = 0, STEP_DONE = 1, STEP_ERROR = 2 };
 
-__device__ __forceinline__ size_t cell_index(const DevProblem &P, int ix, int iy, int iz) {
-  return ((size_t)(iz - 1) * P.ny + (size_t)(iy - 1)) * P.nx + (size_t)(ix - 1);
+__device__ __forceinline__ int cell_index(const DevProblem &P, int ix, int iy, int iz) {
+  // 24-bit multiplies (full rate): i3rc_hip_create guarantees nx*ny < 2^24 and nx*ny*nz < 2^30
+  return (int)(__umul24((unsigned)(iz - 1), (unsigned)(P.nx * P.ny)) + __umul24((unsigned)(iy - 1), (unsigned)P.nx)) + (ix - 1);
 }
 
-// One iteration of accumulationLoop, accumulateExtinctionAlongPath :1690-1806.
-// hasTarget == false: trace to the boundary.
+// One iteration of accumulationLoop, accumulateExtinctionAlongPath :1690-1806.  hasTarget == false: trace to the
+// boundary.  Written as straight-line predicated code (selects, no data-dependent branches except the two rare
+// escapes): on a 64-lane wavefront the lanes take the reference's if/else arms in every combination at every step,
+// so branches would execute both arms anyway and add exec-mask bookkeeping on top.  The arithmetic of each arm is
+// exactly the reference's (checked bit for bit against the oracle by the tracer tests).
 __device__ __forceinline__ StepResult trace_step(const DevProblem &P, const Lds &L, Ray &r, bool hasTarget) {
-  const int sx = r.dx >= 0.0f ? 1 : 0, sy = r.dy >= 0.0f ? 1 : 0, sz = r.dz >= 0.0f ? 1 : 0;
-  const int cx = r.dx >= 0.0f ? 1 : -1, cy = r.dy >= 0.0f ? 1 : -1, cz = r.dz >= 0.0f ? 1 : -1;
-  const float ex = L.xE[r.ix + sx - 1], ey = L.yE[r.iy + sy - 1], ez = L.zE[r.iz + sz - 1];
+  const bool px = r.dx >= 0.0f, py = r.dy >= 0.0f, pz = r.dz >= 0.0f;
+  const int cx = px ? 1 : -1, cy = py ? 1 : -1, cz = pz ? 1 : -1;
+  const float ex = L.xE[r.ix - (px ? 0 : 1)], ey = L.yE[r.iy - (py ? 0 : 1)], ez = L.zE[r.iz - (pz ? 0 : 1)];
   float stx, sty, stz;
   if (__builtin_expect(r.slow, 0)) {   // a direction cosine of (almost) zero: the reference's guarded division
     stx = fabsf(r.dx) >= 2.0f * kTiny ? (ex - r.x) / r.dx : kHuge;
@@ -178,46 +190,51 @@ __device__ __forceinline__ StepResult trace_step(const DevProblem &P, const Lds 
     stz = exact_div(ez - r.z, r.dz, r.rz);
   }
   float step = stx;
-  if (sty < step) step = sty;
-  if (stz < step) step = stz;
-  if (step <= 0.0f) { r.acc = -2.0f; return STEP_ERROR; }
+  step = sty < step ? sty : step;
+  step = stz < step ? stz : step;
+  if (__builtin_expect(step <= 0.0f, 0)) { r.acc = -2.0f; return STEP_ERROR; }   // :1711-1714
 
-  const size_t cell = cell_index(P, r.ix, r.iy, r.iz);
+  const int cell = cell_index(P, r.ix, r.iy, r.iz);
   const float ext = P.ldsGrid ? L.ext[cell] : P.totalExt[cell];
-  if (hasTarget) {
-    if (r.acc + step * ext > r.target) {
-      step = ext >= 1e-20f ? exact_div(r.target - r.acc, ext, refined_rcp(ext)) : (r.target - r.acc) / ext;
-      r.x = r.x + step * r.dx;
-      r.y = r.y + step * r.dy;
-      r.z = r.z + step * r.dz;
-      r.acc = r.target;
-      return STEP_DONE;
-    }
+  const float tauCell = step * ext;
+  bool reach = false;
+  float adv = step;
+  if (hasTarget) {                                                     // :1721-1731
+    reach = r.acc + tauCell > r.target;
+    float part = exact_div(r.target - r.acc, ext, refined_rcp(ext));
+    if (__builtin_expect(reach && ext < 1e-20f, 0)) part = (r.target - r.acc) / ext;
+    adv = reach ? part : step;
   }
-  r.acc = r.acc + step * ext;
+  r.acc = reach ? r.target : r.acc + tauCell;
 
-  if (stx <= step) { r.x = ex; r.ix += cx; }
-  else { r.x = r.x + step * r.dx; if (fabsf(ex - r.x) <= 2.0f * spacingf(r.x)) r.ix += cx; }
-  if (sty <= step) { r.y = ey; r.iy += cy; }
-  else { r.y = r.y + step * r.dy; if (fabsf(ey - r.y) <= 2.0f * spacingf(r.y)) r.iy += cy; }
-  if (stz <= step) { r.z = ez; r.iz += cz; }
-  else { r.z = r.z + step * r.dz; if (fabsf(ez - r.z) <= 2.0f * spacingf(r.z)) r.iz += cz; }
+  const float ax = r.x + adv * r.dx, ay = r.y + adv * r.dy, az = r.z + adv * r.dz;
+  const bool hx = !reach && stx <= step, hy = !reach && sty <= step, hz = !reach && stz <= step;   // face reached
+  // :1744-1769 the face position itself when the face is reached, else the advanced position; the index moves on
+  // when the face is reached or the position ends within 2 spacing() of it
+  const bool bx = hx || (!reach && fabsf(ex - ax) <= 2.0f * spacingf(ax));
+  const bool by = hy || (!reach && fabsf(ey - ay) <= 2.0f * spacingf(ay));
+  const bool bz = hz || (!reach && fabsf(ez - az) <= 2.0f * spacingf(az));
+  r.x = hx ? ex : ax; r.y = hy ? ey : ay; r.z = hz ? ez : az;
+  r.ix += bx ? cx : 0; r.iy += by ? cy : 0; r.iz += bz ? cz : 0;
 
   // periodic wrap :1774-1788 (y uses x's sign, as the reference does)
   const float nudge = (float)(cx * 2);
-  if (r.ix <= 0) { r.ix = P.nx; r.x = P.xMax + nudge * spacingf(r.x); }
-  else if (r.ix >= P.nx + 1) { r.ix = 1; r.x = P.x0 + nudge * spacingf(r.x); }
-  if (r.iy <= 0) { r.iy = P.ny; r.y = P.yMax + nudge * spacingf(r.y); }
-  else if (r.iy >= P.ny + 1) { r.iy = 1; r.y = P.y0 + nudge * spacingf(r.y); }
+  const bool xLo = r.ix <= 0, xHi = r.ix >= P.nx + 1, yLo = r.iy <= 0, yHi = r.iy >= P.ny + 1;
+  const float sxp = nudge * spacingf(r.x), syp = nudge * spacingf(r.y);
+  r.x = xLo ? P.xMax + sxp : (xHi ? P.x0 + sxp : r.x);
+  r.y = yLo ? P.yMax + syp : (yHi ? P.y0 + syp : r.y);
+  r.ix = xLo ? P.nx : (xHi ? 1 : r.ix);
+  r.iy = yLo ? P.ny : (yHi ? 1 : r.iy);
 
-  if (r.iz > P.nz) { r.z = P.zMax + 2.0f * spacingf(P.zMax); return STEP_DONE; }
-  if (r.iz < 1) { r.z = P.z0; return STEP_DONE; }
-  return STEP_CONTINUE;
+  const bool top = r.iz > P.nz, bottom = r.iz < 1;                     // :1793-1804
+  r.z = top ? P.zMax + 2.0f * spacingf(P.zMax) : (bottom ? P.z0 : r.z);
+  return (reach || top || bottom) ? STEP_DONE : STEP_CONTINUE;
 }
 
 // findXYIndicies :1353-1374, findZIndex :1376-1388
+template <bool GENERAL = true>
 __device__ __forceinline__ void find_xy(const DevProblem &P, const Lds &L, float x, float y, int &ix, int &iy) {
-  if (P.xyRegular) {
+  if (!GENERAL || P.xyRegular) {
     int i = min((int)((x - P.x0) / P.deltaX) + 1, P.nx);
     int j = min((int)((y - P.y0) / P.deltaY) + 1, P.ny);
     if (fabsf(L.xE[i] - x) < spacingf(x)) i = i + 1;
@@ -231,8 +248,9 @@ __device__ __forceinline__ void find_xy(const DevProblem &P, const Lds &L, float
     iy = find_index(y, [ye](int k) { return ye[k - 1]; }, P.ny + 1, iy);
   }
 }
+template <bool GENERAL = true>
 __device__ __forceinline__ void find_z(const DevProblem &P, const Lds &L, float z, int &iz) {
-  if (P.zRegular) {
+  if (!GENERAL || P.zRegular) {
     int k = min((int)((z - P.z0) / P.deltaZ) + 1, P.nz);
     if (fabsf(L.zE[k] - z) < spacingf(z)) k = k + 1;
     iz = k;

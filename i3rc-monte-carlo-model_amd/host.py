@@ -416,8 +416,10 @@ class Integrator:
         return out
 
     # -- test hooks
-    def set_tuning(self, evThreshold=32, blocksPerCU=0):
+    def set_tuning(self, evThreshold=40, blocksPerCU=0, forceGeneral=None):
         self._check(self._lib.i3rc_hip_set_tuning(self._h, int(evThreshold), int(blocksPerCU)), "set_tuning")
+        if forceGeneral is not None:
+            self._check(self._lib.i3rc_hip_force_general_kernel(self._h, int(bool(forceGeneral))), "set_tuning")
 
     def trace_rays(self, direction, pos, idx, target=None):
         d, p = f32(direction).reshape(-1, 3).copy(), f32(pos).reshape(-1, 3).copy()

@@ -179,6 +179,10 @@ int i3rc_hip_kernel_ms_history(i3rc_hip_integrator *h, int n, float *ms);
  * event phase (1..64, default 40) and workgroups per CU (0 = occupancy query). */
 int i3rc_hip_set_tuning(i3rc_hip_integrator *h, int evThreshold, int blocksPerCU);
 
+/* Test knob: the launch normally picks a kernel specialised for the common problem class (regular grid, ray tracing,
+ * one component, no BRDF grid, Directional source); 1 forces the general kernel so both can be compared. */
+int i3rc_hip_force_general_kernel(i3rc_hip_integrator *h, int on);
+
 /* Test hook: the raw Philox4x32-10 blocks (out[n][blocksPerPhoton][4]) of photons firstPhoton..+n-1 and the
  * float32 deviates the photon streams derive from them (outf, same shape). */
 int i3rc_hip_philox_blocks(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int64_t firstPhoton, int64_t n,

@@ -287,6 +287,24 @@ def test_results_do_not_depend_on_launch_geometry():
     assert np.allclose(c["raw"], a["raw"], rtol=1e-5, atol=1e-6)
 
 
+def test_specialised_and_general_kernels_trace_the_same_photons():
+    # the launch picks a kernel specialised for regular grid / ray tracing / one component / Directional source;
+    # the general kernel must give the same photons the same fate
+    for ssa, albedo, dirs in ((1.0, 0.0, None), (0.98, 0.3, ([1.0, 0.6], [0.0, 120.0]))):
+        d = cases.step_cloud(ssa=ssa, nlayers=16)
+        kw = dict(surfaceAlbedo=albedo)
+        if dirs:
+            kw.update(intensityMus=dirs[0], intensityPhis=dirs[1])
+        g = make_gpu(d, hg_table(), **kw)
+        n = 50000
+        g.set_tuning(40, 0, forceGeneral=False)
+        a = g.computeRadiativeTransfer(M.new_RandomNumberSequence((5, 6)), M.new_PhotonStream(0.6, 10.0, n))
+        g.set_tuning(40, 0, forceGeneral=True)
+        b = g.computeRadiativeTransfer(M.new_RandomNumberSequence((5, 6)), M.new_PhotonStream(0.6, 10.0, n))
+        assert a["counters"] == b["counters"]
+        assert np.allclose(a["raw"], b["raw"], rtol=1e-5, atol=1e-5)
+
+
 def test_edge_cases_and_errors():
     d = cases.plane_parallel(optical_depth=0.0)  # empty domain: everything reaches the black surface
     g = make_gpu(d, hg_table())
