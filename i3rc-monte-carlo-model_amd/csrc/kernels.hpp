@@ -181,6 +181,11 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
   const bool useBDRF = GENERAL ? (P.useBDRF != 0) : false;
   const bool multiComp = GENERAL ? (P.ncomp > 1) : false;
   const bool directional = GENERAL ? (A.srcKind == 0) : true;
+  // Directional photons all start at z = z0 + (1 - spacing(1)) (zMax - z0): their start layer is wave-uniform
+  const float zStart = P.z0 + (1.0f - spacingf(1.0f)) * (P.zMax - P.z0);
+  int izStart = 1;
+  find_z<GENERAL>(P, L, zStart, izStart);
+  const float rcpDeltaX = refined_rcp(P.deltaX), rcpDeltaY = refined_rcp(P.deltaY);
   const float surfaceZ = P.z0 + spacingf(P.z0);
   const unsigned long long laneBit = 1ull << (threadIdx.x & 63);
 
@@ -257,9 +262,9 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
         if (st == ST_NEW && pid >= 0) {
           if (A.fate) {
             A.fate[pid] = fate; A.fateColumn[pid] = fateCol; A.fateWeight[pid] = fateW; A.fateOrder[pid] = order;
-            A.drawsUsed[pid] = (int32_t)rng.draws;
+            A.drawsUsed[pid] = (int32_t)rng.draws();
           }
-          cnt.draws += rng.draws;
+          cnt.draws += rng.draws();
           pid = -1;
         }
       }
@@ -307,8 +312,18 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
           r.y = P.y0 + py * (P.yMax - P.y0);
           r.z = P.z0 + pz * (P.zMax - P.z0);
           r.ix = 1; r.iy = 1; r.iz = 1;
-          find_xy<GENERAL>(P, L, r.x, r.y, r.ix, r.iy);
-          find_z<GENERAL>(P, L, r.z, r.iz);
+          if (!GENERAL) {   // findXYIndicies :1359-1369 with the divisions by the (uniform) cell sizes done by reciprocal
+            int i = min((int)exact_div(r.x - P.x0, P.deltaX, rcpDeltaX) + 1, P.nx);
+            int j = min((int)exact_div(r.y - P.y0, P.deltaY, rcpDeltaY) + 1, P.ny);
+            if (fabsf(L.xE[i] - r.x) < spacingf(r.x)) i = i + 1;
+            if (fabsf(L.yE[j] - r.y) < spacingf(r.y)) j = j + 1;
+            r.ix = i == P.nx + 1 ? 1 : i;
+            r.iy = j == P.ny + 1 ? 1 : j;
+            r.iz = izStart;
+          } else {
+            find_xy<GENERAL>(P, L, r.x, r.y, r.ix, r.iy);
+            find_z<GENERAL>(P, L, r.z, r.iz);
+          }
           st = ST_TRACE;
         }
         PROF_SEG(3);
@@ -411,9 +426,9 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
         if (st == ST_NEW && pid >= 0) {
           if (A.fate) {
             A.fate[pid] = fate; A.fateColumn[pid] = fateCol; A.fateWeight[pid] = fateW; A.fateOrder[pid] = order;
-            A.drawsUsed[pid] = (int32_t)rng.draws;
+            A.drawsUsed[pid] = (int32_t)rng.draws();
           }
-          cnt.draws += rng.draws;
+          cnt.draws += rng.draws();
           pid = -1;
         }
       }

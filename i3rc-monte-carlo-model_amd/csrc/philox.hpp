@@ -48,13 +48,15 @@ struct PhiloxStream {
   uint32_t k0, k1, id_lo, id_hi, block;
   uint32_t b0, b1, b2, b3;   // current block
   int have;                  // unused words of the block: next() hands out b[4 - have]
-  uint32_t draws;
+  uint32_t discarded;        // deviates generated but not used (dropped at begin_event)
 
   __device__ inline void start(uint32_t seed0, uint32_t seed1, uint64_t photon) {
     k0 = seed0; k1 = seed1;
     id_lo = (uint32_t)photon; id_hi = (uint32_t)(photon >> 32);
-    block = 0; have = 0; draws = 0; b0 = b1 = b2 = b3 = 0;
+    block = 0; have = 0; discarded = 0; b0 = b1 = b2 = b3 = 0;
   }
+  // deviates consumed so far: everything generated minus what is still buffered or was discarded
+  __device__ inline uint32_t draws() const { return 4u * block - (uint32_t)have - discarded; }
 #ifdef I3RC_INLINE_REFILL
   __device__ inline void refill_cold() { refill(); }
 #else
@@ -68,12 +70,11 @@ struct PhiloxStream {
   }
   // fresh block for this event; leftovers of the previous block are discarded (blocks are cheap per lane when the
   // whole wave computes them together, expensive when a few lanes do)
-  __device__ inline void begin_event() { refill(); }
+  __device__ inline void begin_event() { discarded += (uint32_t)have; refill(); }
   __device__ inline float next() {
     if (__builtin_expect(have == 0, 0)) refill();   // inline: an out-of-line call costs scratch spills at every site (measured -13 %)
     const uint32_t u = have == 4 ? b0 : (have == 3 ? b1 : (have == 2 ? b2 : b3));
     have--;
-    draws++;
     return u32_to_unit_float(u);
   }
   // Azimuth for next_direct (:2099-2103).  The reference rejection-samples a point of the unit disc (2 deviates per
@@ -93,12 +94,13 @@ struct ReplayStream {
   static constexpr bool kReplay = true;   // consume deviates exactly where the reference does
   const float *buf;
   int64_t pos, end;
-  uint32_t draws;
-  __device__ inline void start(const float *b, int64_t p, int64_t e) { buf = b; pos = p; end = e; draws = 0; }
+  int64_t first;
+  __device__ inline void start(const float *b, int64_t p, int64_t e) { buf = b; pos = p; end = e; first = p; }
+  __device__ inline uint32_t draws() const { return (uint32_t)(pos - first); }
   __device__ inline void begin_event() {}
   __device__ inline float next() {
     float r = pos < end ? buf[pos] : 0.5f;
-    pos++; draws++;
+    pos++;
     return r;
   }
   // the reference's own rejection sampling, deviate for deviate (next_direct :2098-2103)
