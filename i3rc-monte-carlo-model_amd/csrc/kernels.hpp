@@ -43,6 +43,11 @@ struct Tally {
   __device__ __forceinline__ void down(int col, float w) const {
     if (P.ldsTallies) atomicAdd(&L.tDown[col], w); else add_global(P.tally + P.oDown + col, w);
   }
+  // upward flux at the top (:513) or downward flux at the surface (:531): one atomic for either
+  __device__ __forceinline__ void boundary(bool top, int col, float w) const {
+    if (P.ldsTallies) atomicAdd((top ? L.tUp : L.tDown) + col, w);
+    else add_global(P.tally + (top ? P.oUp : P.oDown) + col, w);
+  }
   __device__ __forceinline__ void absorbed(int col, int cell, float w) const {
     if (P.ldsTallies) atomicAdd(&L.tAbs[col], w); else add_global(P.tally + P.oAbs + col, w);
     add_global(P.tally + P.oVol + cell, w);
@@ -232,32 +237,28 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
       //      generates its random block (part C), which then serves old and new photons in one go.
       const bool blackSurface = !Rng::kReplay && !useBDRF && !(P.albedo > kTiny) && !INTENSITY;
       if (wantEvent) {
-        if (st == ST_DROPPED) { cnt.dropped++; fate = 3; st = ST_NEW; }   // :488-489
-        if (st == ST_EVENT) {
-          if (r.z >= P.zMax) {                                            // :499-514
-            if (!rayTracing) {
-              r.x = make_periodic(r.x - r.dx * fabsf((r.z - P.zMax) / r.dz), P.x0, P.xMax);
-              r.y = make_periodic(r.y - r.dy * fabsf((r.z - P.zMax) / r.dz), P.y0, P.yMax);
+        // one merged branch for the three endings: a single tally atomic and a single bookkeeping block
+        const bool dropped = st == ST_DROPPED;                                            // :488-489
+        const bool atTop = st == ST_EVENT && r.z >= P.zMax;                               // :499-514
+        const bool atBlack = st == ST_EVENT && !atTop && blackSurface && r.z <= surfaceZ; // :515-531, :560-562
+        if (dropped || atTop || atBlack) {
+          if (!dropped) {
+            if (!rayTracing) {   // max cross-section: step back to the boundary (:504-511, :521-528)
+              const float zB = atTop ? P.zMax : P.z0;
+              r.x = make_periodic(r.x - r.dx * fabsf((r.z - zB) / r.dz), P.x0, P.xMax);
+              r.y = make_periodic(r.y - r.dy * fabsf((r.z - zB) / r.dz), P.y0, P.yMax);
               find_xy<GENERAL>(P, L, r.x, r.y, r.ix, r.iy);
             }
             const int c2 = (r.iy - 1) * P.nx + (r.ix - 1);
-            tally.up(c2, w);
-            cnt.top++;
-            fate = 0; fateCol = c2; fateW = w;
-            st = ST_NEW;
-          } else if (blackSurface && r.z <= surfaceZ) {                   // :515-531, :560-562 with albedo 0
-            order++;
-            if (!rayTracing) {
-              r.x = make_periodic(r.x - r.dx * fabsf((r.z - P.z0) / r.dz), P.x0, P.xMax);
-              r.y = make_periodic(r.y - r.dy * fabsf((r.z - P.z0) / r.dz), P.y0, P.yMax);
-              find_xy<GENERAL>(P, L, r.x, r.y, r.ix, r.iy);
-            }
-            const int c2 = (r.iy - 1) * P.nx + (r.ix - 1);
-            tally.down(c2, w);
-            cnt.surf++;
-            fate = 1; fateCol = c2; fateW = w;
-            st = ST_NEW;
+            tally.boundary(atTop, c2, w);
+            fateCol = c2; fateW = w;
           }
+          cnt.dropped += dropped ? 1u : 0u;
+          cnt.top += atTop ? 1u : 0u;
+          cnt.surf += atBlack ? 1u : 0u;
+          order += atBlack ? 1 : 0;
+          fate = dropped ? 3 : (atTop ? 0 : 1);
+          st = ST_NEW;
         }
         if (st == ST_NEW && pid >= 0) {
           if (A.fate) {
