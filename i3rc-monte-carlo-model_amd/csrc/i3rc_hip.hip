@@ -69,6 +69,7 @@ struct i3rc_hip_integrator {
   long long timedLaunches = 0;
   int numCU = 256;
   int evThreshold = 40;
+  int lightThreshold = 24;
   int blocksPerCU = 0;  // 0 = from occupancy query
   bool forceGeneral = false;  // test knob: run the general kernel even when the specialisation applies
   std::string err;
@@ -395,9 +396,15 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan) {
   P.oInt = h->layout.intensityByComponent; P.oExc = h->layout.intensityExcess; P.oCnt = h->layout.counters;
   const size_t ncol = (size_t)h->nx * h->ny, ncell = ncol * h->nz;
   size_t lds = sizeof(float) * ((h->nx + 1) + (h->ny + 1) + (h->nz + 1) + 3 * (size_t)h->nDir);
+  if (h->nDir > 0) lds += sizeof(float) * kParkWords * 256;   // parked photon state of the radiance path
   if (lds > kLdsBudget) return h->fail("domain edge vectors do not fit in LDS");
   P.ldsTallies = 0;
   if (lds + 3 * ncol * sizeof(float) <= kLdsBudget / 2) { P.ldsTallies = 1; lds += 3 * ncol * sizeof(float); }
+  P.ldsIntensity = 0;
+  {
+    const size_t nInt = (size_t)(h->ncomp + 1) * h->nDir * ncol * sizeof(float);
+    if (h->nDir > 0 && nInt <= 16 * 1024 && lds + nInt <= kLdsBudget) { P.ldsIntensity = 1; lds += nInt; }
+  }
   P.ldsGrid = 0;
   if (lds + ncell * sizeof(float) <= kLdsBudget) { P.ldsGrid = 1; lds += ncell * sizeof(float); }
   plan.ldsBytes = (lds + 15) & ~(size_t)15;
@@ -453,7 +460,7 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
   HIPCHK(h, hipMemsetAsync(A.workCounter, 0, sizeof(unsigned long long), h->stream));
   const int slot = (int)(h->timedLaunches % i3rc_hip_integrator::kEventRing);
   if (timeIt) HIPCHK(h, hipEventRecord(h->evStart[slot], h->stream));
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), plan.ldsBytes, h->stream, plan.P, B, h->evThreshold);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), plan.ldsBytes, h->stream, plan.P, B, h->evThreshold, h->lightThreshold);
   HIPCHK(h, hipGetLastError());
   if (timeIt) { HIPCHK(h, hipEventRecord(h->evStop[slot], h->stream)); h->timedLaunches++; }
   return 0;

@@ -19,7 +19,9 @@
 
 namespace i3rc {
 
-enum LaneState { ST_TRACE = 0, ST_EVENT = 1, ST_DROPPED = 2, ST_NEW = 3, ST_DONE = 4 };
+enum LaneState { ST_TRACE = 0, ST_EVENT = 1, ST_DROPPED = 2, ST_NEW = 3, ST_DONE = 4,
+                 ST_SHADOW = 5,   // tracing a local-estimate (shadow) ray towards a radiance direction
+                 ST_LIGHT = 6 };  // a shadow ray ended, or the first one is due: needs the light phase
 
 struct LaneCounters {
   uint32_t photons = 0, dropped = 0, steps = 0, scat = 0, surf = 0, top = 0, roul = 0, shadow = 0, calls = 0;
@@ -42,6 +44,11 @@ struct Tally {
   }
   __device__ __forceinline__ void down(int col, float w) const {
     if (P.ldsTallies) atomicAdd(&L.tDown[col], w); else add_global(P.tally + P.oDown + col, w);
+  }
+  // intensityByComponent(ix, iy, d, comp) (:574-579, :662-667)
+  __device__ __forceinline__ void radiance(int comp, int d, int col, float v) const {
+    const size_t i = ((size_t)comp * P.nDir + d) * ((size_t)P.nx * P.ny) + col;
+    if (P.ldsIntensity) atomicAdd(&L.tInt[i], v); else add_global(P.tally + P.oInt + i, v);
   }
   // upward flux at the top (:513) or downward flux at the surface (:531): one atomic for either
   __device__ __forceinline__ void boundary(bool top, int col, float w) const {
@@ -112,8 +119,8 @@ __device__ __forceinline__ void intensity_contribution(const DevProblem &P, cons
       add_global(P.tally + P.oExc + (size_t)component * P.nDir + d, con - P.maxContrib);
       con = P.maxContrib;
     }
-    const size_t col = (size_t)(r.iy - 1) * P.nx + (size_t)(r.ix - 1);
-    add_global(P.tally + P.oInt + ((size_t)component * P.nDir + d) * ncol + col, con);
+    const Tally tl{P, L};
+    tl.radiance(component, d, (r.iy - 1) * P.nx + (r.ix - 1), con);
   }
 }
 
@@ -153,7 +160,7 @@ struct Reservoir {
 // re-wrapping loops, max-cross-section moves, BRDF lookups, component selection) are compiled out, which shrinks the
 // loop's code and its scalar-register pressure.  GENERAL = true keeps every path behind run-time switches.
 template <class Rng, bool INTENSITY, bool GENERAL>
-__global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold) {
+__global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   {
@@ -165,6 +172,10 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
     L.tUp = p; L.tDown = p + ncol; L.tAbs = p + 2 * ncol;
     if (P.ldsTallies) p += 3 * ncol;
     L.dirCos = p; p += 3 * P.nDir;
+    L.park = p;
+    if (INTENSITY && !Rng::kReplay) p += kParkWords * 256;
+    L.tInt = p;
+    if (P.ldsIntensity) p += (P.ncomp + 1) * P.nDir * ncol;
     L.ext = p;
   }
   for (int i = threadIdx.x; i < 3 * P.nDir; i += blockDim.x) L.dirCos[i] = P.dirCos[i];
@@ -178,6 +189,8 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
     const int ncell = P.nx * P.ny * P.nz;
     for (int i = threadIdx.x; i < ncell; i += blockDim.x) L.ext[i] = P.totalExt[i];
   }
+  if (P.ldsIntensity)
+    for (int i = threadIdx.x; i < (P.ncomp + 1) * P.nDir * P.nx * P.ny; i += blockDim.x) L.tInt[i] = 0.0f;
   __syncthreads();
 
   const Tally tally{P, L};
@@ -207,6 +220,15 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
   float fateW = 0.0f;
   Reservoir res;
   res.refill(A);
+  // Radiance (local estimate) as part of the lane state machine instead of a loop nested in the event: after an
+  // event the photon's own state is parked in LDS and the lane traces one shadow ray per radiance direction in the
+  // common voxel-step phase; ray ends are handled in a light phase of their own (DEFER).  The replay build keeps
+  // the reference's nested order (same deviates at the same places).
+  constexpr bool DEFER = INTENSITY && !Rng::kReplay;
+  float wI = 0.0f, normPF = 0.0f, tauFree = 0.0f;   // weight of the event, phase-function factor and free path of the current ray
+  int dIdx = 0, stage = -1;                          // direction being traced; -1 none, 0 plain, 1 small-contribution RR, 2/3 two-leg RR
+  bool pendingShadow = false;
+  const bool defer = DEFER && rayTracing;            // max cross-section moves the photon inside the event: keep the nested order there
 
 #ifdef I3RC_PROFILE_PHASES   // diagnostic build only (tools/phase_profile.sh): where do a wave's cycles go?
   unsigned long long profEv = 0, profSt = 0, profNEv = 0, profNSt = 0, profLanesEv = 0, profLanesSt = 0, profNew = 0;
@@ -222,12 +244,84 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
 #endif
   for (;;) {
     // ---------------------------------------------------------------- EVENT phase
-    const bool wantEvent = (st != ST_TRACE) && (st != ST_DONE);
+    const bool wantEvent = st == ST_EVENT || st == ST_DROPPED || st == ST_NEW;
     const unsigned long long evMask = __ballot(wantEvent);
-    const unsigned long long trMask = __ballot(st == ST_TRACE);
-    if (evMask == 0ull && trMask == 0ull) break;
+    const unsigned long long trMask = __ballot(st == ST_TRACE || st == ST_SHADOW);
+    unsigned long long liMask = 0ull;
+    if (DEFER) {
+      liMask = __ballot(st == ST_LIGHT);
+      // ------------------------------------------------------------ LIGHT phase (shadow-ray ends and starts)
+      if (liMask != 0ull && (__popcll(liMask) >= lightThreshold || trMask == 0ull)) {
+        if (st == ST_LIGHT) {
+          float *park = L.park + threadIdx.x;
+          if (stage >= 0) {                                              // the ray that just ended (:1517-1596)
+            const float tauB = r.acc;
+            const bool outTop = r.iz >= P.nz + 1;
+            float con = 0.0f;
+            if (stage == 0) con = tauB >= 0.0f ? (wI * normPF) * expf(-tauB) : 0.0f;
+            else if (stage == 1) {
+              const float r2 = rng.next();
+              con = (r2 <= kPi * normPF / P.zetaMin && outTop) ? wI * P.zetaMin / kPi : 0.0f;
+            } else if (stage == 2) {
+              if (outTop && tauB >= 0.0f) con = (wI * normPF) * expf(-tauB);
+              else if (tauB >= 0.0f) {                                   // second leg, up to the free path (:1576-1587)
+                r.acc = 0.0f; r.target = tauFree; stage = 3; st = ST_SHADOW; cnt.calls++;
+              }
+            } else con = outTop ? wI * P.zetaMin / kPi : 0.0f;
+            if (st == ST_LIGHT) {
+              const int comp = __float_as_int(park[13 * 256]) & 0xff;
+              if (P.limitContrib && con > P.maxContrib) {                // :1598-1609
+                add_global(P.tally + P.oExc + (size_t)comp * P.nDir + dIdx, con - P.maxContrib);
+                con = P.maxContrib;
+              }
+              tally.radiance(comp, dIdx, (r.iy - 1) * P.nx + (r.ix - 1), con);
+              dIdx++; stage = -1;
+            }
+          }
+          if (st == ST_LIGHT) {
+            r.x = park[0]; r.y = park[256]; r.z = park[2 * 256];
+            r.ix = __float_as_int(park[3 * 256]); r.iy = __float_as_int(park[4 * 256]); r.iz = __float_as_int(park[5 * 256]);
+            if (dIdx < P.nDir) {                                         // next radiance direction (:1473-1510)
+              const float ux = L.dirCos[3 * dIdx], uy = L.dirCos[3 * dIdx + 1], uz = L.dirCos[3 * dIdx + 2];
+              const int info = __float_as_int(park[13 * 256]);
+              const int comp = info & 0xff;
+              if (comp < 1) normPF = 1.0f / kPi;
+              else {
+                float proj = 0.0f;
+                proj += park[10 * 256] * ux; proj += park[11 * 256] * uy; proj += park[12 * 256] * uz;
+                if (fabsf(proj) > 1.0f) proj = copysignf(1.0f, proj);
+                const float ang = acosf(proj);
+                const int pfi = __float_as_int(park[14 * 256]);
+                const CompTables ct = P.comp[comp - 1];
+                const float *tab = ((info & 0x100) ? ct.fwdOrig : ct.fwd) + (size_t)(pfi - 1) * ct.nFwd;
+                normPF = lookup_phase(tab, ct.nFwd, ang) / ((4.0f * kPi) * fabsf(uz));
+              }
+              r.dx = ux; r.dy = uy; r.dz = uz;
+              r.set_direction();
+              r.acc = 0.0f; r.target = 0.0f;
+              if (!P.useRRI) stage = 0;
+              else {
+                tauFree = -logf(fmaxf(kTiny, rng.next()));
+                if (kPi * normPF <= P.zetaMin) { stage = 1; r.target = tauFree; }
+                else { stage = 2; r.target = -logf(P.zetaMin / fmaxf(kTiny, kPi * normPF)); }
+              }
+              cnt.calls++;
+              st = ST_SHADOW;
+            } else if (w <= kTiny) {
+              st = ST_NEW;                                               // killed by roulette at this event
+            } else {                                                     // back to the photon's own path
+              r.dx = park[6 * 256]; r.dy = park[7 * 256]; r.dz = park[8 * 256];
+              r.target = park[9 * 256]; r.acc = 0.0f;
+              r.set_direction();
+              st = ST_TRACE;
+            }
+          }
+        }
+      }
+    }
+    if (evMask == 0ull && trMask == 0ull && liMask == 0ull) break;
     const unsigned long long profT0 = PROF_T();
-    if (__popcll(evMask) >= evThreshold || trMask == 0ull) {
+    if (evMask != 0ull && (__popcll(evMask) >= evThreshold || (trMask == 0ull && liMask == 0ull))) {
 #ifdef I3RC_PROFILE_PHASES
       profNEv++; profLanesEv += __popcll(evMask);
       profMark = __builtin_amdgcn_s_memtime();
@@ -350,7 +444,10 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
             if (w <= kTiny) { fate = 1; st = ST_NEW; }
             else {
               make_dircos(mu, phi, r.dx, r.dy, r.dz);
-              if (INTENSITY)
+              if (defer) {
+                pendingShadow = true; wI = w;
+                L.park[13 * 256 + threadIdx.x] = __int_as_float(0);     // component 0: the surface
+              } else if (INTENSITY)
                 intensity_contribution(P, L, rng, cnt, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, 0, order);
               st = ST_TRACE;
             }
@@ -390,7 +487,14 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
                 tally.absorbed((r.iy - 1) * P.nx + (r.ix - 1), cell, w * (1.0f - ssa));
                 w = w * ssa;
               }
-              if (INTENSITY)
+              if (defer) {                                                // :654-668, traced after this event
+                pendingShadow = true; wI = w;
+                float *park = L.park + threadIdx.x;
+                park[10 * 256] = r.dx; park[11 * 256] = r.dy; park[12 * 256] = r.dz;   // incoming direction
+                const int useOrig = (P.useHybrid && order <= P.numOrdersOrig) ? 0x100 : 0;
+                park[13 * 256] = __int_as_float(comp | useOrig);
+                park[14 * 256] = __int_as_float(P.pfIndex[(size_t)(comp - 1) * ncell + cell]);
+              } else if (INTENSITY)
                 intensity_contribution(P, L, rng, cnt, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, comp, order);
               if (P.useRR && w < 0.5f) {                                  // :673-680
                 cnt.roul++;
@@ -423,6 +527,15 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
           }
         }
         PROF_SEG(5);
+        if (defer && pendingShadow) {   // park the photon (alive or killed by roulette) and trace its shadow rays first
+          float *park = L.park + threadIdx.x;
+          park[0] = r.x; park[256] = r.y; park[2 * 256] = r.z;
+          park[3 * 256] = __int_as_float(r.ix); park[4 * 256] = __int_as_float(r.iy); park[5 * 256] = __int_as_float(r.iz);
+          park[6 * 256] = r.dx; park[7 * 256] = r.dy; park[8 * 256] = r.dz;
+          park[9 * 256] = r.target;
+          pendingShadow = false; dIdx = 0; stage = -1;
+          st = ST_LIGHT;
+        }
         // a photon that died in part C (roulette, absorbing surface) is closed here and respawns at the next event phase
         if (st == ST_NEW && pid >= 0) {
           if (A.fate) {
@@ -440,11 +553,13 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
     profNSt++; profLanesSt += __popcll(__ballot(st == ST_TRACE));
 #endif
     // ---------------------------------------------------------------- VOXEL-STEP phase
-    if (st == ST_TRACE) {
-      cnt.steps++;
-      const StepResult s = trace_step(P, L, r, true);
-      if (s == STEP_DONE) st = ST_EVENT;
-      else if (s == STEP_ERROR) st = ST_DROPPED;
+    if (st == ST_TRACE || (DEFER && st == ST_SHADOW)) {
+      const bool own = st == ST_TRACE;
+      cnt.steps += own ? 1u : 0u;
+      cnt.shadow += own ? 0u : 1u;
+      const StepResult s = trace_step(P, L, r, own || stage != 0);
+      if (s == STEP_DONE) st = own ? ST_EVENT : ST_LIGHT;
+      else if (s == STEP_ERROR) st = own ? ST_DROPPED : ST_LIGHT;   // a failed shadow ray contributes nothing (:1531-1535)
     }
 #ifdef I3RC_PROFILE_PHASES
     profSt += PROF_T() - profT1;
@@ -472,6 +587,13 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
       if (u != 0.0f) add_global(P.tally + P.oUp + i, u);
       if (d != 0.0f) add_global(P.tally + P.oDown + i, d);
       if (a != 0.0f) add_global(P.tally + P.oAbs + i, a);
+    }
+  }
+  if (P.ldsIntensity) {
+    const int nInt = (P.ncomp + 1) * P.nDir * P.nx * P.ny;
+    for (int i = threadIdx.x; i < nInt; i += blockDim.x) {
+      const float v = L.tInt[i];
+      if (v != 0.0f) add_global(P.tally + P.oInt + i, v);
     }
   }
   const double c[10] = {(double)cnt.photons, (double)cnt.dropped, (double)cnt.steps, (double)cnt.scat, (double)cnt.surf,

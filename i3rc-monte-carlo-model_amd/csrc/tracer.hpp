@@ -45,6 +45,7 @@ struct DevProblem {
   long long oUp, oDown, oAbs, oVol, oInt, oExc, oCnt;
   int ldsTallies;                     // 1: fluxUp/Down/Absorbed privatised in LDS (ncol small)
   int ldsGrid;                        // 1: totalExt staged in LDS
+  int ldsIntensity;                   // 1: intensityByComponent privatised in LDS ((ncomp+1)*nDir*ncol small)
 };
 
 struct RunArgs {
@@ -66,7 +67,10 @@ struct Lds {
   float *tUp, *tDown, *tAbs;  // privatised flux tallies (valid when ldsTallies)
   float *ext;             // totalExt copy (valid when ldsGrid)
   float *dirCos;          // intensity directions
+  float *tInt;            // privatised intensityByComponent (valid when ldsIntensity)
+  float *park;            // [kParkWords][256]: a photon's own state while its shadow rays are traced
 };
+constexpr int kParkWords = 15;
 
 // Fortran SPACING() for real(4)
 __device__ __forceinline__ float spacingf(float x) {
