@@ -74,12 +74,20 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the integrator has no CPU fallback")
+    # Rehearsal mode for a one-GPU box (never used by the driver): I3RC_BENCH_REHEARSAL=1 lets all ranks share GPU 0
+    # and reduces the tallies through gloo on host copies, so the N>1 control flow can be exercised without RCCL.
+    rehearsal = os.environ.get("I3RC_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if n_gpus > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- problem: resident on the device before timing -------------------------------------------------
     d = cases.step_cloud(nlayers=a.nlayers)
@@ -102,9 +110,15 @@ def main():
         tally.zero_()
         integ.launch(M.new_RandomNumberSequence((iseed, batch)), M.new_PhotonStream(1.0, 0.0, a.photons),
                      firstPhoton=rank * a.photons, zero=False)
-        all_reduce_tallies(tally, dist)  # the single exchange step: sum of tallies over GPUs (RCCL)
+        if rehearsal and dist is not None:
+            host = tally.cpu()
+            all_reduce_tallies(host, dist)
+            tally.copy_(host)
+        else:
+            all_reduce_tallies(tally, dist)  # the single exchange step: sum of tallies over GPUs (RCCL)
 
     def sync():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -117,7 +131,7 @@ def main():
         step(1 + k)
     sync()
     elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, dist, device="cuda")
+    elapsed = max_over_ranks(elapsed, dist, device="cpu" if rehearsal else "cuda")
 
     # ---- kernel durations of the K timed launches (HIP events recorded on the launch stream, read now) ------
     kernel_ms = integ.kernel_ms_history(min(a.steps, 64))
