@@ -135,6 +135,18 @@ def test_reference_drivers_run_unchanged_on_gpu(tmp_path):
     fup, eup, fdn, edn = map(float, m.groups())
     # Fup 0.3254, Fdn 0.6746 at 1e6 photons
     assert abs(fup - 0.3254) < 4 * max(eup, 4e-4) and abs(fdn - 0.6746) < 4 * max(edn, 4e-4)
+    # the shell's own driver (same namelists, same ASCII formats) on the same run deck
+    own = os.path.join(BUILD, "i3rcDriver")
+    if os.path.exists(own):
+        nml2 = nml.replace("stepCloud_flux.txt", "own_flux.txt").replace("stepCloud_rad.txt", "own_rad.txt")
+        nml2 = nml2.replace("stepCloud_absprof.txt", "own_absprof.txt").replace("stepCloud_results.nc", "")
+        open(str(out / "own.nml"), "w").write(nml2)
+        r2 = _run([own, str(out / "own.nml")], cwd=ROOT)
+        assert r2.returncode == 0 and "Wrote ASCII results" in r2.stdout, r2.stdout + r2.stderr
+        own_flux = open(str(out / "own_flux.txt")).read()
+        # same seeds, same kernel, same statistics: the two flux files agree line by line
+        assert own_flux.splitlines()[9:] == flux.splitlines()[9:]
+        assert len(open(str(out / "own_rad.txt")).read().splitlines()) == len(open(str(out / "stepCloud_rad.txt")).read().splitlines())
     from scipy.io import netcdf_file
 
     f = netcdf_file(str(out / "stepCloud_results.nc"), "r", mmap=False)
