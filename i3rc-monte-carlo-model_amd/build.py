@@ -20,6 +20,20 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
+COMM_LIB = os.path.join(CSRC, "libi3rc_comm.so")
+COMM_HEADER = os.path.join(os.path.dirname(HERE), "include", "i3rc_comm.h")
+
+
+def build_comm(force=False):
+    """Process layer (RCCL all-reduce / shared-memory test backend): csrc/libi3rc_comm.so, host code only."""
+    src = os.path.join(CSRC, "i3rc_comm.cpp")
+    if not force and os.path.exists(COMM_LIB) and os.path.getmtime(COMM_LIB) > max(os.path.getmtime(src), os.path.getmtime(COMM_HEADER)):
+        return COMM_LIB
+    subprocess.check_call([hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-o", COMM_LIB, src,
+                           "-L/opt/rocm/lib", "-lrccl", "-lamdhip64", "-lrt", "-lpthread"], cwd=CSRC)
+    return COMM_LIB
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -30,6 +44,7 @@ def needs_build():
 
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 ... -> csrc/libi3rc_hip.so (cross-compiles without a GPU)."""
+    build_comm(force)
     if not force and not needs_build():
         return LIB
     cmd = [hipcc()] + HIPCC_FLAGS + ["-o", LIB, os.path.join(CSRC, "i3rc_hip.hip")]

@@ -23,6 +23,7 @@ module monteCarloRadiativeTransfer
   use surfaceProperties,        only: surfaceDescription, copy_surfaceDescription, finalize_surfaceDescription, &
                                       isReady_surfaceDescription, getSurfaceGrid
   use monteCarloIllumination,   only: photonStream, morePhotonsExist, describeStream, streamArrays, consumeStream
+  use MultipleProcesses,        only: localDevice
   use i3rcHipInterface
   implicit none
   private
@@ -88,6 +89,7 @@ contains
     end if
     ! a deviate of exactly 1 must still select the last component
     where(abs(new%cumulativeExt(:, :, :, nc) - 1.) <= spacing(1.)) new%cumulativeExt(:, :, :, nc) = 1. + spacing(1.)
+    new%deviceIndex = localDevice()     ! one process per GPU: the device of this rank
     call createDeviceInstance(new, status)
     if(stateIsFailure(status)) return
     allocate(new%fluxUp(nx, ny), new%fluxDown(nx, ny), new%fluxAbsorbed(nx, ny), new%volumeAbsorption(nx, ny, nz))

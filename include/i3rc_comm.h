@@ -1,0 +1,32 @@
+/*
+ * include/i3rc_comm.h -- process layer of the MI355X integrator: one process per GPU, sums over processes with RCCL.
+ *
+ * Stands where the reference has Code/multipleProcesses_mpi.f95 (MPI_INIT / COMM_RANK / COMM_SIZE :26-39, MPI_Barrier
+ * :41-49, MPI_FINALIZE :51-55, MPI_REDUCE(MPI_REAL, MPI_SUM) :57-131).  The Fortran module MultipleProcesses of the
+ * shell binds these entry points; see INTEGRATION.md.
+ *
+ * Ranks are taken from the environment of the usual launchers: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR /
+ * MASTER_PORT (torchrun style), else OMPI_COMM_WORLD_RANK / _SIZE / _LOCAL_RANK, else a single process.
+ * Backends: "rccl" (default: ncclAllReduce over xGMI; the unique id is handed from rank 0 to the others through a file
+ * in I3RC_COMM_DIR, default /dev/shm, named after MASTER_PORT) and "shm" (I3RC_COMM_BACKEND=shm: POSIX shared memory on
+ * one node, no GPU needed -- used by the CPU tests of the N > 1 path).
+ * All functions return 0 on success; i3rc_comm_last_error() describes the last failure.
+ */
+#ifndef I3RC_COMM_H
+#define I3RC_COMM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int i3rc_comm_init(int *numProcs, int *thisProc);   /* initializeProcesses(numProcs, thisProcNum) */
+int i3rc_comm_local_device(void);                    /* HIP device of this process (LOCAL_RANK), 0 for one process */
+int i3rc_comm_barrier(void);                         /* synchronizeProcesses */
+int i3rc_comm_sum_float(float *values, int64_t n);   /* sumAcrossProcesses: in place, result on every rank */
+int i3rc_comm_finalize(void);                        /* finalizeProcesses */
+const char *i3rc_comm_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -92,6 +92,29 @@ def test_reference_drivers_link_unchanged(shell_built):
     assert not any(os.path.basename(t) in ("monteCarloDriver.f95", "planeParallel.f95") for t in tracked)
 
 
+def _spawn_ranks(cmd, world, port, extra_env=None, cwd=None):
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), I3RC_COMM_BACKEND="shm")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen(cmd, env=env, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    return [p.returncode for p in procs], outs
+
+
+def test_multiple_processes_module_two_and_three_ranks(shell_built):
+    # N > 1 path of module MultipleProcesses (the stand-in for multipleProcesses_mpi.f95) on CPU: shared-memory backend
+    exe = os.path.join(shell_built, "commSelfTest")
+    for world, port in ((2, 29631), (3, 29632)):
+        rcs, outs = _spawn_ranks([exe], world, port)
+        assert rcs == [0] * world, outs
+        for r, o in enumerate(outs):
+            assert f"rank {r} of {world} sums ok master={'T' if r == 0 else 'F'}" in o, o
+    r = _run([exe])   # a single process needs no launcher
+    assert r.returncode == 0 and "rank 0 of 1 sums ok master=T" in r.stdout
+
+
 # ---- GPU --------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_shell_integrator_on_gpu():
@@ -147,6 +170,17 @@ def test_reference_drivers_run_unchanged_on_gpu(tmp_path):
         # same seeds, same kernel, same statistics: the two flux files agree line by line
         assert own_flux.splitlines()[9:] == flux.splitlines()[9:]
         assert len(open(str(out / "own_rad.txt")).read().splitlines()) == len(open(str(out / "stepCloud_rad.txt")).read().splitlines())
+        # ... and as two processes (batches split over ranks, moments summed across processes): same 10 batches
+        nml3 = nml2.replace("own_flux.txt", "own2_flux.txt").replace("own_rad.txt", "own2_rad.txt").replace("own_absprof.txt", "own2_absprof.txt")
+        open(str(out / "own2.nml"), "w").write(nml3)
+        rcs, outs = _spawn_ranks([own, str(out / "own2.nml")], 2, 29641, cwd=ROOT)
+        assert rcs == [0, 0], outs
+        assert "batches on each of" in outs[0]
+        two = open(str(out / "own2_flux.txt")).read().splitlines()
+        one = own_flux.splitlines()
+        m1 = [float(v) for v in one[12].split()[1:]]
+        m2 = [float(v) for v in two[12].split()[1:]]
+        assert np.allclose(m1, m2, atol=2e-4), (one[12], two[12])
     from scipy.io import netcdf_file
 
     f = netcdf_file(str(out / "stepCloud_results.nc"), "r", mmap=False)

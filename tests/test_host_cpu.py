@@ -27,6 +27,12 @@ def test_cabi_library_exports_every_declared_symbol():
     assert b"gfx950" in L.i3rc_hip_version.__class__(("i3rc_hip_version", L)).restype.__name__.encode() or True
     L.i3rc_hip_version.restype = ctypes.c_char_p
     assert b"gfx950" in L.i3rc_hip_version()
+    # process layer (include/i3rc_comm.h)
+    comm = ctypes.CDLL(M.build.build_comm())
+    cdecl = sorted(set(re.findall(r"\b(i3rc_comm_[a-z_]+)\s*\(", open(os.path.join(ROOT, "include", "i3rc_comm.h")).read())))
+    assert len(cdecl) == 6
+    for name in cdecl:
+        assert hasattr(comm, name), name
 
 
 def test_philox_known_answers():
