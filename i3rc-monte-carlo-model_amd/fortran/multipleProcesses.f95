@@ -63,7 +63,10 @@ contains
   end function localDevice
 
   subroutine synchronizeProcesses
-    if(i3rc_comm_barrier() /= 0) stop "synchronizeProcesses failed"
+    if(i3rc_comm_barrier() /= 0) then
+      print *, "synchronizeProcesses failed"
+      stop 1
+    end if
   end subroutine synchronizeProcesses
 
   subroutine finalizeProcesses
@@ -74,7 +77,10 @@ contains
   subroutine sumInPlace(flat)
     real, dimension(:), intent(inout) :: flat
     if(size(flat) == 0) return
-    if(i3rc_comm_sum_float(flat, int(size(flat), c_int64_t)) /= 0) stop "sumAcrossProcesses failed"
+    if(i3rc_comm_sum_float(flat, int(size(flat), c_int64_t)) /= 0) then
+      print *, "sumAcrossProcesses failed"
+      stop 1
+    end if
   end subroutine sumInPlace
 
   function sumScalar(x) result(total)

@@ -112,7 +112,8 @@ program i3rcDriver
   call finalize_PhotonStream(photons)
   call cpu_time(t1)
   call synchronizeProcesses
-  if(MasterProc) print *, "Setup CPU time (secs, approx): ", int(sumAcrossProcesses(t1 - t0))
+  t1 = sumAcrossProcesses(t1 - t0)          ! a collective: every rank takes part
+  if(MasterProc) print *, "Setup CPU time (secs, approx): ", int(t1)
 
   ! -- batches: the unit of work and of the error estimate
   numBatches = max(numBatches, 2)
