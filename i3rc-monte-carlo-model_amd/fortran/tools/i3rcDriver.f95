@@ -46,7 +46,8 @@ program i3rcDriver
   character(len = 256) :: namelistFile
   integer :: nx, ny, nz, nDir, numProcs, thisProc, perProc, batch, firstBatch
   logical :: wantRadiance
-  real    :: t0, t1, t2
+  real    :: t0, t1, t2, cpuSetup
+  integer :: nc, v, rc                       ! netCDF result file: file id, variable id, return code
   real, allocatable :: xEdges(:), yEdges(:), zEdges(:)
   real, allocatable :: up(:, :), down(:, :), absorbed(:, :), profile(:), volume(:, :, :), radiance(:, :, :)
   ! first and second moments over batches, one slab per quantity
@@ -113,6 +114,7 @@ program i3rcDriver
   call cpu_time(t1)
   call synchronizeProcesses
   t1 = sumAcrossProcesses(t1 - t0)          ! a collective: every rank takes part
+  cpuSetup = t1
   if(MasterProc) print *, "Setup CPU time (secs, approx): ", int(t1)
 
   ! -- batches: the unit of work and of the error estimate
@@ -169,8 +171,14 @@ program i3rcDriver
   if(MasterProc) then
     if(len_trim(outputFluxFile) > 0)    call writeFluxFile
     if(len_trim(outputAbsProfFile) > 0) call writeProfileFile
+    if(len_trim(outputAbsVolumeFile) > 0) call writeVolumeFile
     if(len_trim(outputRadFile) > 0)     call writeRadianceFile
-    if(len_trim(outputFluxFile) + len_trim(outputAbsProfFile) + len_trim(outputRadFile) > 0) print *, "Wrote ASCII results"
+    if(len_trim(outputFluxFile) + len_trim(outputAbsProfFile) + len_trim(outputAbsVolumeFile) + len_trim(outputRadFile) > 0) &
+      print *, "Wrote ASCII results"
+    if(len_trim(outputNetcdfFile) > 0) then
+      call writeNetcdfFile
+      print *, "Wrote netCDF results"
+    end if
   end if
   call finalize_Integrator(mc)
 contains
@@ -203,7 +211,7 @@ contains
                                         '   Gaussian_Phase_Func_Width_deg=', hybridPhaseFunWidth
     if(outputType == "Pixel Radiance") then
       write(unit, '(A,L1,A,F5.2)')      '!  Intensity_uses_Russian_Roulette=', useRussianRouletteForIntensity, &
-                                        '   Russian_Roulette_zeta_min=', zetaMin
+                                        '   Intensity_Russian_Roulette_zeta_min=', zetaMin
       write(unit, '(A,L1,A,F5.2)')      '!  limited_intensity_contributions=', limitIntensityContributions, &
                                         '   max_intensity_contribution=', maxIntensityContribution
     end if
@@ -241,11 +249,28 @@ contains
     close(12)
   end subroutine writeProfileFile
 
+  subroutine writeVolumeFile
+    integer :: i, j, k
+    open(unit = 12, file = trim(outputAbsVolumeFile), status = "unknown")
+    call writeHeader(12, "3D Absorption Field", "Volume Absorption ")
+    write(12, '(A)') '!    X       Y        Z       Absorbed_Flux (flux/km)'
+    write(12, '(A)') '!                               Mean     StdErr '
+    do i = 1, nx              ! x outermost, as downstream readers of the reference's file expect
+      do j = 1, ny
+        do k = 1, nz
+          write(12, '(3(F7.3,1X),2(1X,F9.4))') sum(xEdges(i:i + 1)) / 2., sum(yEdges(j:j + 1)) / 2., &
+                                               sum(zEdges(k:k + 1)) / 2., mVolume(i, j, k, :)
+        end do
+      end do
+    end do
+    close(12)
+  end subroutine writeVolumeFile
+
   subroutine writeRadianceFile
     integer :: i, j, d
     open(unit = 12, file = trim(outputRadFile), status = "unknown")
     call writeHeader(12, "Radiance", "Pixel Radiance")
-    write(12, '(A,F7.3,3(A,I4))') '!  RADIANCE AT Z=', zEdges(nz + 1), '    NXO=', nx, '    NYO=', ny, '    NDIR=', nDir
+    write(12, '(A,F7.3,3(A,I4))') '!  RADIANCE AT Z=', zEdges(nz + 1), '   NXO=', nx, '   NYO=', ny, '   NDIR=', nDir
     write(12, '(A)') '!   X      Y         Radiance (Mean, StdErr)'
     do d = 1, nDir
       write(12, '(A,1X,F8.5,1X,F6.2,2X,A)') '! ', intensityMus(d), intensityPhis(d), '<- (mu,phi)'
@@ -257,4 +282,118 @@ contains
     end do
     close(12)
   end subroutine writeRadianceFile
+
+  ! Result file in netCDF classic format: same global attributes, dimensions (x, y, [z], [direction]) and variable
+  ! names as the reference driver's writeResults_netcdf (:609-854), so that scripts reading its files read these.
+  subroutine writeNetcdfFile
+    use netcdf
+    integer :: xDim, yDim, zDim, dirDim
+    logical :: wantZ
+
+    wantZ = reportAbsorptionProfile .or. reportVolumeAbsorption
+    rc = nf90_create(trim(outputNetcdfFile), nf90_clobber, nc)
+    if(rc /= nf90_NoErr) then
+      print *, "Cannot create " // trim(outputNetcdfFile)
+      return
+    end if
+    rc = nf90_put_att(nc, NF90_Global, "description", "Output from I3RC Community Monte Carlo Model")
+    rc = nf90_put_att(nc, NF90_Global, "Domain_filename", trim(domainFileName))
+    rc = nf90_put_att(nc, NF90_Global, "Surface_albedo", surfaceAlbedo)
+    rc = nf90_put_att(nc, NF90_Global, "Total_number_of_photons", numPhotonsPerBatch * numBatches)
+    rc = nf90_put_att(nc, NF90_Global, "Number_of_batches", numBatches)
+    rc = nf90_put_att(nc, NF90_Global, "Solar_flux", solarFlux)
+    rc = nf90_put_att(nc, NF90_Global, "Solar_mu", solarMu)
+    rc = nf90_put_att(nc, NF90_Global, "Solar_phi", solarAzimuth)
+    rc = nf90_put_att(nc, NF90_Global, "Random_number_seed", iseed)
+    rc = nf90_put_att(nc, NF90_Global, "Phase_function_table_sizes", nPhaseIntervals)
+    rc = nf90_put_att(nc, NF90_Global, "Algorithm", merge("Ray_tracing      ", "Max_cross_section", useRayTracing))
+    call flagAndValue("Intensity_uses_hyrbid_phase_functions", useHybridPhaseFunsForIntenCalcs, &
+                      "Hybrid_phase_function_width", hybridPhaseFunWidth)
+    call flagAndValue("Intensity_uses_Russian_roulette", useRussianRouletteForIntensity, &
+                      "Intensity_Russian_roulette_zeta_min", zetaMin)
+    call flagAndValue("limited_intensity_contributions", limitIntensityContributions, &
+                      "max_intensity_contribution", maxIntensityContribution)
+    rc = nf90_put_att(nc, NF90_Global, "Cpu_time_total", t2)
+    rc = nf90_put_att(nc, NF90_Global, "Cpu_time_setup", cpuSetup)
+    rc = nf90_put_att(nc, NF90_Global, "Number_of_processors_used", numProcs)
+
+    rc = nf90_def_dim(nc, "x", nx, xDim)
+    rc = nf90_def_dim(nc, "y", ny, yDim)
+    if(wantZ) rc = nf90_def_dim(nc, "z", nz, zDim)
+    rc = nf90_def_var(nc, "x", nf90_float, xDim, v)
+    rc = nf90_def_var(nc, "y", nf90_float, yDim, v)
+    if(wantZ) rc = nf90_def_var(nc, "z", nf90_float, zDim, v)
+    call definePair("fluxUp", (/ xDim, yDim /))
+    call definePair("fluxDown", (/ xDim, yDim /))
+    call definePair("fluxAbsorbed", (/ xDim, yDim /))
+    if(reportAbsorptionProfile) call definePair("absorptionProfile", (/ zDim /))
+    if(reportVolumeAbsorption)  call definePair("absorbedVolume", (/ xDim, yDim, zDim /))
+    if(wantRadiance) then
+      rc = nf90_def_dim(nc, "direction", nDir, dirDim)
+      rc = nf90_def_var(nc, "intensityMus",  nf90_float, dirDim, v)
+      rc = nf90_def_var(nc, "intensityPhis", nf90_float, dirDim, v)
+      call definePair("intensity", (/ xDim, yDim, dirDim /))
+    end if
+    rc = nf90_enddef(nc)
+    if(rc /= nf90_NoErr) print *, "netCDF output: definitions failed ", rc
+
+    call put1("x", (xEdges(:nx) + xEdges(2:)) / 2)
+    call put1("y", (yEdges(:ny) + yEdges(2:)) / 2)
+    if(wantZ) call put1("z", (zEdges(:nz) + zEdges(2:)) / 2)
+    call put2("fluxUp", mUp(:, :, 1));        call put2("fluxUp_StdErr", mUp(:, :, 2))
+    call put2("fluxDown", mDown(:, :, 1));    call put2("fluxDown_StdErr", mDown(:, :, 2))
+    call put2("fluxAbsorbed", mAbs(:, :, 1)); call put2("fluxAbsorbed_StdErr", mAbs(:, :, 2))
+    if(reportAbsorptionProfile) then
+      call put1("absorptionProfile", mProfile(:, 1)); call put1("absorptionProfile_StdErr", mProfile(:, 2))
+    end if
+    if(reportVolumeAbsorption) then
+      call put3("absorbedVolume", mVolume(:, :, :, 1)); call put3("absorbedVolume_StdErr", mVolume(:, :, :, 2))
+    end if
+    if(wantRadiance) then
+      call put1("intensityMus", intensityMus(:nDir)); call put1("intensityPhis", intensityPhis(:nDir))
+      call put3("intensity", mRad(:, :, :, 1));       call put3("intensity_StdErr", mRad(:, :, :, 2))
+    end if
+    rc = nf90_close(nc)
+    if(rc /= nf90_NoErr) print *, "netCDF output: close failed ", rc
+  end subroutine writeNetcdfFile
+
+    subroutine flagAndValue(flagName, flag, valueName, value)
+      use netcdf
+      character(len = *), intent(in) :: flagName, valueName
+      logical,            intent(in) :: flag
+      real,               intent(in) :: value
+      rc = nf90_put_att(nc, NF90_Global, flagName, merge(1, 0, flag))
+      rc = nf90_put_att(nc, NF90_Global, valueName, merge(value, 0., flag))
+    end subroutine flagAndValue
+    subroutine definePair(name, dims)
+      use netcdf
+      character(len = *), intent(in) :: name
+      integer,            intent(in) :: dims(:)
+      rc = nf90_def_var(nc, name, nf90_float, dims, v)
+      rc = nf90_def_var(nc, name // "_StdErr", nf90_float, dims, v)
+    end subroutine definePair
+    subroutine put1(name, values)
+      use netcdf
+      character(len = *), intent(in) :: name
+      real,               intent(in) :: values(:)
+      rc = nf90_inq_varid(nc, name, v)
+      if(rc == nf90_NoErr) rc = nf90_put_var(nc, v, values)
+      if(rc /= nf90_NoErr) print *, "netCDF output: " // name, rc
+    end subroutine put1
+    subroutine put2(name, values)
+      use netcdf
+      character(len = *), intent(in) :: name
+      real,               intent(in) :: values(:, :)
+      rc = nf90_inq_varid(nc, name, v)
+      if(rc == nf90_NoErr) rc = nf90_put_var(nc, v, values)
+      if(rc /= nf90_NoErr) print *, "netCDF output: " // name, rc
+    end subroutine put2
+    subroutine put3(name, values)
+      use netcdf
+      character(len = *), intent(in) :: name
+      real,               intent(in) :: values(:, :, :)
+      rc = nf90_inq_varid(nc, name, v)
+      if(rc == nf90_NoErr) rc = nf90_put_var(nc, v, values)
+      if(rc /= nf90_NoErr) print *, "netCDF output: " // name, rc
+    end subroutine put3
 end program i3rcDriver

@@ -149,6 +149,8 @@ def test_reference_drivers_run_unchanged_on_gpu(tmp_path):
     dom = str(out / "stepCloud.dom")
     assert _run([mk, dom, "32", "1.0"]).returncode == 0
     nml = open(os.path.join(FDIR, "examples", "stepCloud.nml")).read().replace("gpurun_out/fortran/", str(out) + "/")
+    nml = nml.replace('outputAbsVolumeFile = ""', f'outputAbsVolumeFile = "{out}/stepCloud_absvol.txt"')
+    nml = nml.replace("reportVolumeAbsorption = .false.", "reportVolumeAbsorption = .true.")
     nml_path = str(out / "stepCloud.nml")
     open(nml_path, "w").write(nml)
     r = _run([mc, nml_path], cwd=ROOT)
@@ -162,14 +164,30 @@ def test_reference_drivers_run_unchanged_on_gpu(tmp_path):
     own = os.path.join(BUILD, "i3rcDriver")
     if os.path.exists(own):
         nml2 = nml.replace("stepCloud_flux.txt", "own_flux.txt").replace("stepCloud_rad.txt", "own_rad.txt")
-        nml2 = nml2.replace("stepCloud_absprof.txt", "own_absprof.txt").replace("stepCloud_results.nc", "")
+        nml2 = nml2.replace("stepCloud_absprof.txt", "own_absprof.txt").replace("stepCloud_results.nc", "own_results.nc")
+        nml2 = nml2.replace("stepCloud_absvol.txt", "own_absvol.txt")
         open(str(out / "own.nml"), "w").write(nml2)
         r2 = _run([own, str(out / "own.nml")], cwd=ROOT)
-        assert r2.returncode == 0 and "Wrote ASCII results" in r2.stdout, r2.stdout + r2.stderr
+        assert r2.returncode == 0 and "Wrote ASCII results" in r2.stdout and "Wrote netCDF results" in r2.stdout, r2.stdout + r2.stderr
         own_flux = open(str(out / "own_flux.txt")).read()
         # same seeds, same kernel, same statistics: the two flux files agree line by line
         assert own_flux.splitlines()[9:] == flux.splitlines()[9:]
-        assert len(open(str(out / "own_rad.txt")).read().splitlines()) == len(open(str(out / "stepCloud_rad.txt")).read().splitlines())
+        for name in ("rad", "absprof", "absvol"):   # whole files, headers included (Property_File differs by name only)
+            a = open(str(out / f"own_{name}.txt")).read().splitlines()
+            b = open(str(out / f"stepCloud_{name}.txt")).read().splitlines()
+            assert len(a) == len(b) and [x for x, y in zip(a, b) if x != y and "Property_File" not in x] == [], name
+        from scipy.io import netcdf_file as _nc
+
+        fo = _nc(str(out / "own_results.nc"), "r", mmap=False)
+        fr = _nc(str(out / "stepCloud_results.nc"), "r", mmap=False)
+        assert set(fo.variables) == set(fr.variables) and set(fo.dimensions) == set(fr.dimensions)
+        for k in fr.variables:
+            assert fo.variables[k].dimensions == fr.variables[k].dimensions
+            assert np.array_equal(fo.variables[k].data, fr.variables[k].data), k
+        assert set(fo._attributes) == set(fr._attributes)
+        for k in fr._attributes:
+            if not k.startswith("Cpu_time") and k != "Domain_filename":
+                assert np.all(fo._attributes[k] == fr._attributes[k]), k
         # ... and as two processes (batches split over ranks, moments summed across processes): same 10 batches
         nml3 = nml2.replace("own_flux.txt", "own2_flux.txt").replace("own_rad.txt", "own2_rad.txt").replace("own_absprof.txt", "own2_absprof.txt")
         open(str(out / "own2.nml"), "w").write(nml3)
