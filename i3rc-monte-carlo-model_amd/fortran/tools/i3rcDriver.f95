@@ -306,7 +306,7 @@ contains
     rc = nf90_put_att(nc, NF90_Global, "Solar_phi", solarAzimuth)
     rc = nf90_put_att(nc, NF90_Global, "Random_number_seed", iseed)
     rc = nf90_put_att(nc, NF90_Global, "Phase_function_table_sizes", nPhaseIntervals)
-    rc = nf90_put_att(nc, NF90_Global, "Algorithm", merge("Ray_tracing      ", "Max_cross_section", useRayTracing))
+    rc = nf90_put_att(nc, NF90_Global, "Algorithm", trim(merge("Ray_tracing      ", "Max_cross_section", useRayTracing)))
     call flagAndValue("Intensity_uses_hyrbid_phase_functions", useHybridPhaseFunsForIntenCalcs, &
                       "Hybrid_phase_function_width", hybridPhaseFunWidth)
     call flagAndValue("Intensity_uses_Russian_roulette", useRussianRouletteForIntensity, &

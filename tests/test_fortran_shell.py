@@ -183,7 +183,8 @@ def test_reference_drivers_run_unchanged_on_gpu(tmp_path):
         assert set(fo.variables) == set(fr.variables) and set(fo.dimensions) == set(fr.dimensions)
         for k in fr.variables:
             assert fo.variables[k].dimensions == fr.variables[k].dimensions
-            assert np.array_equal(fo.variables[k].data, fr.variables[k].data), k
+            # two runs of the same deck: float32 LDS partial sums are order dependent, so not bit-equal
+            assert np.allclose(fo.variables[k].data, fr.variables[k].data, rtol=2e-5, atol=1e-7), k
         assert set(fo._attributes) == set(fr._attributes)
         for k in fr._attributes:
             if not k.startswith("Cpu_time") and k != "Domain_filename":
