@@ -56,6 +56,8 @@ struct i3rc_hip_integrator {
   float maxExt = 0.f;
   int xyRegular = 0, zRegular = 0;
   int maxPfIndex[I3RC_MAX_COMPONENTS] = {};
+  float uniformSsa = -1.f;   // one-component domains: the value every cell shares, else -1
+  int uniformPf = 0;         // ... and the phase-function entry every cell shares, else 0
 
   i3rc_tally_layout layout{};
   DevBuf ownTally;
@@ -206,6 +208,15 @@ int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int n
     int m = 0;
     for (size_t i = 0; i < ncell; ++i) m = std::max(m, pfIndex[(size_t)c * ncell + i]);
     h->maxPfIndex[c] = m;
+  }
+  if (ncomp == 1) {   // values every cell shares travel in the kernel arguments (specialised kernel)
+    bool sameSsa = true, samePf = pfIndex[0] >= 1;
+    for (size_t i = 1; i < ncell && (sameSsa || samePf); ++i) {
+      sameSsa = sameSsa && ssa[i] == ssa[0];
+      samePf = samePf && pfIndex[i] == pfIndex[0];
+    }
+    h->uniformSsa = (sameSsa && ssa[0] >= 0.f) ? ssa[0] : -1.f;
+    h->uniformPf = samePf ? pfIndex[0] : 0;
   }
   // defaults of type(integrator) :54-129
   h->params.surfaceAlbedo = 0.f; h->params.useSurfaceBDRF = 0; h->params.useRayTracing = 1; h->params.useRussianRoulette = 1;
@@ -391,9 +402,12 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan) {
   P.limitContrib = h->params.limitIntensityContributions; P.zetaMin = h->params.zetaMin;
   P.maxContrib = h->params.maxIntensityContribution; P.maxExt = h->maxExt;
   P.dirCos = (const float *)h->dDir.p;
+  P.uniformSsa = h->uniformSsa; P.uniformPf = h->uniformPf;
+  if (h->layout.total >= ((int64_t)1 << 31)) return h->fail("tally buffer too large (2^31 elements or more)");
   P.tally = h->tally;
-  P.oUp = h->layout.fluxUp; P.oDown = h->layout.fluxDown; P.oAbs = h->layout.fluxAbsorbed; P.oVol = h->layout.volumeAbsorption;
-  P.oInt = h->layout.intensityByComponent; P.oExc = h->layout.intensityExcess; P.oCnt = h->layout.counters;
+  P.oUp = (int)h->layout.fluxUp; P.oDown = (int)h->layout.fluxDown; P.oAbs = (int)h->layout.fluxAbsorbed;
+  P.oVol = (int)h->layout.volumeAbsorption; P.oInt = (int)h->layout.intensityByComponent;
+  P.oExc = (int)h->layout.intensityExcess; P.oCnt = (int)h->layout.counters;
   const size_t ncol = (size_t)h->nx * h->ny, ncell = ncol * h->nz;
   size_t lds = sizeof(float) * ((h->nx + 1) + (h->ny + 1) + (h->nz + 1) + 3 * (size_t)h->nDir);
   if (h->nDir > 0) lds += sizeof(float) * kParkWords * 256;   // parked photon state of the radiance path

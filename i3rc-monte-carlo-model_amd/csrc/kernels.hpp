@@ -23,10 +23,19 @@ enum LaneState { ST_TRACE = 0, ST_EVENT = 1, ST_DROPPED = 2, ST_NEW = 3, ST_DONE
                  ST_SHADOW = 5,   // tracing a local-estimate (shadow) ray towards a radiance direction
                  ST_LIGHT = 6 };  // a shadow ray ended, or the first one is due: needs the light phase
 
-struct LaneCounters {
+// Work counters (I3RC_CNT_*) are kept per WAVE, in scalar registers: they are only ever advanced in uniform control
+// flow by the population count of a ballot, so they cost no vector registers and no vector instructions.  The
+// nested local-estimate path (replay / max cross-section builds) counts its tracer work per lane.
+struct WaveCounters {   // 32 bits are enough: a wave hands its counts over every time it refills its photon reservoir
   uint32_t photons = 0, dropped = 0, steps = 0, scat = 0, surf = 0, top = 0, roul = 0, shadow = 0, calls = 0;
-  unsigned long long draws = 0;
 };
+struct NestedCounters { uint32_t shadow = 0, calls = 0; };
+
+__device__ __forceinline__ unsigned count_lanes(bool p) { return (unsigned)__popcll(__ballot(p)); }
+// number of lanes below this one whose bit is set in a wave-uniform mask
+__device__ __forceinline__ int lanes_below(unsigned long long mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -39,31 +48,28 @@ __device__ __forceinline__ void add_global(double *p, float v) { unsafeAtomicAdd
 struct Tally {
   const DevProblem &P;
   const Lds &L;
-  __device__ __forceinline__ void up(int col, float w) const {
-    if (P.ldsTallies) atomicAdd(&L.tUp[col], w); else add_global(P.tally + P.oUp + col, w);
-  }
   __device__ __forceinline__ void down(int col, float w) const {
-    if (P.ldsTallies) atomicAdd(&L.tDown[col], w); else add_global(P.tally + P.oDown + col, w);
+    if (P.ldsTallies) lds_add(&L.tDown[col], w); else add_global(P.tally + P.oDown + col, w);
   }
   // intensityByComponent(ix, iy, d, comp) (:574-579, :662-667)
   __device__ __forceinline__ void radiance(int comp, int d, int col, float v) const {
-    const size_t i = ((size_t)comp * P.nDir + d) * ((size_t)P.nx * P.ny) + col;
-    if (P.ldsIntensity) atomicAdd(&L.tInt[i], v); else add_global(P.tally + P.oInt + i, v);
+    const int i = (comp * P.nDir + d) * (P.nx * P.ny) + col;
+    if (P.ldsIntensity) lds_add(&L.tInt[i], v); else add_global(P.tally + P.oInt + i, v);
   }
   // upward flux at the top (:513) or downward flux at the surface (:531): one atomic for either
   __device__ __forceinline__ void boundary(bool top, int col, float w) const {
-    if (P.ldsTallies) atomicAdd((top ? L.tUp : L.tDown) + col, w);
+    if (P.ldsTallies) lds_add((top ? L.tUp : L.tDown) + col, w);
     else add_global(P.tally + (top ? P.oUp : P.oDown) + col, w);
   }
   __device__ __forceinline__ void absorbed(int col, int cell, float w) const {
-    if (P.ldsTallies) atomicAdd(&L.tAbs[col], w); else add_global(P.tally + P.oAbs + col, w);
+    if (P.ldsTallies) lds_add(&L.tAbs[col], w); else add_global(P.tally + P.oAbs + col, w);
     add_global(P.tally + P.oVol + cell, w);
   }
 };
 
 // computeIntensityContribution :1419-1611 for one event; adds straight into intensityByComponent.
 template <class Rng>
-__device__ __forceinline__ void intensity_contribution(const DevProblem &P, const Lds &L, Rng &rng, LaneCounters &cnt,
+__device__ __forceinline__ void intensity_contribution(const DevProblem &P, const Lds &L, Rng &rng, NestedCounters &cnt,
                                                        float weight, float x, float y, float z, int ix, int iy, int iz,
                                                        float dx, float dy, float dz, int component, int order) {
   const int zIndexMax = P.nz + 1;
@@ -116,7 +122,7 @@ __device__ __forceinline__ void intensity_contribution(const DevProblem &P, cons
       }
     }
     if (P.limitContrib && con > P.maxContrib) {
-      add_global(P.tally + P.oExc + (size_t)component * P.nDir + d, con - P.maxContrib);
+      add_global(P.tally + P.oExc + component * P.nDir + d, con - P.maxContrib);
       con = P.maxContrib;
     }
     const Tally tl{P, L};
@@ -128,27 +134,30 @@ template <class Rng>
 struct RngInit;
 template <>
 struct RngInit<PhiloxStream> {
+  static __device__ __forceinline__ void init(PhiloxStream &g, const RunArgs &A) { g.init(A.seed0, A.seed1); }
   static __device__ __forceinline__ void start(PhiloxStream &g, const RunArgs &A, long long i) {
-    g.start(A.seed0, A.seed1, (uint64_t)(A.firstPhoton + i));
+    g.start((uint64_t)(A.firstPhoton + i));
   }
 };
 template <>
 struct RngInit<ReplayStream> {
-  static __device__ __forceinline__ void start(ReplayStream &g, const RunArgs &A, long long i) {
-    g.start(A.randoms, A.drawStart[i], A.nRandoms);
-  }
+  static __device__ __forceinline__ void init(ReplayStream &g, const RunArgs &A) { g.init(A.randoms, A.nRandoms); }
+  static __device__ __forceinline__ void start(ReplayStream &g, const RunArgs &A, long long i) { g.start(A.drawStart[i]); }
 };
 
 // Wave-private reservoir of photon indices: one returning atomic per `chunk` photons instead of one per respawn
-// round (the returning atomic costs microseconds; every wave would pay it in ~97 % of its event phases).
+// round (the returning atomic costs microseconds; every wave would pay it in ~97 % of its event phases).  The two
+// bounds are wave-uniform and held in scalar registers (readfirstlane tells the compiler so).
 struct Reservoir {
-  long long next, end;   // wave-uniform
-  __device__ __forceinline__ void refill(const RunArgs &A) {
-    long long base = 0;
-    if ((threadIdx.x & 63) == 0) base = (long long)atomicAdd(A.workCounter, (unsigned long long)A.chunk);
-    base = __shfl(base, 0, 64);
-    next = base < A.nPhotons ? base : A.nPhotons;
-    end = base + A.chunk < A.nPhotons ? base + A.chunk : A.nPhotons;
+  long long next, end;
+  __device__ __forceinline__ void refill(const RunArgs &A) {   // call in uniform control flow only
+    unsigned long long base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(A.workCounter, (unsigned long long)A.chunk);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)__shfl((unsigned)base, 0, 64));
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)__shfl((unsigned)(base >> 32), 0, 64));
+    const long long b = (long long)(((unsigned long long)hi << 32) | lo);
+    next = b < A.nPhotons ? b : A.nPhotons;
+    end = b + A.chunk < A.nPhotons ? b + A.chunk : A.nPhotons;
   }
 };
 
@@ -164,7 +173,7 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   {
-    float *p = smem;
+    lds_float *p = (lds_float *)smem;
     L.xE = p; p += P.nx + 1;
     L.yE = p; p += P.ny + 1;
     L.zE = p; p += P.nz + 1;
@@ -193,6 +202,8 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
     for (int i = threadIdx.x; i < (P.ncomp + 1) * P.nDir * P.nx * P.ny; i += blockDim.x) L.tInt[i] = 0.0f;
   __syncthreads();
 
+  constexpr bool REPLAY = Rng::kReplay;        // per-photon fates are recorded by i3rc_hip_run_replay only
+  constexpr bool NEED_PID = REPLAY || GENERAL; // explicit photon sources are indexed by photon number
   const Tally tally{P, L};
   const size_t ncell = (size_t)P.nx * P.ny * P.nz;
   const bool rayTracing = GENERAL ? (P.useRayTracing != 0) : true;
@@ -205,18 +216,19 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
   find_z<GENERAL>(P, L, zStart, izStart);
   const float rcpDeltaX = refined_rcp(P.deltaX), rcpDeltaY = refined_rcp(P.deltaY);
   const float surfaceZ = P.z0 + spacingf(P.z0);
-  const unsigned long long laneBit = 1ull << (threadIdx.x & 63);
 
-  LaneCounters cnt;
+  WaveCounters wc;
+  NestedCounters nested;
   Rng rng;
+  RngInit<Rng>::init(rng, A);
   Ray r;
   r.x = r.y = r.z = 0.0f; r.dx = r.dy = 0.0f; r.dz = -1.0f; r.ix = r.iy = r.iz = 1; r.acc = 0.0f; r.target = 0.0f;
   r.rx = r.ry = r.rz = 0.0f; r.slow = 1;
   float w = 0.0f;
   int order = 0;
   int st = ST_NEW;
-  long long pid = -1;
-  int fate = -1, fateCol = -1;
+  long long pid = -1;                 // photon number within the launch (NEED_PID builds)
+  int fate = -1, fateCol = -1;        // REPLAY builds
   float fateW = 0.0f;
   Reservoir res;
   res.refill(A);
@@ -229,6 +241,27 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
   int dIdx = 0, stage = -1;                          // direction being traced; -1 none, 0 plain, 1 small-contribution RR, 2/3 two-leg RR
   bool pendingShadow = false;
   const bool defer = DEFER && rayTracing;            // max cross-section moves the photon inside the event: keep the nested order there
+
+  // hands the wave's work counters over to the tally buffer (uniform control flow only)
+  auto flush_counters = [&]() {
+    if ((threadIdx.x & 63) == 0) {
+      const uint32_t c[9] = {wc.photons, wc.dropped, wc.steps, wc.scat, wc.surf, wc.top, wc.roul, wc.shadow, wc.calls};
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+        if (c[k] != 0u) unsafeAtomicAdd(P.tally + P.oCnt + k, (double)c[k]);
+    }
+    wc = WaveCounters();
+  };
+  // a photon's record for i3rc_hip_run_replay; production builds keep no per-photon record
+  auto close_photon = [&]() {
+    if (REPLAY) {
+      if (A.fate) {
+        A.fate[pid] = fate; A.fateColumn[pid] = fateCol; A.fateWeight[pid] = fateW; A.fateOrder[pid] = order;
+        A.drawsUsed[pid] = (int32_t)rng.draws_of_photon();
+      }
+    }
+    rng.close();
+  };
 
 #ifdef I3RC_PROFILE_PHASES   // diagnostic build only (tools/phase_profile.sh): where do a wave's cycles go?
   unsigned long long profEv = 0, profSt = 0, profNEv = 0, profNSt = 0, profLanesEv = 0, profLanesSt = 0, profNew = 0;
@@ -253,7 +286,7 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
       // ------------------------------------------------------------ LIGHT phase (shadow-ray ends and starts)
       if (liMask != 0ull && (__popcll(liMask) >= lightThreshold || trMask == 0ull)) {
         if (st == ST_LIGHT) {
-          float *park = L.park + threadIdx.x;
+          lds_float *park = L.park + threadIdx.x;
           if (stage >= 0) {                                              // the ray that just ended (:1517-1596)
             const float tauB = r.acc;
             const bool outTop = r.iz >= P.nz + 1;
@@ -265,13 +298,13 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
             } else if (stage == 2) {
               if (outTop && tauB >= 0.0f) con = (wI * normPF) * expf(-tauB);
               else if (tauB >= 0.0f) {                                   // second leg, up to the free path (:1576-1587)
-                r.acc = 0.0f; r.target = tauFree; stage = 3; st = ST_SHADOW; cnt.calls++;
+                r.acc = 0.0f; r.target = tauFree; stage = 3; st = ST_SHADOW;
               }
             } else con = outTop ? wI * P.zetaMin / kPi : 0.0f;
             if (st == ST_LIGHT) {
               const int comp = __float_as_int(park[13 * 256]) & 0xff;
               if (P.limitContrib && con > P.maxContrib) {                // :1598-1609
-                add_global(P.tally + P.oExc + (size_t)comp * P.nDir + dIdx, con - P.maxContrib);
+                add_global(P.tally + P.oExc + comp * P.nDir + dIdx, con - P.maxContrib);
                 con = P.maxContrib;
               }
               tally.radiance(comp, dIdx, (r.iy - 1) * P.nx + (r.ix - 1), con);
@@ -305,7 +338,6 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
                 if (kPi * normPF <= P.zetaMin) { stage = 1; r.target = tauFree; }
                 else { stage = 2; r.target = -logf(P.zetaMin / fmaxf(kTiny, kPi * normPF)); }
               }
-              cnt.calls++;
               st = ST_SHADOW;
             } else if (w <= kTiny) {
               st = ST_NEW;                                               // killed by roulette at this event
@@ -317,6 +349,8 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
             }
           }
         }
+        // every lane that entered as ST_LIGHT and leaves as ST_SHADOW has started exactly one tracer call
+        wc.calls += (unsigned)__popcll(__ballot(st == ST_SHADOW) & liMask);
       }
     }
     if (evMask == 0ull && trMask == 0ull && liMask == 0ull) break;
@@ -329,64 +363,68 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
       // ---- part A: endings that need no random number -- tracer drop, exit through the top, arrival at a black
       //      surface -- are tallied first so that the lanes can be given their next photon before the wave
       //      generates its random block (part C), which then serves old and new photons in one go.
-      const bool blackSurface = !Rng::kReplay && !useBDRF && !(P.albedo > kTiny) && !INTENSITY;
-      if (wantEvent) {
+      const bool blackSurface = !REPLAY && !useBDRF && !(P.albedo > kTiny) && !INTENSITY;
+      const bool isEv = wantEvent && st == ST_EVENT;
+      const bool dropped = wantEvent && st == ST_DROPPED;                 // :488-489
+      const bool atTop = isEv && r.z >= P.zMax;                           // :499-514
+      const bool atSurface = isEv && !atTop && r.z <= surfaceZ;           // :515-531
+      const bool atBlack = atSurface && blackSurface;                     // ... and :560-562
+      wc.dropped += count_lanes(dropped);
+      wc.top += count_lanes(atTop);
+      wc.surf += count_lanes(atSurface);
+      if (dropped || atTop || atBlack) {
         // one merged branch for the three endings: a single tally atomic and a single bookkeeping block
-        const bool dropped = st == ST_DROPPED;                                            // :488-489
-        const bool atTop = st == ST_EVENT && r.z >= P.zMax;                               // :499-514
-        const bool atBlack = st == ST_EVENT && !atTop && blackSurface && r.z <= surfaceZ; // :515-531, :560-562
-        if (dropped || atTop || atBlack) {
-          if (!dropped) {
-            if (!rayTracing) {   // max cross-section: step back to the boundary (:504-511, :521-528)
-              const float zB = atTop ? P.zMax : P.z0;
-              r.x = make_periodic(r.x - r.dx * fabsf((r.z - zB) / r.dz), P.x0, P.xMax);
-              r.y = make_periodic(r.y - r.dy * fabsf((r.z - zB) / r.dz), P.y0, P.yMax);
-              find_xy<GENERAL>(P, L, r.x, r.y, r.ix, r.iy);
-            }
-            const int c2 = (r.iy - 1) * P.nx + (r.ix - 1);
-            tally.boundary(atTop, c2, w);
-            fateCol = c2; fateW = w;
+        if (!dropped) {
+          if (!rayTracing) {   // max cross-section: step back to the boundary (:504-511, :521-528)
+            const float zB = atTop ? P.zMax : P.z0;
+            r.x = make_periodic(r.x - r.dx * fabsf((r.z - zB) / r.dz), P.x0, P.xMax);
+            r.y = make_periodic(r.y - r.dy * fabsf((r.z - zB) / r.dz), P.y0, P.yMax);
+            find_xy<GENERAL>(P, L, r.x, r.y, r.ix, r.iy);
           }
-          cnt.dropped += dropped ? 1u : 0u;
-          cnt.top += atTop ? 1u : 0u;
-          cnt.surf += atBlack ? 1u : 0u;
+          const int c2 = (r.iy - 1) * P.nx + (r.ix - 1);
+          tally.boundary(atTop, c2, w);
+          if (REPLAY) { fateCol = c2; fateW = w; }
+        }
+        if (REPLAY) {
           order += atBlack ? 1 : 0;
           fate = dropped ? 3 : (atTop ? 0 : 1);
-          st = ST_NEW;
         }
-        if (st == ST_NEW && pid >= 0) {
-          if (A.fate) {
-            A.fate[pid] = fate; A.fateColumn[pid] = fateCol; A.fateWeight[pid] = fateW; A.fateOrder[pid] = order;
-            A.drawsUsed[pid] = (int32_t)rng.draws();
-          }
-          cnt.draws += rng.draws();
-          pid = -1;
-        }
+        close_photon();
+        st = ST_NEW;
       }
       PROF_SEG(0);
-      // ---- part B (converged): hand out photon indices from the wave's reservoir
-      const unsigned long long newMask = __ballot(wantEvent && st == ST_NEW);
+      // ---- part B (uniform): hand out photon indices from the wave's reservoir
+      const bool isNew = wantEvent && st == ST_NEW;
+      const unsigned long long newMask = __ballot(isNew);
       if (newMask != 0ull) {
         int need = __popcll(newMask);
-        int rank = __popcll(newMask & (laneBit - 1ull));
-        const bool isNew = (newMask & laneBit) != 0ull;
-        for (int round = 0; round < 2 && need > 0; ++round) {   // at most one refill per visit (chunk >= 64)
-          const long long avail = res.end - res.next;
-          if (isNew && pid < 0 && rank >= 0 && rank < avail) pid = res.next + rank;
-          const long long taken = avail < need ? avail : need;
-          res.next += taken;
-          need -= (int)taken;
-          rank -= (int)taken;
-          if (need > 0) {
-            if (res.end >= A.nPhotons) break;                   // batch exhausted
-            res.refill(A);
+        int rank = lanes_below(newMask);
+        long long mine = -1;
+        long long avail = res.end - res.next;
+        if (avail < (long long)need && res.end < A.nPhotons) {   // drain the reservoir, then refill it (chunk >= 64 covers the rest)
+          if (isNew && rank < (int)avail) mine = res.next + rank;
+          wc.photons += (unsigned)avail;                        // numPhotonsProcessed :459
+          need -= (int)avail;
+          rank -= (int)avail;
+          flush_counters();
+          res.refill(A);
+          avail = res.end - res.next;
+        }
+        const int taken = (int)(avail < (long long)need ? avail : (long long)need);   // < need only when the batch is exhausted
+        if (isNew && mine < 0 && rank >= 0 && rank < taken) mine = res.next + rank;
+        res.next += taken;
+        wc.photons += (unsigned)taken;
+        if (isNew) {
+          if (mine < 0) st = ST_DONE;
+          else {
+            RngInit<Rng>::start(rng, A, mine);
+            if (NEED_PID) pid = mine;
           }
         }
-        if (isNew && pid < 0) st = ST_DONE;
-        if (isNew && pid >= 0) RngInit<Rng>::start(rng, A, pid);
       }
       PROF_SEG(1);
       // ---- part C: one random block per lane for this event, then the event itself
+      bool didScatter = false, didRoulette = false, startedTrace = false;   // per-lane flags -> wave counters below
       if (wantEvent && st != ST_DONE) {
         rng.begin_event();
         PROF_SEG(2);
@@ -400,9 +438,9 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
             px = A.sx[pid]; py = A.sy[pid]; pz = A.sz[pid];
             make_dircos(A.smu[pid], A.sphi[pid], r.dx, r.dy, r.dz);
           }
-          order = 0; fate = -1; fateCol = -1; fateW = 0.0f;
+          order = 0;
+          if (REPLAY) { fate = -1; fateCol = -1; fateW = 0.0f; }
           w = 1.0f;
-          cnt.photons++;
           r.x = P.x0 + px * (P.xMax - P.x0);
           r.y = P.y0 + py * (P.yMax - P.y0);
           r.z = P.z0 + pz * (P.zMax - P.z0);
@@ -434,21 +472,20 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
             r.z = surfaceZ;
             const int c2 = (r.iy - 1) * P.nx + (r.ix - 1);
             tally.down(c2, w);
-            cnt.surf++;
-            fateCol = c2; fateW = w;
+            if (REPLAY) { fateCol = c2; fateW = w; }
             float mu;
             do { mu = exact_sqrt(rng.next()); } while (!(fabsf(mu) > 2.0f * kTiny));
             const float phi = (2.0f * kPi) * rng.next();
             if (useBDRF) w = w * surface_reflectance(P, r.x, r.y);
             else w = w * P.albedo;
-            if (w <= kTiny) { fate = 1; st = ST_NEW; }
+            if (w <= kTiny) { if (REPLAY) fate = 1; st = ST_NEW; }
             else {
               make_dircos(mu, phi, r.dx, r.dy, r.dz);
               if (defer) {
                 pendingShadow = true; wI = w;
                 L.park[13 * 256 + threadIdx.x] = __int_as_float(0);     // component 0: the surface
               } else if (INTENSITY)
-                intensity_contribution(P, L, rng, cnt, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, 0, order);
+                intensity_contribution(P, L, rng, nested, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, 0, order);
               st = ST_TRACE;
             }
           } else {                                                        // :581-689
@@ -457,8 +494,9 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
             if (!rayTracing) scatterThis = rng.next() < P.totalExt[cell] / P.maxExt;
             if (scatterThis) {
               order++;
-              cnt.scat++;
-              const float extHere = P.ldsGrid ? L.ext[cell] : P.totalExt[cell];
+              didScatter = true;
+              float extHere;
+              if (P.ldsGrid) extHere = L.ext[cell]; else extHere = P.totalExt[cell];
               if (extHere <= 0.0f) {                                      // :606-632 (quirk Q2 kept)
                 if (r.x - L.xE[r.ix - 1] <= 0.0f && r.dx > 0.0f) {
                   r.x = r.x - spacingf(r.x);
@@ -474,7 +512,7 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
                 cell = cell_index(P, r.ix, r.iy, r.iz);
               }
               int comp = 1;                                               // :637-638
-              if (multiComp || Rng::kReplay) {
+              if (multiComp || REPLAY) {
                 const float rc = rng.next();
                 if (multiComp) {
                   const float *cum = P.cumExt + cell;
@@ -482,27 +520,33 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
                                     P.ncomp + 1, 0);
                 }
               }
-              const float ssa = P.ssa[(size_t)(comp - 1) * ncell + cell];
+              // single-scattering albedo and phase-function entry of the cell; a value shared by the whole (one-component)
+              // domain comes from the kernel arguments instead of two dependent memory reads
+              float ssa;
+              if (!GENERAL && P.uniformSsa >= 0.0f) ssa = P.uniformSsa;
+              else ssa = P.ssa[(size_t)(comp - 1) * ncell + cell];
               if (ssa < 1.0f) {                                           // :642-649
                 tally.absorbed((r.iy - 1) * P.nx + (r.ix - 1), cell, w * (1.0f - ssa));
                 w = w * ssa;
               }
+              int pfi;
+              if (!GENERAL && P.uniformPf >= 1) pfi = P.uniformPf;
+              else pfi = P.pfIndex[(size_t)(comp - 1) * ncell + cell];
               if (defer) {                                                // :654-668, traced after this event
                 pendingShadow = true; wI = w;
-                float *park = L.park + threadIdx.x;
+                lds_float *park = L.park + threadIdx.x;
                 park[10 * 256] = r.dx; park[11 * 256] = r.dy; park[12 * 256] = r.dz;   // incoming direction
                 const int useOrig = (P.useHybrid && order <= P.numOrdersOrig) ? 0x100 : 0;
                 park[13 * 256] = __int_as_float(comp | useOrig);
-                park[14 * 256] = __int_as_float(P.pfIndex[(size_t)(comp - 1) * ncell + cell]);
+                park[14 * 256] = __int_as_float(pfi);
               } else if (INTENSITY)
-                intensity_contribution(P, L, rng, cnt, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, comp, order);
+                intensity_contribution(P, L, rng, nested, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, comp, order);
               if (P.useRR && w < 0.5f) {                                  // :673-680
-                cnt.roul++;
+                didRoulette = true;
                 if (rng.next() >= w / 1.0f) w = 0.0f; else w = 1.0f;
               }
-              if (w <= kTiny) { fate = 2; st = ST_NEW; }
+              if (w <= kTiny) { if (REPLAY) fate = 2; st = ST_NEW; }
               else {
-                const int pfi = P.pfIndex[(size_t)(comp - 1) * ncell + cell];
                 const CompTables ct = P.comp[comp - 1];
                 const float cosS = scattering_cosine(rng.next(), ct.invCos + (size_t)(pfi - 1) * ct.nInv, ct.nInv,
                                                      refined_rcp((float)ct.nInv));
@@ -518,7 +562,7 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
         if (st == ST_TRACE) {                                             // :480
           const float tau = -sample_log(fmaxf(kTiny, rng.next()));
           r.acc = 0.0f; r.target = tau;
-          if (rayTracing) { cnt.calls++; r.set_direction(); }
+          if (rayTracing) { startedTrace = true; r.set_direction(); }
           else {                                                          // :494-496 max cross-section move
             r.x = make_periodic(r.x + r.dx * tau / P.maxExt, P.x0, P.xMax);
             r.y = make_periodic(r.y + r.dy * tau / P.maxExt, P.y0, P.yMax);
@@ -528,7 +572,7 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
         }
         PROF_SEG(5);
         if (defer && pendingShadow) {   // park the photon (alive or killed by roulette) and trace its shadow rays first
-          float *park = L.park + threadIdx.x;
+          lds_float *park = L.park + threadIdx.x;
           park[0] = r.x; park[256] = r.y; park[2 * 256] = r.z;
           park[3 * 256] = __int_as_float(r.ix); park[4 * 256] = __int_as_float(r.iy); park[5 * 256] = __int_as_float(r.iz);
           park[6 * 256] = r.dx; park[7 * 256] = r.dy; park[8 * 256] = r.dz;
@@ -537,15 +581,11 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
           st = ST_LIGHT;
         }
         // a photon that died in part C (roulette, absorbing surface) is closed here and respawns at the next event phase
-        if (st == ST_NEW && pid >= 0) {
-          if (A.fate) {
-            A.fate[pid] = fate; A.fateColumn[pid] = fateCol; A.fateWeight[pid] = fateW; A.fateOrder[pid] = order;
-            A.drawsUsed[pid] = (int32_t)rng.draws();
-          }
-          cnt.draws += rng.draws();
-          pid = -1;
-        }
+        if (st == ST_NEW) close_photon();
       }
+      wc.scat += count_lanes(didScatter);
+      wc.roul += count_lanes(didRoulette);
+      wc.calls += count_lanes(startedTrace);
     }
     const unsigned long long profT1 = PROF_T();
 #ifdef I3RC_PROFILE_PHASES
@@ -553,10 +593,10 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
     profNSt++; profLanesSt += __popcll(__ballot(st == ST_TRACE));
 #endif
     // ---------------------------------------------------------------- VOXEL-STEP phase
-    if (st == ST_TRACE || (DEFER && st == ST_SHADOW)) {
-      const bool own = st == ST_TRACE;
-      cnt.steps += own ? 1u : 0u;
-      cnt.shadow += own ? 0u : 1u;
+    const bool own = st == ST_TRACE, shadowRay = DEFER && st == ST_SHADOW;
+    wc.steps += count_lanes(own);
+    if (DEFER) wc.shadow += count_lanes(shadowRay);
+    if (own || shadowRay) {
       const StepResult s = trace_step(P, L, r, own || stage != 0);
       if (s == STEP_DONE) st = own ? ST_EVENT : ST_LIGHT;
       else if (s == STEP_ERROR) st = own ? ST_DROPPED : ST_LIGHT;   // a failed shadow ray contributes nothing (:1531-1535)
@@ -596,12 +636,14 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
       if (v != 0.0f) add_global(P.tally + P.oInt + i, v);
     }
   }
-  const double c[10] = {(double)cnt.photons, (double)cnt.dropped, (double)cnt.steps, (double)cnt.scat, (double)cnt.surf,
-                        (double)cnt.top, (double)cnt.roul, (double)cnt.shadow, (double)(cnt.calls), (double)cnt.draws};
-#pragma unroll
-  for (int k = 0; k < 10; ++k) {
-    const double s = wave_sum(c[k]);
-    if ((threadIdx.x & 63) == 0 && s != 0.0) unsafeAtomicAdd(P.tally + P.oCnt + k, s);
+  // nested local-estimate work and the deviate count are per lane; everything else is already per wave
+  const double nestedShadow = wave_sum((double)nested.shadow), nestedCalls = wave_sum((double)nested.calls);
+  const double draws = wave_sum((double)rng.total());
+  flush_counters();
+  if ((threadIdx.x & 63) == 0) {
+    if (nestedShadow != 0.0) unsafeAtomicAdd(P.tally + P.oCnt + I3RC_CNT_SHADOW_STEPS, nestedShadow);
+    if (nestedCalls != 0.0) unsafeAtomicAdd(P.tally + P.oCnt + I3RC_CNT_TRACER_CALLS, nestedCalls);
+    if (draws != 0.0) unsafeAtomicAdd(P.tally + P.oCnt + I3RC_CNT_RNG_DRAWS, draws);
   }
 }
 
@@ -610,7 +652,7 @@ __global__ void __launch_bounds__(256) trace_rays_kernel(const DevProblem P, lon
                                                          int32_t *idx, const float *target, float *tau, int32_t *steps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
-  L.xE = smem; L.yE = L.xE + P.nx + 1; L.zE = L.yE + P.ny + 1;
+  L.xE = (lds_float *)smem; L.yE = L.xE + P.nx + 1; L.zE = L.yE + P.ny + 1;
   L.tUp = L.tDown = L.tAbs = L.ext = L.dirCos = nullptr;
   for (int i = threadIdx.x; i <= P.nx; i += blockDim.x) L.xE[i] = P.xE[i];
   for (int i = threadIdx.x; i <= P.ny; i += blockDim.x) L.yE[i] = P.yE[i];
@@ -652,9 +694,11 @@ __global__ void philox_kernel(uint32_t seed0, uint32_t seed1, long long firstPho
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   PhiloxStream g;
-  g.start(seed0, seed1, (uint64_t)(firstPhoton + i));
+  g.init(seed0, seed1);
+  g.start((uint64_t)(firstPhoton + i));
   for (int b = 0; b < blocksPerPhoton; ++b) {
     const Philox4 o = philox4x32_10(g.id_lo, g.id_hi, (uint32_t)b, 0u, seed0, seed1);
+    g.begin_event();   // block b of the stream, as the photon kernel draws it
     for (int k = 0; k < 4; ++k) {
       out[(i * blocksPerPhoton + b) * 4 + k] = o.v[k];
       outf[(i * blocksPerPhoton + b) * 4 + k] = g.next();

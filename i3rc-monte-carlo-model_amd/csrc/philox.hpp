@@ -45,34 +45,42 @@ __host__ __device__ inline float u32_to_unit_float(uint32_t u) {
 // needs a fifth deviate (component choice + roulette + angle + azimuth + optical depth) refills on demand.
 struct PhiloxStream {
   static constexpr bool kReplay = false;
-  uint32_t k0, k1, id_lo, id_hi, block;
+  uint32_t k0, k1;           // key: the same for every photon of a launch (wave-uniform, lives in scalar registers)
+  uint32_t id_lo, id_hi, block;
   uint32_t b0, b1, b2, b3;   // current block
   int have;                  // unused words of the block: next() hands out b[4 - have]
-  uint32_t discarded;        // deviates generated but not used (dropped at begin_event)
+  uint32_t used;             // deviates consumed by this lane in blocks already retired (all its photons)
 
-  __device__ inline void start(uint32_t seed0, uint32_t seed1, uint64_t photon) {
+  // once per lane, in uniform control flow
+  __device__ inline void init(uint32_t seed0, uint32_t seed1) {
     k0 = seed0; k1 = seed1;
-    id_lo = (uint32_t)photon; id_hi = (uint32_t)(photon >> 32);
-    block = 0; have = 0; discarded = 0; b0 = b1 = b2 = b3 = 0;
+    id_lo = id_hi = 0u; block = 0u; have = 4; used = 0u; b0 = b1 = b2 = b3 = 0u;
   }
-  // deviates consumed so far: everything generated minus what is still buffered or was discarded
-  __device__ inline uint32_t draws() const { return 4u * block - (uint32_t)have - discarded; }
-#ifdef I3RC_INLINE_REFILL
-  __device__ inline void refill_cold() { refill(); }
-#else
-  __device__ __attribute__((noinline)) void refill_cold() { refill(); }
-#endif   // one shared copy for the rare mid-event refill
+  // next photon of this lane; what is left of the previous photon's block is retired by the begin_event() that follows
+  __device__ inline void start(uint64_t photon) {
+    id_lo = (uint32_t)photon; id_hi = (uint32_t)(photon >> 32);
+    block = 0u;
+  }
+  __device__ inline void close() {}
+  __device__ inline uint32_t draws_of_photon() const { return 0u; }   // per-photon records are a replay-stream feature
+  // deviates consumed by this lane so far (kernel epilogue)
+  __device__ inline uint32_t total() const { return used + (4u - (uint32_t)have); }
   __device__ inline void refill() {
-    const Philox4 o = philox4x32_10(id_lo, id_hi, block, 0u, k0, k1);
+    // The key is wave-uniform; the empty asm makes it opaque here so that the ten round keys (k + r W) are made by
+    // scalar adds next to their use instead of being hoisted out of the photon loop into twenty scalar registers
+    // (which then spill).
+    uint32_t s0 = k0, s1 = k1;
+    asm volatile("" : "+s"(s0), "+s"(s1));
+    const Philox4 o = philox4x32_10(id_lo, id_hi, block, 0u, s0, s1);
     block++;
     b0 = o.v[0]; b1 = o.v[1]; b2 = o.v[2]; b3 = o.v[3];
     have = 4;
   }
-  // fresh block for this event; leftovers of the previous block are discarded (blocks are cheap per lane when the
+  // fresh block for this event; leftovers of the previous block are dropped (blocks are cheap per lane when the
   // whole wave computes them together, expensive when a few lanes do)
-  __device__ inline void begin_event() { discarded += (uint32_t)have; refill(); }
+  __device__ inline void begin_event() { used += 4u - (uint32_t)have; refill(); }
   __device__ inline float next() {
-    if (__builtin_expect(have == 0, 0)) refill();   // inline: an out-of-line call costs scratch spills at every site (measured -13 %)
+    if (__builtin_expect(have == 0, 0)) { used += 4u; refill(); }   // inline: an out-of-line call costs scratch spills at every site (measured -13 %)
     const uint32_t u = have == 4 ? b0 : (have == 3 ? b1 : (have == 2 ? b2 : b3));
     have--;
     return u32_to_unit_float(u);
@@ -95,8 +103,12 @@ struct ReplayStream {
   const float *buf;
   int64_t pos, end;
   int64_t first;
-  __device__ inline void start(const float *b, int64_t p, int64_t e) { buf = b; pos = p; end = e; first = p; }
-  __device__ inline uint32_t draws() const { return (uint32_t)(pos - first); }
+  uint32_t closed;           // deviates consumed by the photons this lane has finished
+  __device__ inline void init(const float *b, int64_t e) { buf = b; end = e; pos = first = 0; closed = 0u; }
+  __device__ inline void start(int64_t p) { pos = p; first = p; }
+  __device__ inline uint32_t draws_of_photon() const { return (uint32_t)(pos - first); }
+  __device__ inline void close() { closed += draws_of_photon(); first = pos; }
+  __device__ inline uint32_t total() const { return closed; }
   __device__ inline void begin_event() {}
   __device__ inline float next() {
     float r = pos < end ? buf[pos] : 0.5f;

@@ -40,9 +40,12 @@ struct DevProblem {
   int useRayTracing, useRR, nDir, useHybrid, numOrdersOrig, useRRI, limitContrib;
   float zetaMin, maxContrib, maxExt;
   const float *dirCos;                // [nDir][3] (global; staged to LDS)
-  // tallies (float64, packed; offsets in elements)
+  // single-component shortcuts (specialised kernel): a value every cell shares is passed in the kernarg segment
+  float uniformSsa;                   // >= 0: ssa of every cell of component 1; < 0: per-cell values differ
+  int uniformPf;                      // >= 1: phaseFunctionIndex of every cell of component 1; 0: per-cell values differ
+  // tallies (float64, packed; offsets in elements: i3rc_hip_create keeps the whole buffer below 2^31 elements)
   double *tally;
-  long long oUp, oDown, oAbs, oVol, oInt, oExc, oCnt;
+  int oUp, oDown, oAbs, oVol, oInt, oExc, oCnt;
   int ldsTallies;                     // 1: fluxUp/Down/Absorbed privatised in LDS (ncol small)
   int ldsGrid;                        // 1: totalExt staged in LDS
   int ldsIntensity;                   // 1: intensityByComponent privatised in LDS ((ncomp+1)*nDir*ncol small)
@@ -61,15 +64,19 @@ struct RunArgs {
   int32_t *fate, *fateColumn; float *fateWeight; int32_t *fateOrder, *drawsUsed;
 };
 
-// LDS carve-up shared by all device functions (offsets in floats from the dynamic LDS base).
+// LDS carve-up shared by all device functions.  The pointers carry the LDS address space in their type, so every
+// access is a ds_* instruction even where the same value may come from LDS or from global memory (a generic pointer
+// there ends in a flat_load of a selected address).
+typedef __attribute__((address_space(3))) float lds_float;
 struct Lds {
-  float *xE, *yE, *zE;    // edges
-  float *tUp, *tDown, *tAbs;  // privatised flux tallies (valid when ldsTallies)
-  float *ext;             // totalExt copy (valid when ldsGrid)
-  float *dirCos;          // intensity directions
-  float *tInt;            // privatised intensityByComponent (valid when ldsIntensity)
-  float *park;            // [kParkWords][256]: a photon's own state while its shadow rays are traced
+  lds_float *xE, *yE, *zE;    // edges
+  lds_float *tUp, *tDown, *tAbs;  // privatised flux tallies (valid when ldsTallies)
+  lds_float *ext;             // totalExt copy (valid when ldsGrid)
+  lds_float *dirCos;          // intensity directions
+  lds_float *tInt;            // privatised intensityByComponent (valid when ldsIntensity)
+  lds_float *park;            // [kParkWords][256]: a photon's own state while its shadow rays are traced
 };
+__device__ __forceinline__ void lds_add(lds_float *p, float v) { atomicAdd((float *)p, v); }
 constexpr int kParkWords = 15;
 
 // Fortran SPACING() for real(4)
@@ -199,7 +206,9 @@ __device__ __forceinline__ StepResult trace_step(const DevProblem &P, const Lds 
   if (__builtin_expect(step <= 0.0f, 0)) { r.acc = -2.0f; return STEP_ERROR; }   // :1711-1714
 
   const int cell = cell_index(P, r.ix, r.iy, r.iz);
-  const float ext = P.ldsGrid ? L.ext[cell] : P.totalExt[cell];
+  float ext;
+  if (P.ldsGrid) ext = L.ext[cell];      // ds_read; a pointer select here would turn both into flat loads
+  else ext = P.totalExt[cell];
   const float tauCell = step * ext;
   bool reach = false;
   float adv = step;
@@ -247,7 +256,7 @@ __device__ __forceinline__ void find_xy(const DevProblem &P, const Lds &L, float
     if (j == P.ny + 1) j = 1;
     ix = i; iy = j;
   } else {
-    const float *xe = L.xE, *ye = L.yE;
+    const lds_float *xe = L.xE, *ye = L.yE;
     ix = find_index(x, [xe](int k) { return xe[k - 1]; }, P.nx + 1, ix);
     iy = find_index(y, [ye](int k) { return ye[k - 1]; }, P.ny + 1, iy);
   }
@@ -259,7 +268,7 @@ __device__ __forceinline__ void find_z(const DevProblem &P, const Lds &L, float 
     if (fabsf(L.zE[k] - z) < spacingf(z)) k = k + 1;
     iz = k;
   } else {
-    const float *ze = L.zE;
+    const lds_float *ze = L.zE;
     iz = find_index(z, [ze](int k) { return ze[k - 1]; }, P.nz + 1, iz);
   }
 }
