@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "pool_kernel.hpp"
 
 using namespace i3rc;
 
@@ -73,7 +74,7 @@ struct i3rc_hip_integrator {
   int evThreshold = 40;
   int lightThreshold = 24;
   int blocksPerCU = 0;  // 0 = from occupancy query
-  bool forceGeneral = false;  // test knob: run the general kernel even when the specialisation applies
+  int kernelVariant = I3RC_KERNEL_AUTO;  // test / tuning knob (i3rc_hip_select_kernel)
   std::string err;
 
   int fail(const std::string &m) { err = m; return 1; }
@@ -353,11 +354,16 @@ int i3rc_hip_set_tuning(i3rc_hip_integrator *h, int evThreshold, int blocksPerCU
   return 0;
 }
 
-/* Test knob: 1 = always run the general kernel, even when the specialised one applies. */
-int i3rc_hip_force_general_kernel(i3rc_hip_integrator *h, int on) {
+int i3rc_hip_select_kernel(i3rc_hip_integrator *h, int variant) {
   if (!h) return 1;
-  h->forceGeneral = on != 0;
+  if (variant < I3RC_KERNEL_AUTO || variant > I3RC_KERNEL_POOL) return h->fail("i3rc_hip_select_kernel: unknown variant");
+  h->kernelVariant = variant;
   return 0;
+}
+
+/* Older name of i3rc_hip_select_kernel(h, on ? I3RC_KERNEL_GENERAL : I3RC_KERNEL_AUTO). */
+int i3rc_hip_force_general_kernel(i3rc_hip_integrator *h, int on) {
+  return i3rc_hip_select_kernel(h, on ? I3RC_KERNEL_GENERAL : I3RC_KERNEL_AUTO);
 }
 
 }  // extern "C"
@@ -368,11 +374,18 @@ struct LaunchPlan {
   DevProblem P;
   size_t ldsBytes;
   bool intensity;
+  bool pool;      // photon_pool_kernel (flux-only problems of the common class)
 };
 
 constexpr size_t kLdsBudget = 64 * 1024;  // per workgroup: leaves room for >= 2 workgroups per CU
 
-int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan) {
+// Which kernel runs a launch (see photon_kernel / photon_pool_kernel): the common problem class -- regular grid,
+// ray tracing, one component, no BRDF grid, Directional source -- has specialised kernels.
+bool common_class(const i3rc_hip_integrator *h, int srcKind) {
+  return h->xyRegular && h->zRegular && h->params.useRayTracing && !h->params.useSurfaceBDRF && h->ncomp == 1 && srcKind == 0;
+}
+
+int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool wantPool = false) {
   DevProblem &P = plan.P;
   std::memset(&P, 0, sizeof(P));
   for (int c = 0; c < h->ncomp; ++c)
@@ -392,6 +405,7 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan) {
   if (hipMemcpyAsync(h->dComp.p, h->comp, sizeof(CompTables) * I3RC_MAX_COMPONENTS, hipMemcpyHostToDevice, h->stream) != hipSuccess)
     return h->fail("hipMemcpyAsync(component tables) failed");
   P.comp = (const CompTables *)h->dComp.p;
+  P.comp0 = h->comp[0];
   P.albedo = h->params.surfaceAlbedo; P.useBDRF = h->params.useSurfaceBDRF;
   P.nxs = h->nxs; P.nys = h->nys;
   P.xsE = (const float *)h->dXs.p; P.ysE = (const float *)h->dYs.p; P.brdf = (const float *)h->dBrdf.p;
@@ -412,15 +426,20 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan) {
   size_t lds = sizeof(float) * ((h->nx + 1) + (h->ny + 1) + (h->nz + 1) + 3 * (size_t)h->nDir);
   if (h->nDir > 0) lds += sizeof(float) * kParkWords * 256;   // parked photon state of the radiance path
   if (lds > kLdsBudget) return h->fail("domain edge vectors do not fit in LDS");
+  // the pool kernel wants 4 workgroups per CU (160 KB of LDS): what the pools leave of 40 KB is the budget for
+  // edges, tallies and grid
+  plan.pool = wantPool && h->nDir == 0 && lds + kPoolBytesPerBlock <= 40 * 1024;
+  const size_t budget = plan.pool ? 40 * 1024 - (size_t)kPoolBytesPerBlock : kLdsBudget;
   P.ldsTallies = 0;
-  if (lds + 3 * ncol * sizeof(float) <= kLdsBudget / 2) { P.ldsTallies = 1; lds += 3 * ncol * sizeof(float); }
+  if (lds + 3 * ncol * sizeof(float) <= (plan.pool ? budget : kLdsBudget / 2)) { P.ldsTallies = 1; lds += 3 * ncol * sizeof(float); }
   P.ldsIntensity = 0;
   {
     const size_t nInt = (size_t)(h->ncomp + 1) * h->nDir * ncol * sizeof(float);
     if (h->nDir > 0 && nInt <= 16 * 1024 && lds + nInt <= kLdsBudget) { P.ldsIntensity = 1; lds += nInt; }
   }
   P.ldsGrid = 0;
-  if (lds + ncell * sizeof(float) <= kLdsBudget) { P.ldsGrid = 1; lds += ncell * sizeof(float); }
+  if (lds + ncell * sizeof(float) <= budget) { P.ldsGrid = 1; lds += ncell * sizeof(float); }
+  if (plan.pool) lds += kPoolBytesPerBlock;
   plan.ldsBytes = (lds + 15) & ~(size_t)15;
   plan.intensity = h->nDir > 0;
   return 0;
@@ -453,28 +472,30 @@ int upload_source(i3rc_hip_integrator *h, const i3rc_source *src, int64_t n, Run
 
 template <class Rng>
 int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, bool timeIt) {
-  // fast specialisation when the problem is in the common class (see photon_kernel), else the general kernel
-  const bool simple = !Rng::kReplay && plan.P.xyRegular && plan.P.zRegular && plan.P.useRayTracing && !plan.P.useBDRF &&
-                      plan.P.ncomp == 1 && A.srcKind == 0 && !h->forceGeneral;
+  // fast specialisations when the problem is in the common class (see photon_kernel), else the general kernel
+  const bool simple = !Rng::kReplay && common_class(h, A.srcKind) && h->kernelVariant != I3RC_KERNEL_GENERAL;
+  const bool pool = simple && plan.pool;
   auto kern = plan.intensity ? (simple ? photon_kernel<Rng, true, false> : photon_kernel<Rng, true, true>)
                              : (simple ? photon_kernel<Rng, false, false> : photon_kernel<Rng, false, true>);
+  const void *fn = pool ? (const void *)photon_pool_kernel : (const void *)kern;
   int perCU = h->blocksPerCU;
   if (perCU <= 0) {
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, plan.ldsBytes) != hipSuccess || occ < 1) occ = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, plan.ldsBytes) != hipSuccess || occ < 1) occ = 2;
     perCU = std::min(occ, 8);
   }
   if (plan.ldsBytes > 48 * 1024)
-    HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.ldsBytes));
+    HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.ldsBytes));
   long long blocks = (long long)h->numCU * perCU;
   const long long need = (A.nPhotons + 255) / 256;
   if (blocks > need) blocks = std::max(1ll, need);
   RunArgs B = A;   // photon indices are handed to waves in chunks (one returning atomic per chunk)
-  B.chunk = (int)std::min<long long>(1024, std::max<long long>(64, A.nPhotons / (blocks * 4 * 8)));
+  B.chunk = (int)std::min<long long>(1024, std::max<long long>(pool ? kPool : 64, A.nPhotons / (blocks * 4 * 8)));
   HIPCHK(h, hipMemsetAsync(A.workCounter, 0, sizeof(unsigned long long), h->stream));
   const int slot = (int)(h->timedLaunches % i3rc_hip_integrator::kEventRing);
   if (timeIt) HIPCHK(h, hipEventRecord(h->evStart[slot], h->stream));
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), plan.ldsBytes, h->stream, plan.P, B, h->evThreshold, h->lightThreshold);
+  if (pool) hipLaunchKernelGGL(photon_pool_kernel, dim3((unsigned)blocks), dim3(256), plan.ldsBytes, h->stream, plan.P, B);
+  else hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), plan.ldsBytes, h->stream, plan.P, B, h->evThreshold, h->lightThreshold);
   HIPCHK(h, hipGetLastError());
   if (timeIt) { HIPCHK(h, hipEventRecord(h->evStop[slot], h->stream)); h->timedLaunches++; }
   return 0;
@@ -491,7 +512,9 @@ int i3rc_hip_launch_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1
   if (nPhotons <= 0) return h->fail("setIllumination: must ask for non-negative number of photons.");  // illumination :78-79
   HIPCHK(h, hipSetDevice(h->device));
   LaunchPlan plan;
-  if (make_problem(h, plan)) return 1;
+  // the pool kernel is an experiment (slower than the per-lane kernel on every case measured so far): on request only
+  const bool wantPool = common_class(h, src->kind) && nPhotons < ((int64_t)1 << 32) && h->kernelVariant == I3RC_KERNEL_POOL;
+  if (make_problem(h, plan, wantPool)) return 1;
   RunArgs A;
   std::memset(&A, 0, sizeof(A));
   A.seed0 = seed0; A.seed1 = seed1; A.firstPhoton = firstPhoton; A.nPhotons = nPhotons;

@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
                 if (fabsf(proj) > 1.0f) proj = copysignf(1.0f, proj);
                 const float ang = acosf(proj);
                 const int pfi = __float_as_int(park[14 * 256]);
-                const CompTables ct = P.comp[comp - 1];
+                const CompTables ct = GENERAL ? P.comp[comp - 1] : P.comp0;
                 const float *tab = ((info & 0x100) ? ct.fwdOrig : ct.fwd) + (size_t)(pfi - 1) * ct.nFwd;
                 normPF = lookup_phase(tab, ct.nFwd, ang) / ((4.0f * kPi) * fabsf(uz));
               }
@@ -547,7 +547,7 @@ __global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevPr
               }
               if (w <= kTiny) { if (REPLAY) fate = 2; st = ST_NEW; }
               else {
-                const CompTables ct = P.comp[comp - 1];
+                const CompTables ct = GENERAL ? P.comp[comp - 1] : P.comp0;
                 const float cosS = scattering_cosine(rng.next(), ct.invCos + (size_t)(pfi - 1) * ct.nInv, ct.nInv,
                                                      refined_rcp((float)ct.nInv));
                 next_direct(rng, cosS, r.dx, r.dy, r.dz);                 // :684-687

@@ -33,6 +33,8 @@ struct DevProblem {
   const float *cumExt, *ssa;          // [ncomp][nz][ny][nx]
   const int32_t *pfIndex;             // [ncomp][nz][ny][nx]
   const CompTables *comp;             // [ncomp] phase-function tables (device memory: indexed per lane)
+  CompTables comp0;                   // tables of component 1 by value: the specialised (one-component) kernel reads them
+                                      // from scalar registers, and its table loads are global_load, not flat_load
   // surface
   float albedo; int useBDRF; int nxs, nys;
   const float *xsE, *ysE, *brdf;

@@ -179,8 +179,16 @@ int i3rc_hip_kernel_ms_history(i3rc_hip_integrator *h, int n, float *ms);
  * event phase (1..64, default 40) and workgroups per CU (0 = occupancy query). */
 int i3rc_hip_set_tuning(i3rc_hip_integrator *h, int evThreshold, int blocksPerCU);
 
-/* Test knob: the launch normally picks a kernel specialised for the common problem class (regular grid, ray tracing,
- * one component, no BRDF grid, Directional source); 1 forces the general kernel so both can be compared. */
+/* Test / tuning knob.  A launch normally (AUTO) runs the one-photon-per-lane kernel specialised for the common
+ * problem class (regular grid, ray tracing, one component, no BRDF grid, Directional source) when the problem is
+ * in it, else the general kernel.  All kernels trace the same photon paths from the same per-photon random streams,
+ * so tests run one against the other.
+ *   GENERAL: always the general kernel;  LANE: same choice as AUTO;
+ *   POOL: the experimental two-photons-per-lane kernel with photon state in LDS (flux-only problems of the common
+ *         class; fuller wavefronts, but measured slower than LANE -- DESIGN.md) where it applies. */
+enum { I3RC_KERNEL_AUTO = 0, I3RC_KERNEL_GENERAL = 1, I3RC_KERNEL_LANE = 2, I3RC_KERNEL_POOL = 3 };
+int i3rc_hip_select_kernel(i3rc_hip_integrator *h, int variant);
+/* = i3rc_hip_select_kernel(h, on ? I3RC_KERNEL_GENERAL : I3RC_KERNEL_AUTO) */
 int i3rc_hip_force_general_kernel(i3rc_hip_integrator *h, int on);
 
 /* Test hook: the raw Philox4x32-10 blocks (out[n][blocksPerPhoton][4]) of photons firstPhoton..+n-1 and the

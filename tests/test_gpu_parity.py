@@ -305,6 +305,35 @@ def test_specialised_and_general_kernels_trace_the_same_photons():
         assert np.allclose(a["raw"], b["raw"], rtol=1e-5, atol=1e-5)
 
 
+def test_pool_lane_and_general_kernels_trace_the_same_photons():
+    # flux-only problems of the common class run the photon-pool kernel (128 photons per wave in LDS, full
+    # wavefronts in every phase); the one-photon-per-lane kernel and the general kernel must give every photon the
+    # same fate: identical work counters, tallies equal up to the float32 order of the LDS partial sums
+    cfgs = [(cases.step_cloud(ssa=1.0, nlayers=16), 0.0, 1.0, 0.0, 200000),
+            (cases.step_cloud(ssa=0.97, nlayers=32), 0.4, 0.5, 75.0, 60000),
+            (cases.plane_parallel(optical_depth=0.3), 1.0, 0.3, 0.0, 20000),      # mirror-white surface, thin layer
+            (cases.radar_cloud_64(), 0.1, 0.8, 200.0, 20000)]                      # tallies and grid in HBM, not in LDS
+    for d, albedo, mu0, az, n in cfgs:
+        table = hg_table() if "table" not in d else d["table"]
+        g = make_gpu(d, table, surfaceAlbedo=albedo)
+        out = {}
+        for kernel in ("pool", "lane", "general"):
+            g.set_tuning(40, 0, kernel=kernel)
+            out[kernel] = g.computeRadiativeTransfer(M.new_RandomNumberSequence((8, 2)), M.new_PhotonStream(mu0, az, n))
+        g.set_tuning(40, 0, kernel="auto")
+        for other in ("lane", "general"):
+            assert out["pool"]["counters"] == out[other]["counters"], other
+            assert np.allclose(out["pool"]["raw"], out[other]["raw"], rtol=2e-5, atol=1e-5), other
+        # a launch that ends in the middle of a pool refill, and one smaller than a pool
+        for m in (1, 63, 129, 5000):
+            g.set_tuning(40, 0, kernel="pool")
+            a = g.computeRadiativeTransfer(M.new_RandomNumberSequence((8, 3)), M.new_PhotonStream(mu0, az, m))
+            g.set_tuning(40, 0, kernel="lane")
+            b = g.computeRadiativeTransfer(M.new_RandomNumberSequence((8, 3)), M.new_PhotonStream(mu0, az, m))
+            assert a["counters"] == b["counters"] and a["counters"]["photons"] == m
+            assert np.allclose(a["raw"], b["raw"], rtol=2e-5, atol=1e-5)
+
+
 def test_edge_cases_and_errors():
     d = cases.plane_parallel(optical_depth=0.0)  # empty domain: everything reaches the black surface
     g = make_gpu(d, hg_table())

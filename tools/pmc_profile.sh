@@ -19,7 +19,7 @@ import csv,glob
 vals={}
 for f in glob.glob("$OUT/p*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "photon_kernel" in r["Kernel_Name"]:
+        if "photon_kernel" in r["Kernel_Name"] or "photon_pool_kernel" in r["Kernel_Name"]:
             vals[r["Counter_Name"]]=vals.get(r["Counter_Name"],0)+float(r["Counter_Value"])
             vals["_VGPR"]=r["VGPR_Count"]; vals["_SGPR"]=r["SGPR_Count"]; vals["_LDS"]=r["LDS_Block_Size"]; vals["_grid"]=r["Grid_Size"]
 with open("$OUT/summary.txt","w") as o:
