@@ -51,6 +51,7 @@ struct i3rc_hip_integrator {
   DevBuf dComp;
   DevBuf dXs, dYs, dBrdf;
   int nxs = 0, nys = 0;
+  float brdf0 = 0.f;          // reflectance of the first surface cell (a 1 x 1 surface grid is a plain Lambertian albedo)
   DevBuf dDir;
   int nDir = 0;
   i3rc_params params{};
@@ -71,8 +72,8 @@ struct i3rc_hip_integrator {
   hipEvent_t evStart[kEventRing] = {}, evStop[kEventRing] = {};
   long long timedLaunches = 0;
   int numCU = 256;
-  int evThreshold = 40;
-  int lightThreshold = 24;
+  int evThreshold = 0;        // lanes waiting before a wave runs its event phase; 0 = default (40 flux-only, 24 with radiances)
+  int lightThreshold = 0;     // lanes with an ended shadow ray before a wave runs its light phase; 0 = default (24, or 8 from 3 directions on)
   int blocksPerCU = 0;  // 0 = from occupancy query
   int kernelVariant = I3RC_KERNEL_AUTO;  // test / tuning knob (i3rc_hip_select_kernel)
   std::string err;
@@ -298,6 +299,7 @@ int i3rc_hip_set_surface(i3rc_hip_integrator *h, int nxs, int nys, const float *
   HIPCHK(h, h->dYs.upload(ys, sizeof(float) * (nys + 1)));
   HIPCHK(h, h->dBrdf.upload(brdf, sizeof(float) * (size_t)nxs * nys));
   h->nxs = nxs; h->nys = nys;
+  h->brdf0 = brdf[0];
   return 0;
 }
 
@@ -349,8 +351,15 @@ int i3rc_hip_zero_tallies(i3rc_hip_integrator *h) {
 /* Tunables for experiments (not part of the reference API): event-phase ballot threshold, blocks per CU. */
 int i3rc_hip_set_tuning(i3rc_hip_integrator *h, int evThreshold, int blocksPerCU) {
   if (!h) return 1;
-  if (evThreshold >= 1 && evThreshold <= 64) h->evThreshold = evThreshold;
+  if (evThreshold >= 0 && evThreshold <= 64) h->evThreshold = evThreshold;   // 0 = default
   if (blocksPerCU >= 0 && blocksPerCU <= 8) h->blocksPerCU = blocksPerCU;
+  return 0;
+}
+
+int i3rc_hip_set_light_threshold(i3rc_hip_integrator *h, int lanes) {
+  if (!h) return 1;
+  if (lanes < 0 || lanes > 64) return h->fail("i3rc_hip_set_light_threshold: need 1..64 lanes (0 = default)");
+  h->lightThreshold = lanes;
   return 0;
 }
 
@@ -381,8 +390,14 @@ constexpr size_t kLdsBudget = 64 * 1024;  // per workgroup: leaves room for >= 2
 
 // Which kernel runs a launch (see photon_kernel / photon_pool_kernel): the common problem class -- regular grid,
 // ray tracing, one component, no BRDF grid, Directional source -- has specialised kernels.
+// A surface description with a single cell (new_SurfaceDescription((/ albedo /)), the form BASELINE.json's Landsat
+// radiance case uses) reflects like surfaceAlbedo: computeSurfaceReflectance returns its one parameter wherever the
+// photon lands (Code/surfaceProperties.f95:121-162), and the weight is multiplied by the same float.
+bool uniform_surface(const i3rc_hip_integrator *h) { return h->params.useSurfaceBDRF && h->nxs == 1 && h->nys == 1; }
+
 bool common_class(const i3rc_hip_integrator *h, int srcKind) {
-  return h->xyRegular && h->zRegular && h->params.useRayTracing && !h->params.useSurfaceBDRF && h->ncomp == 1 && srcKind == 0;
+  const bool gridSurface = h->params.useSurfaceBDRF && !uniform_surface(h);
+  return h->xyRegular && h->zRegular && h->params.useRayTracing && !gridSurface && h->ncomp == 1 && srcKind == 0;
 }
 
 int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool wantPool = false) {
@@ -407,6 +422,7 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool wantPool = false
   P.comp = (const CompTables *)h->dComp.p;
   P.comp0 = h->comp[0];
   P.albedo = h->params.surfaceAlbedo; P.useBDRF = h->params.useSurfaceBDRF;
+  if (uniform_surface(h)) { P.albedo = h->brdf0; P.useBDRF = 0; }
   P.nxs = h->nxs; P.nys = h->nys;
   P.xsE = (const float *)h->dXs.p; P.ysE = (const float *)h->dYs.p; P.brdf = (const float *)h->dBrdf.p;
   if (P.useBDRF && !P.brdf) return h->fail("computeRadiativeTransfer: surfaceBDRF requested but no surface description set");
@@ -495,7 +511,15 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
   const int slot = (int)(h->timedLaunches % i3rc_hip_integrator::kEventRing);
   if (timeIt) HIPCHK(h, hipEventRecord(h->evStart[slot], h->stream));
   if (pool) hipLaunchKernelGGL(photon_pool_kernel, dim3((unsigned)blocks), dim3(256), plan.ldsBytes, h->stream, plan.P, B);
-  else hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), plan.ldsBytes, h->stream, plan.P, B, h->evThreshold, h->lightThreshold);
+  else {
+    // measured optima (tools/quick_bench.py, tools/radiance_sweep.py): photons' own paths alone 40; with shadow rays in
+    // the mix events are a smaller share of the work and waiting for them costs more than a thinner event phase
+    // (radar + 1 direction: 40 / 24 is 8 % faster than 24 / 8; Landsat + 7 directions: 24 / 8 is 34 % faster than 40 / 24)
+    const bool manyRays = h->nDir >= 3;
+    const int evThreshold = h->evThreshold > 0 ? h->evThreshold : (manyRays ? 24 : 40);
+    const int lightThreshold = h->lightThreshold > 0 ? h->lightThreshold : (manyRays ? 8 : 24);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), plan.ldsBytes, h->stream, plan.P, B, evThreshold, lightThreshold);
+  }
   HIPCHK(h, hipGetLastError());
   if (timeIt) { HIPCHK(h, hipEventRecord(h->evStop[slot], h->stream)); h->timedLaunches++; }
   return 0;

@@ -168,8 +168,9 @@ struct Reservoir {
 // Lambertian albedo (no BRDF grid), Directional source, production RNG: the rare paths (grid searches, periodic
 // re-wrapping loops, max-cross-section moves, BRDF lookups, component selection) are compiled out, which shrinks the
 // loop's code and its scalar-register pressure.  GENERAL = true keeps every path behind run-time switches.
+// (the general radiance kernel keeps the most state live: 4 waves per SIMD give it 128 vector registers and no spills)
 template <class Rng, bool INTENSITY, bool GENERAL>
-__global__ void __launch_bounds__(256, I3RC_MIN_WAVES) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
+__global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAVES) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   {

@@ -418,13 +418,15 @@ class Integrator:
     # -- test hooks
     KERNELS = {"auto": 0, "general": 1, "lane": 2, "pool": 3}
 
-    def set_tuning(self, evThreshold=40, blocksPerCU=0, forceGeneral=None, kernel=None):
+    def set_tuning(self, evThreshold=0, blocksPerCU=0, forceGeneral=None, kernel=None, lightThreshold=None):
         """Experiment knobs of the C ABI (i3rc_hip_set_tuning / i3rc_hip_select_kernel); kernel is one of KERNELS."""
         self._check(self._lib.i3rc_hip_set_tuning(self._h, int(evThreshold), int(blocksPerCU)), "set_tuning")
         if forceGeneral is not None:
             self._check(self._lib.i3rc_hip_force_general_kernel(self._h, int(bool(forceGeneral))), "set_tuning")
         if kernel is not None:
             self._check(self._lib.i3rc_hip_select_kernel(self._h, self.KERNELS[kernel]), "set_tuning")
+        if lightThreshold is not None:
+            self._check(self._lib.i3rc_hip_set_light_threshold(self._h, int(lightThreshold)), "set_tuning")
 
     def trace_rays(self, direction, pos, idx, target=None):
         d, p = f32(direction).reshape(-1, 3).copy(), f32(pos).reshape(-1, 3).copy()
