@@ -189,6 +189,12 @@ __device__ __forceinline__ int cell_index(const DevProblem &P, int ix, int iy, i
 // so branches would execute both arms anyway and add exec-mask bookkeeping on top.  The arithmetic of each arm is
 // exactly the reference's (checked bit for bit against the oracle by the tracer tests).
 __device__ __forceinline__ StepResult trace_step(const DevProblem &P, const Lds &L, Ray &r, bool hasTarget) {
+  // the extinction of the current cell is requested first: its latency (LDS, or L2 / HBM for grids that do not fit
+  // in LDS) is covered by the three face-distance divisions below
+  const int cell = cell_index(P, r.ix, r.iy, r.iz);
+  float ext;
+  if (P.ldsGrid) ext = L.ext[cell];      // ds_read; a pointer select here would turn both into flat loads
+  else ext = P.totalExt[cell];
   const bool px = r.dx >= 0.0f, py = r.dy >= 0.0f, pz = r.dz >= 0.0f;
   const int cx = px ? 1 : -1, cy = py ? 1 : -1, cz = pz ? 1 : -1;
   const float ex = L.xE[r.ix - (px ? 0 : 1)], ey = L.yE[r.iy - (py ? 0 : 1)], ez = L.zE[r.iz - (pz ? 0 : 1)];
@@ -207,10 +213,6 @@ __device__ __forceinline__ StepResult trace_step(const DevProblem &P, const Lds 
   step = stz < step ? stz : step;
   if (__builtin_expect(step <= 0.0f, 0)) { r.acc = -2.0f; return STEP_ERROR; }   // :1711-1714
 
-  const int cell = cell_index(P, r.ix, r.iy, r.iz);
-  float ext;
-  if (P.ldsGrid) ext = L.ext[cell];      // ds_read; a pointer select here would turn both into flat loads
-  else ext = P.totalExt[cell];
   const float tauCell = step * ext;
   bool reach = false;
   float adv = step;
