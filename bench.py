@@ -139,6 +139,11 @@ def main():
     raw = tally.cpu().numpy()
     res = integ.finish(raw)
     counters = res["counters"]
+    # the last step's tallies must be those of exactly one step: every photon leaves through the top, reaches the
+    # (black) surface or is dropped by the tracer -- a wrong count or a lost / doubled tally shows here
+    closure = float(res["fluxUp"].mean() + res["fluxDown"].mean()) + counters["dropped"] / counters["photons"]
+    if counters["photons"] != float(a.photons) * n_gpus or abs(closure - 1.0) > 1e-4:
+        raise SystemExit(f"bench: inconsistent results (photons {counters['photons']:.0f}, energy closure {closure:.6f})")
     local = {k: v / n_gpus for k, v in counters.items()}  # identical work per rank (weak scaling)
     avg_ms = float(np.mean(kernel_ms))
     bpp, skd = algorithmic_bytes_per_photon(local)

@@ -337,7 +337,13 @@ int i3rc_hip_bind_tally_buffer(i3rc_hip_integrator *h, void *devicePtr, size_t b
 
 int i3rc_hip_set_stream(i3rc_hip_integrator *h, void *s) {
   if (!h) return 1;
-  h->stream = s ? (hipStream_t)s : h->ownStream;
+  h->stream = (hipStream_t)s;   // NULL is HIP's null stream (what torch.cuda.current_stream() is by default)
+  return 0;
+}
+
+int i3rc_hip_use_own_stream(i3rc_hip_integrator *h) {
+  if (!h) return 1;
+  h->stream = h->ownStream;
   return 0;
 }
 

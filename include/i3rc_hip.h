@@ -124,8 +124,12 @@ int i3rc_hip_get_tally_layout(const i3rc_hip_integrator *h, i3rc_tally_layout *l
  * layout.total float64 elements.  NULL restores the handle's own buffer. */
 int i3rc_hip_bind_tally_buffer(i3rc_hip_integrator *h, void *devicePtr, size_t bytes);
 
-/* Run on this HIP stream (hipStream_t as void*); NULL = the handle's own stream. */
+/* Run on the caller's HIP stream (hipStream_t as void*), so that launches are ordered with the caller's own work on
+ * it (zeroing a bound tally buffer, an RCCL all-reduce of it).  NULL is a stream like any other: HIP's null stream,
+ * which is what torch.cuda.current_stream() is unless the caller changed it.  i3rc_hip_use_own_stream goes back to
+ * the private non-blocking stream every handle starts with. */
 int i3rc_hip_set_stream(i3rc_hip_integrator *h, void *hipStream);
+int i3rc_hip_use_own_stream(i3rc_hip_integrator *h);
 
 /* computeRadiativeTransfer :296-309: zero all tallies and counters (asynchronous on the stream). */
 int i3rc_hip_zero_tallies(i3rc_hip_integrator *h);

@@ -149,3 +149,36 @@ def test_max_cross_section_mode_matches_oracle(oracle):
     o = make_oracle(oracle, d, [hg_table().inverse_table(9001)])
     o.specify(useRayTracing=0, surfaceAlbedo=0.1)
     _parity(oracle, g, o, 8, 20000, 0.9)
+
+
+def test_bound_tally_buffer_follows_the_callers_stream():
+    # bench.py / multigpu.py pattern: tallies accumulate in a caller-owned device buffer (a torch tensor that RCCL
+    # all-reduces) and launches run on the caller's stream, so "zero the buffer, launch, zero, launch" without any
+    # host synchronisation must leave exactly the last launch's tallies (a kernel on another stream would race with
+    # the zeroing; that bug showed as fluxes 2x too large)
+    import torch
+    from i3rc_monte_carlo_model_amd import binding as B
+
+    d = cases.step_cloud(nlayers=16)
+    g = make_gpu(d, hg_table())
+    n = 2_000_000
+    ref = g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 2)), M.new_PhotonStream(1.0, 0.0, n))
+    lay = g.layout()
+    tally = torch.zeros(lay.total, dtype=torch.float64, device="cuda")
+    lib = B.load()
+    for stream in (torch.cuda.current_stream(), torch.cuda.Stream()):    # the null stream and a created one
+        assert lib.i3rc_hip_bind_tally_buffer(g._h, tally.data_ptr(), tally.numel() * 8) == 0
+        assert lib.i3rc_hip_set_stream(g._h, stream.cuda_stream) == 0
+        with torch.cuda.stream(stream):
+            for batch in (1, 2):
+                tally.zero_()
+                g.launch(M.new_RandomNumberSequence((10, batch)), M.new_PhotonStream(1.0, 0.0, n), zero=False)
+            doubled = tally * 2          # more work of the caller's on the same stream, ordered after the kernel
+        stream.synchronize()
+        r = g.finish(tally.cpu().numpy())
+        assert r["counters"] == ref["counters"]
+        assert np.allclose(r["raw"], ref["raw"], rtol=1e-6, atol=1e-6)
+        assert torch.equal(doubled, tally * 2)
+    assert lib.i3rc_hip_bind_tally_buffer(g._h, None, 0) == 0 and lib.i3rc_hip_use_own_stream(g._h) == 0
+    again = g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 2)), M.new_PhotonStream(1.0, 0.0, n))
+    assert again["counters"] == ref["counters"]
