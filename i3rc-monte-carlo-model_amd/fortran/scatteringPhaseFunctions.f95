@@ -279,8 +279,15 @@ contains
     end do
     thisCopy%key(:) = original%key(:)
     thisCopy%description = original%description
-    ! every copied entry owns its angle grid, so the copy is a "general" table even if the original shared one
-    thisCopy%oneAngleSet = .false.
+    ! a table whose entries share one angle grid stays such a table (only those can be written to files): the copies
+    ! of entries 2... give up their own grid and alias the copy of entry 1's, as in the original
+    thisCopy%oneAngleSet = original%oneAngleSet
+    if(thisCopy%oneAngleSet) then
+      do i = 2, size(thisCopy%phaseFunctions)
+        if(associated(thisCopy%phaseFunctions(i)%scatteringAngle)) deallocate(thisCopy%phaseFunctions(i)%scatteringAngle)
+        thisCopy%phaseFunctions(i)%scatteringAngle => thisCopy%phaseFunctions(1)%scatteringAngle
+      end do
+    end if
   end function copy_PhaseFunctionTable
 
   subroutine finalize_PhaseFunction(phaseFunctionVar)

@@ -104,13 +104,13 @@ def landsat_cloud(ssa=1.0, nlayers=119):
     ny, nx = tau.shape
     if nlayers == 119:
         dzl = f32(20.0)
-        nfill = np.rint(thick / dzl).astype(np.int64)
+        nfill = np.floor(thick / dzl + f32(0.5)).astype(np.int64)   # Fortran nint(): halves away from zero (np.rint: to even)
         with np.errstate(all="ignore"):
             e = np.where(tau > np.finfo(np.float32).tiny, tau / (nfill.astype(np.float32) * dzl), f32(0.0)).astype(np.float32)
         ze = dzl * np.arange(0, nlayers + 1, dtype=np.float32) + f32(200.0)
     else:
         dzl = f32(2380.0) / f32(nlayers)
-        nfill = np.where(tau > 0, np.maximum(1, np.rint(thick / dzl).astype(np.int64)), 0)
+        nfill = np.where(tau > 0, np.maximum(1, np.floor(thick / dzl + f32(0.5)).astype(np.int64)), 0)
         with np.errstate(all="ignore"):
             e = np.where(tau > 0, tau / (nfill.astype(np.float32) * dzl), f32(0.0)).astype(np.float32)
         ze = (dzl * np.arange(0, nlayers + 1, dtype=np.float32) + f32(200.0)).astype(np.float32)

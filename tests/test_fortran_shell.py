@@ -80,6 +80,112 @@ def test_netcdf_classic_files_are_readable_by_an_independent_reader(shell_built,
     assert np.allclose(f.variables["x-Edges"].data, np.arange(33) * 15.625)
 
 
+def _write_i3rc_data_files(directory):
+    """The I3RC phase-1 input data (tests/golden/i3rc_phase1_inputs.npz) as text files in the case definition's own
+    formats, for the Fortran case generators."""
+    inp = np.load(os.path.join(ROOT, "tests", "golden", "i3rc_phase1_inputs.npz"))
+    with open(os.path.join(directory, "mmcr_tau_32km_020898"), "w") as f:
+        for row in inp["mmcr_tau"]:
+            f.write("".join("%8.3f" % v for v in row) + "\n")
+    for name, key, fmt in (("scene43.tau.128x128", "landsat_tau", "%7.2f"), ("scene43.dz.128x128", "landsat_dz_km", "%7.3f")):
+        with open(os.path.join(directory, name), "w") as f:
+            for row in inp[key]:
+                f.write("".join(fmt % v for v in row) + "\n")
+    with open(os.path.join(directory, "C.1_PF"), "w") as f:
+        for a, v in zip(inp["c1_angle_deg"], inp["c1_value"]):
+            f.write("%7.1f   %.7E\n" % (a, v))
+    with open(os.path.join(directory, "C.1_leg_coef"), "w") as f:
+        for v in inp["c1_legendre"]:
+            f.write("   %.7g\n" % v)
+    return inp
+
+
+def test_i3rc_case_generators_write_the_case_definitions(shell_built, tmp_path):
+    # Fortran tools (SURVEY.md 8f row 4): radar and Landsat domains from the I3RC data files, compared with the
+    # numpy recipes the GPU parity tests use (tests/cases.py) -- two independent statements of the same recipe
+    from scipy.io import netcdf_file
+    from tests import cases
+
+    inp = _write_i3rc_data_files(str(tmp_path))
+    dom = str(tmp_path / "radar.dom")
+    r = _run([os.path.join(shell_built, "makeRadarCloudDomain"), str(tmp_path), dom, "0.99", "hg"])
+    assert r.returncode == 0 and "mean column optical depth" in r.stdout, r.stdout + r.stderr
+    assert os.path.exists(dom), (r.stdout, os.listdir(str(tmp_path)))
+    f = netcdf_file(dom, "r", mmap=False)
+    want = cases.radar_cloud(ssa=0.99)
+    assert np.array_equal(f.variables["Component1_Extinction"].data, want["ext"])
+    assert np.array_equal(f.variables["x-Edges"].data, want["xe"]) and np.array_equal(f.variables["z-Edges"].data, want["ze"])
+    assert np.allclose(f.variables["Component1_SingleScatteringAlbedo"].data, 0.99)
+    coef = f.variables["Component1_legendreCoefficients"].data
+    assert coef.shape == (299,) and abs(coef[0] - 0.85) < 1e-7
+    tau_mean = float(r.stdout.split("optical depth")[1].split(",")[0])
+    assert abs(tau_mean - inp["mmcr_tau"].sum() / 640) < 2e-3          # SURVEY.md 8d: mean column optical depth 19.5
+    # the tabulated C1 phase function travels as angle / value pairs, the expanded one as Legendre coefficients
+    r = _run([os.path.join(shell_built, "makeRadarCloudDomain"), str(tmp_path), dom, "1.0", "c1"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    f = netcdf_file(dom, "r", mmap=False)
+    assert f.Component1_phaseFunctionStorageType == b"Angle-Value"
+    ang, val = cases.c1_phase_function()
+    assert np.allclose(f.variables["Component1_scatteringAngle"].data, ang, rtol=1e-6)
+    stored = f.variables["Component1_phaseFunctionValues"].data.ravel()
+    assert stored.shape == (1801,) and np.allclose(stored / stored[0], val / val[0], rtol=2e-6)   # normalised on construction
+    r = _run([os.path.join(shell_built, "makeRadarCloudDomain"), str(tmp_path), dom, "1.0", "c1legendre"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    f = netcdf_file(dom, "r", mmap=False)
+    coef = f.variables["Component1_legendreCoefficients"].data
+    assert coef.shape == (299,) and np.allclose(coef[:3], inp["c1_legendre"][1:4] / np.array([3, 5, 7]), rtol=1e-6)
+    # Landsat scene: the reference's 119 layers and the labelled 36-layer re-binning
+    for nl in (119, 36):
+        dom = str(tmp_path / f"landsat{nl}.dom")
+        r = _run([os.path.join(shell_built, "makeLandsatCloudDomain"), str(tmp_path), dom, "1.0", str(nl)])
+        assert r.returncode == 0, r.stdout + r.stderr
+        f = netcdf_file(dom, "r", mmap=False)
+        want = cases.landsat_cloud(nlayers=nl)
+        ext = f.variables["Component1_Extinction"].data
+        assert ext.shape == (nl, 128, 128)
+        assert np.array_equal(ext > 0, want["ext"] > 0) and np.allclose(ext, want["ext"], rtol=3e-7, atol=0)
+        assert np.allclose(f.variables["z-Edges"].data, want["ze"], rtol=1e-6)
+        pfi = f.variables["Component1_PhaseFunctionIndex"].data
+        assert np.array_equal(pfi == 1, ext > 0) and np.array_equal(pfi == 0, ext == 0)
+        tau_mean = float(r.stdout.split("optical depth")[1].split(",")[0])
+        assert abs(tau_mean - inp["landsat_tau"].mean()) < 2e-3       # SURVEY.md 8d: mean column optical depth 10.06
+
+
+def test_optical_properties_to_domain_importer(shell_built, tmp_path):
+    # SHDOM-like ASCII property file -> domain file (Tools/OpticalPropertiesToDomain.readme:27-65)
+    from scipy.io import netcdf_file
+
+    g1, g2 = 0.85, 0.6
+    chi1 = [(2 * l + 1) * g1**l for l in range(1, 9)]
+    chi2 = [(2 * l + 1) * g2**l for l in range(1, 5)]
+    prp = tmp_path / "field.prp"
+    lines = ["Tabulated phase function property file", "2 1 3", "100. 250.  0. 50. 150. 400.", "2",
+             "8 " + " ".join("%.7f" % c for c in chi1[:5]), " ".join("%.7f" % c for c in chi1[5:]),   # entry continues on the next line
+             "4 " + " ".join("%.7f" % c for c in chi2)]
+    cells = [(1, 1, 1, 280.0, 0.01, 1.0, 1), (2, 1, 1, 280.0, 0.02, 0.9, 2), (2, 1, 3, 270.0, 0.005, 1.0, 1)]
+    lines += ["%d %d %d %.1f %.5f %.3f %d" % c for c in cells]
+    prp.write_text("\n".join(lines) + "\n")
+    out = tmp_path / "field.dom"
+    nml = tmp_path / "convert.nml"
+    nml.write_text(f"&fileNames\n  PropFileName = '{prp}',\n  outputFileName = '{out}'\n/\n")
+    r = _run([os.path.join(shell_built, "opticalPropertiesToDomain"), str(nml)])
+    assert r.returncode == 0 and "3 cells listed, 2 phase functions" in r.stdout, r.stdout + r.stderr
+    f = netcdf_file(str(out), "r", mmap=False)
+    ext = f.variables["Component1_Extinction"].data            # (z, y, x)
+    assert ext.shape == (3, 1, 2)
+    assert np.allclose(ext[0, 0], [0.01, 0.02]) and ext[1].max() == 0 and np.allclose(ext[2, 0], [0, 0.005])
+    assert np.allclose(f.variables["Component1_SingleScatteringAlbedo"].data[0, 0], [1.0, 0.9])
+    assert list(f.variables["Component1_PhaseFunctionIndex"].data[0, 0]) == [1, 2]
+    assert np.allclose(f.variables["z-Edges"].data, [0, 50, 150, 400]) and np.allclose(f.variables["x-Edges"].data, [0, 100, 200])
+    start, length = f.variables["Component1_start"].data, f.variables["Component1_length"].data
+    coef = f.variables["Component1_legendreCoefficients"].data
+    assert list(length) == [8, 4] and list(start) == [1, 9]
+    assert np.allclose(coef[:8], [g1**l for l in range(1, 9)], rtol=1e-5) and np.allclose(coef[8:], [g2**l for l in range(1, 5)], rtol=1e-5)
+    # a bad index is refused
+    prp.write_text("\n".join(lines[:7] + ["3 1 1 280. 0.01 1.0 1"]) + "\n")
+    assert _run([os.path.join(shell_built, "opticalPropertiesToDomain"), str(nml)]).returncode != 0
+
+
 @pytest.mark.skipif(not HAVE_REF, reason="reference tree not present (GPU box)")
 def test_reference_drivers_link_unchanged(shell_built):
     # drop-in boundary: the reference's own driver sources, compiled in place, link against the shell
@@ -207,3 +313,46 @@ def test_reference_drivers_run_unchanged_on_gpu(tmp_path):
     f = netcdf_file(str(out / "stepCloud_results.nc"), "r", mmap=False)
     assert f.variables["fluxUp"].data.shape == (1, 32) and f.variables["intensity"].data.shape == (1, 1, 32)
     assert abs(f.variables["fluxUp"].data.mean() - fup) < 1e-3
+
+
+@pytest.mark.gpu
+def test_generated_case_domains_run_through_the_driver_on_gpu(tmp_path):
+    # case generator -> domain file -> read_Domain -> i3rcDriver on the GPU, against the Python host path on the numpy
+    # statement of the same case (Landsat scene re-binned to 36 layers: clear cells carry phase function index 0)
+    import i3rc_monte_carlo_model_amd as M
+    from tests import cases
+
+    gen, drv = os.path.join(BUILD, "makeLandsatCloudDomain"), os.path.join(BUILD, "i3rcDriver")
+    if not (os.path.exists(gen) and os.path.exists(drv)):
+        pytest.skip("Fortran shell not built")
+    _write_i3rc_data_files(str(tmp_path))
+    dom = str(tmp_path / "landsat36.dom")
+    assert _run([gen, str(tmp_path), dom, "0.99", "36"]).returncode == 0 and os.path.exists(dom)
+    nml = tmp_path / "landsat.nml"
+    nml.write_text(f"""&radiativeTransfer
+  solarFlux = 1., solarMu = 0.5, solarAzimuth = 30., surfaceAlbedo = 0.2 /
+&monteCarlo
+  numPhotonsPerBatch = 200000, numBatches = 10, iseed = 7, nPhaseIntervals = 10001 /
+&algorithms
+  useRayTracing = .true., useRussianRoulette = .true. /
+&output
+  reportVolumeAbsorption = .false., reportAbsorptionProfile = .true. /
+&fileNames
+  domainFileName = "{dom}", outputFluxFile = "{tmp_path}/flux.txt", outputAbsProfFile = "{tmp_path}/prof.txt" /
+""")
+    r = _run([drv, str(nml)], cwd=ROOT)
+    assert r.returncode == 0 and "Wrote ASCII results" in r.stdout, r.stdout + r.stderr
+    m = re.search(r"Average:\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)", open(str(tmp_path / "flux.txt")).read())
+    fup, eup, fdn, edn, fab, eab = map(float, m.groups())
+    d = cases.landsat_cloud(ssa=0.99, nlayers=36)
+    dm = M.new_Domain(d["xe"], d["ye"], d["ze"])
+    dm.addOpticalComponent("cloud", d["ext"], d["ssa"], np.maximum(d["pf"], 1), M.PhaseFunctionTable([M.henyey_greenstein(0.85, 299)]))
+    g = M.new_Integrator(dm)
+    g.specifyParameters(surfaceAlbedo=0.2, minInverseTableSize=10001)
+    ups, dns, abss = [], [], []
+    for b in range(1, 11):   # the driver's batches: seed (iseed, batch), so the two runs trace the same photons
+        res = g.computeRadiativeTransfer(M.new_RandomNumberSequence((7, b)), M.new_PhotonStream(0.5, 30.0, 200000))
+        ups.append(res["fluxUp"].mean()); dns.append(res["fluxDown"].mean()); abss.append(res["fluxAbsorbed"].mean())
+    # solarFlux = 1 and the same photons: the means agree to the 4 decimals the flux file prints
+    assert abs(fup - np.mean(ups)) < 2e-4 and abs(fdn - np.mean(dns)) < 2e-4 and abs(fab - np.mean(abss)) < 2e-4
+    assert abs(eup - np.std(ups, ddof=1) / np.sqrt(10)) < 2e-4
