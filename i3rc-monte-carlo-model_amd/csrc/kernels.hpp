@@ -85,7 +85,7 @@ __device__ __forceinline__ void intensity_contribution(const DevProblem &P, cons
       if (fabsf(proj) > 1.0f) proj = copysignf(1.0f, proj);
       const float ang = acosf(proj);
       const size_t ncell = ncol * P.nz;
-      const int pfi = P.pfIndex[(size_t)(component - 1) * ncell + cell_index(P, ix, iy, iz)];
+      const int pfi = max(P.pfIndex[(size_t)(component - 1) * ncell + cell_index(P, ix, iy, iz)], 1);
       const CompTables ct = P.comp[component - 1];
       const int n = ct.nFwd;
       const float *tab = ((P.useHybrid && order <= P.numOrdersOrig) ? ct.fwdOrig : ct.fwd) + (size_t)(pfi - 1) * n;
@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
               }
               int pfi;
               if (!GENERAL && P.uniformPf >= 1) pfi = P.uniformPf;
-              else pfi = P.pfIndex[(size_t)(comp - 1) * ncell + cell];
+              else pfi = max(P.pfIndex[(size_t)(comp - 1) * ncell + cell], 1);   // (index 0 marks clear cells: never a table offset of -1)
               if (defer) {                                                // :654-668, traced after this event
                 pendingShadow = true; wI = w;
                 lds_float *park = L.park + threadIdx.x;

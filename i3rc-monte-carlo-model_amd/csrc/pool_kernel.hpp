@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(256, 4) photon_pool_kernel(const DevProblem P,
           if (w <= kTiny) st = ST_NEW;
           else {
             int pfi;
-            if (P.uniformPf >= 1) pfi = P.uniformPf; else pfi = P.pfIndex[cell];
+            if (P.uniformPf >= 1) pfi = P.uniformPf; else pfi = max(P.pfIndex[cell], 1);
             const CompTables ct = P.comp0;
             const float cosS = scattering_cosine(rng.next(), ct.invCos + (size_t)(pfi - 1) * ct.nInv, ct.nInv,
                                                  refined_rcp((float)ct.nInv));
