@@ -1,0 +1,104 @@
+"""BASELINE.json configs[2..4] at test size (configs[1], the step cloud, is test_gpu_parity.py; the reference-exact
+radar 640 x 1 x 54 and Landsat 128 x 128 x 119 fields are test_gpu_features.py): the labelled synthetic shapes of
+SURVEY.md 8d, HIP path against the oracle on the same seeds / batch scheme, domain means within
+3 sqrt(se_gpu^2 + se_ref^2) (standard errors from the batch-to-batch variance, monteCarloDriver.f95:358-378)."""
+import numpy as np
+import pytest
+
+import i3rc_monte_carlo_model_amd as M
+from tests import cases
+from tests.test_gpu_parity import _batches_gpu, _batches_oracle, hg_table, make_gpu, make_oracle
+
+pytestmark = pytest.mark.gpu
+DIRS7_MU = [1.0, 0.5, 0.5, 0.8, 0.8, 0.3, 0.3]
+DIRS7_PHI = [0.0, 0.0, 180.0, 90.0, 270.0, 45.0, 225.0]
+
+
+def _means_agree(gr, orr, keys):
+    nb = len(gr)
+    for key in keys:
+        dg = np.array([r[key].mean(dtype=np.float64) for r in gr])
+        dr = np.array([r[key].mean(dtype=np.float64) for r in orr])
+        tol = 3.0 * np.sqrt(dg.var(ddof=1) / nb + dr.var(ddof=1) / nb) + 1e-6
+        assert abs(dg.mean() - dr.mean()) <= tol, (key, dg.mean(), dr.mean(), tol)
+
+
+def _two_stage(oracle, g, o, nb, n, mu0, keys, per_direction=False):
+    """As test_gpu_parity._parity: a first failure is re-examined once on an independent sample twice as large."""
+    def run(nbatches, iseed):
+        gr, orr = _batches_gpu(g, nbatches, n, mu0, iseed=iseed), _batches_oracle(oracle, o, nbatches, n, mu0, iseed=iseed)
+        _means_agree(gr, orr, keys)
+        if per_direction:   # every radiance direction on its own, not only their mean
+            nd = gr[0]["intensity"].shape[0]
+            for k in range(nd):
+                dg = np.array([r["intensity"][k].mean(dtype=np.float64) for r in gr])
+                dr = np.array([r["intensity"][k].mean(dtype=np.float64) for r in orr])
+                tol = 3.0 * np.sqrt(dg.var(ddof=1) / nbatches + dr.var(ddof=1) / nbatches) + 1e-6
+                assert abs(dg.mean() - dr.mean()) <= tol, ("intensity", k, dg.mean(), dr.mean(), tol)
+        return gr, orr
+    try:
+        return run(nb, 10)
+    except AssertionError as first:
+        try:
+            return run(2 * nb, 11)
+        except AssertionError as second:
+            raise AssertionError(f"failed twice: {first.args} then {second.args}")
+
+
+def test_config2_radar_64x64x54_flux_and_nadir_radiance(oracle):
+    d = cases.radar_cloud_64()
+    tab = hg_table(0.85, 299)
+    inv, fwd = tab.inverse_table(10001), tab.forward_table(10001)
+    g = make_gpu(d, tab, intensityMus=[1.0], intensityPhis=[0.0], useRussianRouletteForIntensity=True, zetaMin=0.3)
+    g.set_tables(1, inverse=inv, forward=fwd, forward_orig=fwd)
+    o = make_oracle(oracle, d, [inv], [fwd], [fwd])
+    o.specify(intensityMus=[1.0], intensityPhis=[0.0], useRRForIntensity=1, zetaMin=0.3)
+    gr, orr = _two_stage(oracle, g, o, 8, 25000, 1.0, ("fluxUp", "fluxDown", "intensity"))
+    # dropped-photon deficit (quirk Q4) is part of the result: same rate on both sides
+    n = 25000 * len(gr)
+    dg, do = sum(r["counters"]["dropped"] for r in gr) / n, sum(r["nBad"] for r in orr) / n
+    assert abs(dg - do) < 3 * np.sqrt((do + 1e-5) / n) + 2e-4
+    # the nadir radiance field has the field's structure: brighter over the thick columns
+    tau = d["ext"].sum(0) * 45.0
+    inten = np.stack([r["intensity"][0] for r in gr]).mean(0)
+    assert inten[tau > np.median(tau)].mean() > inten[tau <= np.median(tau)].mean()
+
+
+def test_config3_landsat_128x128x36_flux(oracle):
+    d = cases.landsat_cloud(nlayers=36)
+    tab = hg_table(0.85, 299)
+    inv = tab.inverse_table(10001)
+    g = make_gpu(d, tab)
+    g.set_tables(1, inverse=inv)
+    o = make_oracle(oracle, d, [inv])
+    gr, orr = _two_stage(oracle, g, o, 4, 40000, 1.0, ("fluxUp", "fluxDown"))
+    r0 = gr[0]   # black surface, no absorption: every photon is tallied once or dropped by the tracer
+    closure = r0["fluxUp"].mean(dtype=np.float64) + r0["fluxDown"].mean(dtype=np.float64)
+    assert abs(closure - (1 - r0["counters"]["dropped"] / 40000)) < 2e-6
+    # sharding the batch over 8 ranks by photon range (multigpu.shard_photons) and summing the raw tallies is the
+    # same computation: BASELINE.json runs this case on 8 GPUs
+    from i3rc_monte_carlo_model_amd import multigpu
+    raw = np.zeros_like(r0["raw"])
+    for rank in range(8):
+        first, count = multigpu.shard_photons(40000, 8, rank)
+        g.launch(M.new_RandomNumberSequence((10, 1)), M.new_PhotonStream(1.0, 0.0, count), firstPhoton=first)
+        raw += g.fetch()
+    lay = g.layout()
+    assert np.array_equal(raw[lay.counters:lay.counters + 10], r0["raw"][lay.counters:lay.counters + 10])
+    assert np.allclose(raw, r0["raw"], rtol=1e-9, atol=1e-9)
+
+
+def test_config4_landsat_seven_radiances_lambertian_surface_object(oracle):
+    d = cases.landsat_cloud()
+    tab = hg_table(0.85, 299)
+    inv, fwd = tab.inverse_table(10001), tab.forward_table(10001)
+    g = make_gpu(d, tab, intensityMus=DIRS7_MU, intensityPhis=DIRS7_PHI, useRussianRouletteForIntensity=True, zetaMin=0.3,
+                 surfaceBDRF=M.new_SurfaceDescription([0.2]))
+    g.set_tables(1, inverse=inv, forward=fwd, forward_orig=fwd)
+    o = make_oracle(oracle, d, [inv], [fwd], [fwd])
+    o.specify(intensityMus=DIRS7_MU, intensityPhis=DIRS7_PHI, useRRForIntensity=1, zetaMin=0.3,
+              surfaceBDRF=(np.array([0.0, np.finfo(np.float32).max], np.float32), np.array([0.0, np.finfo(np.float32).max], np.float32),
+                           np.array([[0.2]], np.float32)))
+    gr, orr = _two_stage(oracle, g, o, 8, 10000, 0.5, ("fluxUp", "fluxDown", "intensity"), per_direction=True)
+    sh = sum(r["counters"]["shadowSteps"] for r in gr) / (10000 * len(gr))
+    assert sh > 1500   # ~3200 cell steps per photon, almost all of them shadow rays
