@@ -45,6 +45,8 @@ struct i3rc_hip_integrator {
   int nx = 0, ny = 0, nz = 0, ncomp = 0;
   std::vector<float> xE, yE, zE;  // host copies (normalisation, checks)
   DevBuf dxE, dyE, dzE, dExt, dCum, dSsa, dPf;
+  DevBuf dExtBrick;              // totalExt in bricks of 32 cells (DevProblem::extBrick)
+  int bsx = 0, bsy = 0, bsz = 0, nbx = 0, nby = 0, nbz = 0;
   DevBuf dInv[I3RC_MAX_COMPONENTS], dInvCos[I3RC_MAX_COMPONENTS], dFwd[I3RC_MAX_COMPONENTS], dFwdOrig[I3RC_MAX_COMPONENTS];
   CompTables comp[I3RC_MAX_COMPONENTS] = {};
   int nInvEntries[I3RC_MAX_COMPONENTS] = {}, nFwdEntries[I3RC_MAX_COMPONENTS] = {};
@@ -182,6 +184,30 @@ int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int n
   CCHK(h->dyE.upload(yEdges, sizeof(float) * (ny + 1)));
   CCHK(h->dzE.upload(zEdges, sizeof(float) * (nz + 1)));
   CCHK(h->dExt.upload(totalExt, sizeof(float) * ncell));
+  {
+    // bricks of 32 cells: 8 deep where the grid has the layers for it (photon paths and shadow rays cross z faces
+    // most often in cloud fields, whose cells are flatter than wide), the rest shared by x and y
+    auto log2le = [](int n, int cap) { int s = 0; while ((2 << s) <= n && s + 1 <= cap) ++s; return s; };
+    h->bsz = log2le(nz, 3);
+    h->bsy = log2le(ny, (5 - h->bsz) / 2);
+    h->bsx = 5 - h->bsz - h->bsy;
+    h->nbx = (nx + (1 << h->bsx) - 1) >> h->bsx; h->nby = (ny + (1 << h->bsy) - 1) >> h->bsy; h->nbz = (nz + (1 << h->bsz) - 1) >> h->bsz;
+    if ((int64_t)h->nbx * h->nby >= ((int64_t)1 << 24) || (int64_t)h->nbx * h->nby * h->nbz >= ((int64_t)1 << 26)) {
+      g_createError = "i3rc_hip_create: domain too large for the bricked extinction copy";
+      delete h;
+      return 1;
+    }
+    std::vector<float> brick((size_t)h->nbx * h->nby * h->nbz * 32, 0.0f);
+    for (int k = 0; k < nz; ++k)
+      for (int j = 0; j < ny; ++j)
+        for (int i = 0; i < nx; ++i) {
+          const size_t b = ((size_t)(k >> h->bsz) * h->nby + (size_t)(j >> h->bsy)) * h->nbx + (size_t)(i >> h->bsx);
+          const size_t w = ((size_t)(k & ((1 << h->bsz) - 1)) << (h->bsx + h->bsy)) | ((size_t)(j & ((1 << h->bsy) - 1)) << h->bsx) |
+                           (size_t)(i & ((1 << h->bsx) - 1));
+          brick[b * 32 + w] = totalExt[((size_t)k * ny + j) * nx + i];
+        }
+    CCHK(h->dExtBrick.upload(brick.data(), sizeof(float) * brick.size()));
+  }
   CCHK(h->dCum.upload(cumExt, sizeof(float) * ncell * ncomp));
   CCHK(h->dSsa.upload(ssa, sizeof(float) * ncell * ncomp));
   CCHK(h->dPf.upload(pfIndex, sizeof(int32_t) * ncell * ncomp));
@@ -406,6 +432,8 @@ bool common_class(const i3rc_hip_integrator *h, int srcKind) {
   return h->xyRegular && h->zRegular && h->params.useRayTracing && !gridSurface && h->ncomp == 1 && srcKind == 0;
 }
 
+size_t ncell_bytes(const i3rc_hip_integrator *h) { return sizeof(float) * (size_t)h->nx * h->ny * h->nz; }
+
 int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool wantPool = false) {
   DevProblem &P = plan.P;
   std::memset(&P, 0, sizeof(P));
@@ -421,6 +449,9 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool wantPool = false
   P.z0 = h->zE.front(); P.zMax = h->zE.back();
   P.deltaX = h->xE[1] - h->xE[0]; P.deltaY = h->yE[1] - h->yE[0]; P.deltaZ = h->zE[1] - h->zE[0];
   P.xE = (const float *)h->dxE.p; P.yE = (const float *)h->dyE.p; P.zE = (const float *)h->dzE.p;
+  // bricks pay off once the field no longer fits in one XCD's 4 MB of L2
+  P.extBrick = (ncell_bytes(h) > ((size_t)4 << 20)) ? (const float *)h->dExtBrick.p : nullptr;
+  P.bsx = h->bsx; P.bsy = h->bsy; P.bsz = h->bsz; P.nbx = h->nbx; P.nbxy = h->nbx * h->nby;
   P.totalExt = (const float *)h->dExt.p; P.cumExt = (const float *)h->dCum.p; P.ssa = (const float *)h->dSsa.p;
   P.pfIndex = (const int32_t *)h->dPf.p;
   if (hipMemcpyAsync(h->dComp.p, h->comp, sizeof(CompTables) * I3RC_MAX_COMPONENTS, hipMemcpyHostToDevice, h->stream) != hipSuccess)
@@ -497,8 +528,14 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
   // fast specialisations when the problem is in the common class (see photon_kernel), else the general kernel
   const bool simple = !Rng::kReplay && common_class(h, A.srcKind) && h->kernelVariant != I3RC_KERNEL_GENERAL;
   const bool pool = simple && plan.pool;
-  auto kern = plan.intensity ? (simple ? photon_kernel<Rng, true, false> : photon_kernel<Rng, true, true>)
-                             : (simple ? photon_kernel<Rng, false, false> : photon_kernel<Rng, false, true>);
+  // the specialised kernels exist once per place of the extinction grid (LDS / global / global in bricks)
+  using Kernel = void (*)(DevProblem, RunArgs, int, int);
+  const int place = plan.P.ldsGrid ? GRID_LDS : (plan.P.extBrick ? GRID_BRICKS : GRID_GLOBAL);
+  static const Kernel special[2][3] = {
+      {photon_kernel<Rng, false, false, GRID_LDS>, photon_kernel<Rng, false, false, GRID_GLOBAL>, photon_kernel<Rng, false, false, GRID_BRICKS>},
+      {photon_kernel<Rng, true, false, GRID_LDS>, photon_kernel<Rng, true, false, GRID_GLOBAL>, photon_kernel<Rng, true, false, GRID_BRICKS>}};
+  Kernel kern = simple ? special[plan.intensity ? 1 : 0][place]
+                       : (plan.intensity ? photon_kernel<Rng, true, true, GRID_ANY> : photon_kernel<Rng, false, true, GRID_ANY>);
   const void *fn = pool ? (const void *)photon_pool_kernel : (const void *)kern;
   int perCU = h->blocksPerCU;
   if (perCU <= 0) {
@@ -613,6 +650,7 @@ int i3rc_hip_trace_rays(i3rc_hip_integrator *h, int64_t n, const float *dir, flo
   std::memcpy(h->comp, saved, sizeof(saved));
   if (rc) return 1;
   plan.P.ldsGrid = 0; plan.P.ldsTallies = 0;
+  plan.P.extBrick = (const float *)h->dExtBrick.p;   // the test hook always reads the bricked copy (its index is checked bit for bit)
   DevBuf dDir, dPos, dIdx, dTar, dTau, dSteps;
   HIPCHK(h, dDir.upload(dir, sizeof(float) * 3 * n)); HIPCHK(h, dPos.upload(pos, sizeof(float) * 3 * n));
   HIPCHK(h, dIdx.upload(idx, sizeof(int32_t) * 3 * n)); HIPCHK(h, dTar.upload(target, sizeof(float) * n));

@@ -169,7 +169,7 @@ struct Reservoir {
 // re-wrapping loops, max-cross-section moves, BRDF lookups, component selection) are compiled out, which shrinks the
 // loop's code and its scalar-register pressure.  GENERAL = true keeps every path behind run-time switches.
 // (the general radiance kernel keeps the most state live: 4 waves per SIMD give it 128 vector registers and no spills)
-template <class Rng, bool INTENSITY, bool GENERAL>
+template <class Rng, bool INTENSITY, bool GENERAL, int GRID = GRID_ANY>
 __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAVES) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
   for (int i = threadIdx.x; i <= P.nz; i += blockDim.x) L.zE[i] = P.zE[i];
   if (P.ldsTallies)
     for (int i = threadIdx.x; i < 3 * P.nx * P.ny; i += blockDim.x) L.tUp[i] = 0.0f;
-  if (P.ldsGrid) {
+  if (GRID == GRID_ANY ? (P.ldsGrid != 0) : GRID == GRID_LDS) {
     const int ncell = P.nx * P.ny * P.nz;
     for (int i = threadIdx.x; i < ncell; i += blockDim.x) L.ext[i] = P.totalExt[i];
   }
@@ -496,8 +496,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
             if (scatterThis) {
               order++;
               didScatter = true;
-              float extHere;
-              if (P.ldsGrid) extHere = L.ext[cell]; else extHere = P.totalExt[cell];
+              const float extHere = cell_extinction<GRID>(P, L, r.ix, r.iy, r.iz);
               if (extHere <= 0.0f) {                                      // :606-632 (quirk Q2 kept)
                 if (r.x - L.xE[r.ix - 1] <= 0.0f && r.dx > 0.0f) {
                   r.x = r.x - spacingf(r.x);
@@ -598,7 +597,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
     wc.steps += count_lanes(own);
     if (DEFER) wc.shadow += count_lanes(shadowRay);
     if (own || shadowRay) {
-      const StepResult s = trace_step(P, L, r, own || stage != 0);
+      const StepResult s = trace_step<GRID>(P, L, r, own || stage != 0);
       if (s == STEP_DONE) st = own ? ST_EVENT : ST_LIGHT;
       else if (s == STEP_ERROR) st = own ? ST_DROPPED : ST_LIGHT;   // a failed shadow ray contributes nothing (:1531-1535)
     }

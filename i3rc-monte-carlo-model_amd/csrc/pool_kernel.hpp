@@ -215,8 +215,7 @@ __global__ void __launch_bounds__(256, 4) photon_pool_kernel(const DevProblem P,
         } else {                                                        // :581-689
           didScatter = true;
           int cell = cell_index(P, ix, iy, iz);
-          float extHere;
-          if (P.ldsGrid) extHere = L.ext[cell]; else extHere = P.totalExt[cell];
+          const float extHere = cell_extinction(P, L, ix, iy, iz);
           if (extHere <= 0.0f) {                                        // :606-632 (quirk Q2 kept)
             x = ph[F_X * kPool]; y = ph[F_Y * kPool];
             movedXY = true;

@@ -1,9 +1,12 @@
 #!/bin/bash
 # Collect instruction-mix / stall counters of the photon kernel (separate PMC passes, kernel-trace only).
 # usage: tools/pmc_profile.sh <outdir-under-gpurun_out> [bench args]
+#        CASE=landsat tools/pmc_profile.sh <outdir>        profiles tools/run_case.py <CASE> instead of bench.py
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; shift
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+PROG=$R/bench.py
 ARGS="--steps 1 --warmup 0 --photons 20000000 --no-cpu-baseline $@"
+if [ -n "$CASE" ]; then PROG=$R/tools/run_case.py; ARGS="$CASE $@"; fi
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM" \
            "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" \
@@ -11,7 +14,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS_ATOMIC SQ_IFETCH SQ_INSTS_FLAT" \
            "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -- python3 $R/bench.py $ARGS > $OUT/p$i.json 2> $OUT/p$i.err
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -- python3 $PROG $ARGS > $OUT/p$i.json 2> $OUT/p$i.err
   echo "pass $i done"
 done
 python3 - <<PY
