@@ -559,7 +559,8 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
     // the mix events are a smaller share of the work and waiting for them costs more than a thinner event phase
     // (radar + 1 direction: 40 / 24 is 8 % faster than 24 / 8; Landsat + 7 directions: 24 / 8 is 34 % faster than 40 / 24)
     const bool manyRays = h->nDir >= 3;
-    const int evThreshold = h->evThreshold > 0 ? h->evThreshold : (manyRays ? 24 : 40);
+    // flux-only launches without a threshold of the caller's adapt it per wave, starting from 40 (negative = adaptive)
+    const int evThreshold = h->evThreshold > 0 ? h->evThreshold : (plan.intensity ? (manyRays ? 24 : 40) : -40);
     const int lightThreshold = h->lightThreshold > 0 ? h->lightThreshold : (manyRays ? 8 : 24);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), plan.ldsBytes, h->stream, plan.P, B, evThreshold, lightThreshold);
   }
