@@ -1,4 +1,6 @@
-"""Single-GPU throughput of the BASELINE.json configurations (bench.py measures configs[1] only)."""
+"""Single-GPU throughput of the BASELINE.json configurations (bench.py measures configs[1] only), at photon counts
+of the order BASELINE.json names per GPU (small launches are dominated by the ramp and tail of the persistent kernel:
+radar flux 6.8e8 photons/s at 2e7 photons, 1.0e9 at 1e8)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,17 +15,17 @@ hg64 = M.PhaseFunctionTable([M.henyey_greenstein(0.85, 64)])
 hg299 = M.PhaseFunctionTable([M.henyey_greenstein(0.85, 299)])
 dirs7 = dict(intensityMus=[1, .5, .5, .8, .8, .3, .3], intensityPhis=[0, 0, 180, 90, 270, 45, 225])
 runs = [
-  ("step cloud 32x1x16 flux", cases.step_cloud(nlayers=16), hg64, {}, 1.0, 50_000_000),
-  ("step cloud 32x1x32 flux", cases.step_cloud(nlayers=32), hg64, {}, 1.0, 50_000_000),
-  ("radar 640x1x54 flux", cases.radar_cloud(), hg299, {}, 1.0, 20_000_000),
+  ("step cloud 32x1x16 flux", cases.step_cloud(nlayers=16), hg64, {}, 1.0, 100_000_000),
+  ("step cloud 32x1x32 flux", cases.step_cloud(nlayers=32), hg64, {}, 1.0, 100_000_000),
+  ("radar 640x1x54 flux", cases.radar_cloud(), hg299, {}, 1.0, 100_000_000),
   ("radar 640x1x54 flux + nadir radiance (RR, zeta 0.3)", cases.radar_cloud(), hg299,
-     dict(intensityMus=[1.0], intensityPhis=[0.0], useRussianRouletteForIntensity=True, zetaMin=0.3), 1.0, 10_000_000),
+     dict(intensityMus=[1.0], intensityPhis=[0.0], useRussianRouletteForIntensity=True, zetaMin=0.3), 1.0, 50_000_000),
   ("radar-64 64x64x54 flux + nadir radiance", cases.radar_cloud_64(), hg299,
-     dict(intensityMus=[1.0], intensityPhis=[0.0], useRussianRouletteForIntensity=True, zetaMin=0.3), 1.0, 10_000_000),
-  ("landsat 128x128x119 flux mu0=1", cases.landsat_cloud(), hg299, {}, 1.0, 20_000_000),
-  ("landsat 128x128x36 flux mu0=1", cases.landsat_cloud(nlayers=36), hg299, {}, 1.0, 20_000_000),
+     dict(intensityMus=[1.0], intensityPhis=[0.0], useRussianRouletteForIntensity=True, zetaMin=0.3), 1.0, 50_000_000),
+  ("landsat 128x128x119 flux mu0=1", cases.landsat_cloud(), hg299, {}, 1.0, 100_000_000),
+  ("landsat 128x128x36 flux mu0=1", cases.landsat_cloud(nlayers=36), hg299, {}, 1.0, 100_000_000),
   ("landsat 128x128x119 + 7 radiances + Lambertian 0.2 (BRDF object), mu0=.5", cases.landsat_cloud(), hg299,
-     dict(surfaceBDRF=M.new_SurfaceDescription([0.2]), useRussianRouletteForIntensity=True, zetaMin=0.3, **dirs7), 0.5, 2_000_000),
+     dict(surfaceBDRF=M.new_SurfaceDescription([0.2]), useRussianRouletteForIntensity=True, zetaMin=0.3, **dirs7), 0.5, 20_000_000),
 ]
 for name, d, tab, kw, mu0, n in runs:
     g = build(d, tab, **kw)
