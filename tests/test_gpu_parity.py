@@ -359,3 +359,42 @@ def test_edge_cases_and_errors():
         g.computeRadiativeTransfer(M.new_RandomNumberSequence((1, 1)), s)
     g.finalize_Integrator()
     assert not g.isReady_Integrator()
+
+
+def test_step_cloud_at_1e8_photons_size_independent_properties(oracle):
+    # BASELINE.json configs[1] at its full size: 1e8 photons as 20 batches of 5e6 (float64 tallies: no 2^24
+    # saturation).  The oracle cannot follow to this size, so the checks are the ones that do not depend on it:
+    # exact bookkeeping per batch, the batch-to-batch scatter predicted by binomial statistics, and agreement with
+    # the oracle's (necessarily smaller) sample and with the reference's recorded 1e6-photon result within 3 sigma.
+    d = cases.step_cloud(nlayers=16)
+    tab = hg_table()
+    g = make_gpu(d, tab, minInverseTableSize=10001)
+    nb, n = 20, 5_000_000
+    ups, dns, drops = [], [], []
+    cols = np.zeros((1, 32))
+    for b in range(1, nb + 1):
+        r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, b)), M.new_PhotonStream(1.0, 0.0, n))
+        c = r["counters"]
+        assert c["photons"] == n and c["exitsTop"] + c["surfaceHits"] + c["dropped"] == n    # every photon ends once
+        up, dn = r["fluxUp"].mean(dtype=np.float64), r["fluxDown"].mean(dtype=np.float64)
+        assert abs(up + dn + c["dropped"] / n - 1.0) < 1e-6
+        assert abs(up * n - c["exitsTop"]) < 1e-3 * n ** 0.5 + 40     # unit weights: the flux tally counts photons (float32 file format)
+        ups.append(up); dns.append(dn); drops.append(c["dropped"] / n)
+        cols += r["fluxUp"].astype(np.float64)
+    ups, dns = np.array(ups), np.array(dns)
+    p = ups.mean()
+    expected_sd = np.sqrt(p * (1 - p) / n)          # a photon leaves through the top or it does not
+    assert 0.6 * expected_sd < ups.std(ddof=1) < 1.5 * expected_sd, (ups.std(ddof=1), expected_sd)
+    se = ups.std(ddof=1) / np.sqrt(nb)               # ~4.7e-5 at 1e8 photons
+    assert 3e-5 < se < 7e-5
+    # the reference's own 1e6-photon run: Fup 0.3254, Fdown 0.6746 (printed to 4 digits; its standard error 4.7e-4)
+    assert abs(p - 0.3254) < 3 * 4.7e-4 + 5e-5 and abs(dns.mean() - 0.6746) < 3 * 4.7e-4 + 5e-5
+    assert 1.5e-5 < np.mean(drops) < 4e-5            # quirk Q4: tracer drops, 2e-5...3e-5 on this case
+    # the oracle on 10 x 2e5 photons
+    o = make_oracle(oracle, d, [tab.inverse_table(10001)])
+    orr = _batches_oracle(oracle, o, 10, 200000, 1.0)
+    ou = np.array([r["fluxUp"].mean(dtype=np.float64) for r in orr])
+    assert abs(p - ou.mean()) < 3 * np.sqrt(se ** 2 + ou.var(ddof=1) / 10)
+    # per column: thin half (columns 1-16, optical depth 2) darker than the thick half (optical depth 18)
+    col = cols[0] / nb
+    assert col[:12].max() < col[20:].min()
