@@ -2,18 +2,20 @@
 //
 // Mapping (MI355X-first, not a port of the scalar Fortran loop nest):
 //   * one photon per LANE, 64 photons in flight per wavefront, persistent waves: a lane that loses its photon
-//     (exit, absorption, roulette, tracer drop) pulls the next photon index from a device-wide counter
-//     (the compiler aggregates the per-lane atomicAdd into one add per wave);
+//     (exit, absorption, roulette, tracer drop) gets the next photon index from the wave's reservoir, which is
+//     refilled from a device-wide counter with one returning atomic per <= 1024 photons;
 //   * the reference's three nested data-dependent loops (photon / order of scattering / voxel step,
-//     computeRT :452-691 + accumulateExtinctionAlongPath :1690-1806) are flattened into one loop with two
-//     phases: a cheap VOXEL-STEP phase executed by the lanes that are tracing and an EVENT phase (scatter,
-//     surface, exit + respawn, new optical depth) that only runs when a ballot says enough lanes are
-//     waiting for it (evThreshold), which keeps both phases well populated;
-//   * cell edges (and, when they fit, the extinction grid) are staged in LDS with coalesced loads;
-//     flux tallies are privatised per workgroup in LDS (ds_add_f32) and flushed once with float64
-//     atomics; large domains tally straight to HBM with float64 atomics;
-//   * per-photon Philox4x32-10 streams keyed by (seed, batch) make a photon's path independent of the
-//     launch geometry and of the number of GPUs.
+//     computeRT :452-691 + accumulateExtinctionAlongPath :1690-1806) are flattened into a lane state machine with
+//     ballot-gated phases: a VOXEL-STEP phase executed by the lanes that are tracing, an EVENT phase (exit tallies,
+//     next photon, one Philox block for the whole wave, scatter / surface / new photon, new optical depth) that runs
+//     when enough lanes wait for it, and for radiances a LIGHT phase: local-estimate (shadow) rays are traced by the
+//     same voxel-step phase while the photon's own state is parked in LDS;
+//   * cell edges (and, when they fit, the extinction grid) are staged in LDS with coalesced loads; grids beyond an
+//     XCD's L2 are read from a copy in 32-cell bricks; flux and radiance tallies are privatised per workgroup in LDS
+//     (ds_add_f32) and flushed once with float64 atomics; large domains tally straight to HBM with float64 atomics;
+//   * per-photon Philox4x32-10 streams keyed by (seed, batch) make a photon's path independent of the launch
+//     geometry, of every scheduling threshold and of the number of GPUs;
+//   * work counters live in scalar registers (advanced by s_bcnt1 of ballots in uniform control flow).
 #pragma once
 #include "tracer.hpp"
 

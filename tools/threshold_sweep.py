@@ -16,7 +16,7 @@ for name in sys.argv[1:]:
     g = M.new_Integrator(dom); g.specifyParameters(minInverseTableSize=10001)
     g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 0)), M.new_PhotonStream(1.0, 0.0, 100000))
     out = []
-    for thr in (0, 40, 0, 40, 24, 16):
+    for thr in (0, 8, 16, 24, 32, 40, 48):   # 0 = the per-wave adaptive default
         g.set_tuning(thr, 0)
         best = 0
         for rep in range(2):
