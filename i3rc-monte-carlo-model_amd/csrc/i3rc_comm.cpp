@@ -1,13 +1,20 @@
 // Process layer (include/i3rc_comm.h): one process per GPU, sums of host arrays over processes.
-//   backend rccl : ncclAllReduce(float, sum) over xGMI; bootstrap = ncclUniqueId passed through a file
+//   backend rccl : ncclAllReduce(float, sum) over xGMI
 //   backend shm  : POSIX shared memory + sense-reversing barrier (single node, CPU only; tests)
+// Bootstrap of either: rank 0 listens on MASTER_ADDR:MASTER_PORT (I3RC_COMM_PORT overrides the port) and sends every
+// other rank a small blob -- the ncclUniqueId, or the name of the shared-memory segment it has just created.  A TCP
+// rendezvous leaves nothing behind that a later run could mistake for its own (a file or a named segment would).
 #include "../../include/i3rc_comm.h"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <arpa/inet.h>
 #include <fcntl.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
 #include <sys/mman.h>
+#include <sys/socket.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -38,6 +45,72 @@ std::string env_str(const char *a, const char *dflt) {
   return v ? v : dflt;
 }
 
+// ---- rendezvous: rank 0 -> everyone, n bytes -----------------------------------------------------------------------
+int rendezvous_port() { return env_int("I3RC_COMM_PORT", "MASTER_PORT", 29500); }
+
+bool send_all(int fd, const void *buf, size_t n) {
+  const char *p = (const char *)buf;
+  while (n > 0) {
+    const ssize_t k = ::send(fd, p, n, MSG_NOSIGNAL);
+    if (k <= 0) return false;
+    p += k; n -= (size_t)k;
+  }
+  return true;
+}
+bool recv_all(int fd, void *buf, size_t n) {
+  char *p = (char *)buf;
+  while (n > 0) {
+    const ssize_t k = ::recv(fd, p, n, 0);
+    if (k <= 0) return false;
+    p += k; n -= (size_t)k;
+  }
+  return true;
+}
+
+int rendezvous_broadcast(void *blob, size_t n) {
+  const int port = rendezvous_port();
+  if (g_rank == 0) {
+    const int srv = ::socket(AF_INET, SOCK_STREAM, 0);
+    if (srv < 0) return fail("i3rc_comm_init: socket() failed");
+    int one = 1;
+    (void)setsockopt(srv, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+    sockaddr_in addr{};
+    addr.sin_family = AF_INET; addr.sin_addr.s_addr = htonl(INADDR_ANY); addr.sin_port = htons((uint16_t)port);
+    if (::bind(srv, (sockaddr *)&addr, sizeof(addr)) != 0 || ::listen(srv, g_size) != 0) {
+      ::close(srv);
+      return fail("i3rc_comm_init: cannot listen on port " + std::to_string(port) + " (MASTER_PORT / I3RC_COMM_PORT in use?)");
+    }
+    timeval tv{120, 0};                                   // a rank that never shows up must not hang the others for ever
+    (void)setsockopt(srv, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+    for (int peer = 1; peer < g_size; ++peer) {
+      const int fd = ::accept(srv, nullptr, nullptr);
+      if (fd < 0) { ::close(srv); return fail("i3rc_comm_init: timed out waiting for the other processes"); }
+      const bool ok = send_all(fd, blob, n);
+      ::close(fd);
+      if (!ok) { ::close(srv); return fail("i3rc_comm_init: sending the rendezvous blob failed"); }
+    }
+    ::close(srv);
+    return 0;
+  }
+  sockaddr_in addr{};
+  addr.sin_family = AF_INET; addr.sin_port = htons((uint16_t)port);
+  const std::string host = env_str("MASTER_ADDR", "127.0.0.1");
+  if (inet_pton(AF_INET, host.c_str(), &addr.sin_addr) != 1) return fail("i3rc_comm_init: MASTER_ADDR must be an IPv4 address");
+  for (int tries = 0; tries < 1200; ++tries) {             // up to 2 minutes for rank 0 to come up
+    const int fd = ::socket(AF_INET, SOCK_STREAM, 0);
+    if (fd < 0) return fail("i3rc_comm_init: socket() failed");
+    if (::connect(fd, (sockaddr *)&addr, sizeof(addr)) == 0) {
+      const bool ok = recv_all(fd, blob, n);
+      ::close(fd);
+      if (ok) return 0;
+      return fail("i3rc_comm_init: receiving the rendezvous blob failed");
+    }
+    ::close(fd);
+    std::this_thread::sleep_for(std::chrono::milliseconds(100));
+  }
+  return fail("i3rc_comm_init: timed out connecting to " + host + ":" + std::to_string(port));
+}
+
 // ---- rccl ---------------------------------------------------------------------------------------------------------
 ncclComm_t g_comm = nullptr;
 hipStream_t g_stream = nullptr;
@@ -49,27 +122,10 @@ int rccl_init() {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("i3rc_comm_init: no HIP device for the rccl backend");
   if (g_local >= ndev) return fail("i3rc_comm_init: LOCAL_RANK exceeds the number of GPUs of this node");
   if (hipSetDevice(g_local) != hipSuccess) return fail("i3rc_comm_init: hipSetDevice failed");
-  const std::string path = env_str("I3RC_COMM_DIR", "/dev/shm") + "/i3rc_nccl_" + env_str("MASTER_PORT", "29500") + ".id";
   ncclUniqueId id;
-  if (g_rank == 0) {
-    if (ncclGetUniqueId(&id) != ncclSuccess) return fail("i3rc_comm_init: ncclGetUniqueId failed");
-    const std::string tmp = path + ".tmp";
-    FILE *f = std::fopen(tmp.c_str(), "wb");
-    if (!f || std::fwrite(&id, sizeof(id), 1, f) != 1) return fail("i3rc_comm_init: cannot write " + tmp);
-    std::fclose(f);
-    if (std::rename(tmp.c_str(), path.c_str()) != 0) return fail("i3rc_comm_init: cannot publish " + path);
-  } else {
-    bool got = false;
-    for (int tries = 0; tries < 1200 && !got; ++tries) {   // up to 2 minutes
-      FILE *f = std::fopen(path.c_str(), "rb");
-      if (f) {
-        got = std::fread(&id, sizeof(id), 1, f) == 1;
-        std::fclose(f);
-      }
-      if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
-    }
-    if (!got) return fail("i3rc_comm_init: timed out waiting for " + path);
-  }
+  std::memset(&id, 0, sizeof(id));
+  if (g_rank == 0 && ncclGetUniqueId(&id) != ncclSuccess) return fail("i3rc_comm_init: ncclGetUniqueId failed");
+  if (rendezvous_broadcast(&id, sizeof(id))) return 1;
   if (ncclCommInitRank(&g_comm, g_size, id, g_rank) != ncclSuccess) return fail("i3rc_comm_init: ncclCommInitRank failed");
   if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return fail("i3rc_comm_init: stream");
   return 0;
@@ -119,21 +175,20 @@ int shm_barrier() {
 }
 
 int shm_init() {
-  g_shmName = "/i3rc_comm_" + env_str("MASTER_PORT", "29500");
   g_shmBytes = 4096 + sizeof(float) * (size_t)kSlotFloats * g_size;
+  char name[64] = {0};
   int fd = -1;
-  if (g_rank == 0) {
-    shm_unlink(g_shmName.c_str());
-    fd = shm_open(g_shmName.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-    if (fd < 0 || ftruncate(fd, (off_t)g_shmBytes) != 0) return fail("i3rc_comm_init: cannot create shared memory " + g_shmName);
-  } else {
-    for (int tries = 0; tries < 1200 && fd < 0; ++tries) {
-      fd = shm_open(g_shmName.c_str(), O_RDWR, 0600);
-      struct stat st;
-      if (fd >= 0 && (fstat(fd, &st) != 0 || (size_t)st.st_size < g_shmBytes)) { close(fd); fd = -1; }
-      if (fd < 0) std::this_thread::sleep_for(std::chrono::milliseconds(100));
-    }
-    if (fd < 0) return fail("i3rc_comm_init: timed out waiting for shared memory " + g_shmName);
+  if (g_rank == 0) {   // a fresh segment per run, named after this process; the others learn the name at the rendezvous
+    std::snprintf(name, sizeof(name), "/i3rc_comm_%d_%ld", rendezvous_port(), (long)getpid());
+    shm_unlink(name);
+    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)g_shmBytes) != 0) return fail(std::string("i3rc_comm_init: cannot create shared memory ") + name);
+  }
+  if (rendezvous_broadcast(name, sizeof(name))) return 1;
+  g_shmName = name;
+  if (g_rank != 0) {
+    fd = shm_open(name, O_RDWR, 0600);
+    if (fd < 0) return fail(std::string("i3rc_comm_init: cannot open shared memory ") + name);
   }
   void *p = mmap(nullptr, g_shmBytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
   close(fd);
@@ -215,7 +270,6 @@ int i3rc_comm_finalize(void) {
     if (g_dev) (void)hipFree(g_dev);
     if (g_stream) (void)hipStreamDestroy(g_stream);
     g_comm = nullptr; g_dev = nullptr; g_stream = nullptr; g_devCap = 0;
-    if (g_rank == 0) std::remove((env_str("I3RC_COMM_DIR", "/dev/shm") + "/i3rc_nccl_" + env_str("MASTER_PORT", "29500") + ".id").c_str());
   } else if (g_backend == SHM) {
     (void)shm_barrier();
     munmap((void *)g_hdr, g_shmBytes);

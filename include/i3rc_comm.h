@@ -7,9 +7,10 @@
  *
  * Ranks are taken from the environment of the usual launchers: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR /
  * MASTER_PORT (torchrun style), else OMPI_COMM_WORLD_RANK / _SIZE / _LOCAL_RANK, else a single process.
- * Backends: "rccl" (default: ncclAllReduce over xGMI; the unique id is handed from rank 0 to the others through a file
- * in I3RC_COMM_DIR, default /dev/shm, named after MASTER_PORT) and "shm" (I3RC_COMM_BACKEND=shm: POSIX shared memory on
- * one node, no GPU needed -- used by the CPU tests of the N > 1 path).
+ * Backends: "rccl" (default: ncclAllReduce over xGMI) and "shm" (I3RC_COMM_BACKEND=shm: POSIX shared memory on one
+ * node, no GPU needed -- used by the CPU tests of the N > 1 path).  Bootstrap of both: rank 0 listens on
+ * MASTER_ADDR:MASTER_PORT (IPv4; I3RC_COMM_PORT overrides the port, e.g. under a launcher that keeps MASTER_PORT for
+ * itself) and hands the ncclUniqueId / the segment name to the other ranks; nothing is left behind for a later run.
  * All functions return 0 on success; i3rc_comm_last_error() describes the last failure.
  */
 #ifndef I3RC_COMM_H
