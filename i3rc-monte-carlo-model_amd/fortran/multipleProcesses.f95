@@ -41,6 +41,15 @@ module MultipleProcesses
       import
       integer(c_int) :: rc
     end function
+    function i3rc_comm_last_error() bind(C, name = "i3rc_comm_last_error") result(text)
+      import
+      type(c_ptr) :: text
+    end function
+    function c_strlen(text) bind(C, name = "strlen") result(n)
+      import
+      type(c_ptr), value :: text
+      integer(c_size_t)  :: n
+    end function
   end interface
 
   public :: MasterProc, initializeProcesses, synchronizeProcesses, finalizeProcesses, sumAcrossProcesses
@@ -50,7 +59,7 @@ contains
     integer, intent(out) :: numProcs, thisProcNum
     integer(c_int) :: n, r
     if(i3rc_comm_init(n, r) /= 0) then
-      print *, "initializeProcesses: cannot set up the process group"
+      print *, "initializeProcesses: cannot set up the process group: " // lastError()
       stop 1
     end if
     numProcs    = n
@@ -64,7 +73,7 @@ contains
 
   subroutine synchronizeProcesses
     if(i3rc_comm_barrier() /= 0) then
-      print *, "synchronizeProcesses failed"
+      print *, "synchronizeProcesses failed: " // lastError()
       stop 1
     end if
   end subroutine synchronizeProcesses
@@ -78,7 +87,7 @@ contains
     real, dimension(:), intent(inout) :: flat
     if(size(flat) == 0) return
     if(i3rc_comm_sum_float(flat, int(size(flat), c_int64_t)) /= 0) then
-      print *, "sumAcrossProcesses failed"
+      print *, "sumAcrossProcesses failed: " // lastError()
       stop 1
     end if
   end subroutine sumInPlace
@@ -129,4 +138,19 @@ contains
     total = reshape(flat, shape(x))
     deallocate(flat)
   end function sumRank4
+  function lastError() result(message)
+    character(len = 256) :: message
+    character(kind = c_char), pointer :: chars(:)
+    type(c_ptr) :: text
+    integer     :: i, n
+    message = ""
+    text = i3rc_comm_last_error()
+    if(.not. c_associated(text)) return
+    n = min(int(c_strlen(text)), len(message))
+    call c_f_pointer(text, chars, (/ n /))
+    do i = 1, n
+      message(i:i) = chars(i)
+    end do
+  end function lastError
+
 end module MultipleProcesses
