@@ -95,7 +95,7 @@ __device__ __forceinline__ void intensity_contribution(const DevProblem &P, cons
     }
     Ray r;
     r.x = x; r.y = y; r.z = z; r.ix = ix; r.iy = iy; r.iz = iz; r.dx = ux; r.dy = uy; r.dz = uz;
-    r.set_direction();
+    r.set_direction(L);
     float con;
     auto run = [&](bool hasTarget, float target) {
       r.acc = 0.0f; r.target = target;
@@ -227,6 +227,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
   Ray r;
   r.x = r.y = r.z = 0.0f; r.dx = r.dy = 0.0f; r.dz = -1.0f; r.ix = r.iy = r.iz = 1; r.acc = 0.0f; r.target = 0.0f;
   r.rx = r.ry = r.rz = 0.0f; r.slow = 1;
+  r.ex = r.ey = r.ez = 0; r.cx = r.cy = r.cz = 1; r.nudge = 2.0f;
   float w = 0.0f;
   int order = 0;
   int st = ST_NEW;
@@ -346,7 +347,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
                 normPF = lookup_phase(tab, ct.nFwd, ang) / ((4.0f * kPi) * fabsf(uz));
               }
               r.dx = ux; r.dy = uy; r.dz = uz;
-              r.set_direction();
+              r.set_direction(L);
               r.acc = 0.0f; r.target = 0.0f;
               if (!P.useRRI) stage = 0;
               else {
@@ -360,7 +361,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
             } else {                                                     // back to the photon's own path
               r.dx = park[6 * 256]; r.dy = park[7 * 256]; r.dz = park[8 * 256];
               r.target = park[9 * 256]; r.acc = 0.0f;
-              r.set_direction();
+              r.set_direction(L);
               st = ST_TRACE;
             }
           }
@@ -577,7 +578,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
         if (st == ST_TRACE) {                                             // :480
           const float tau = -sample_log(fmaxf(kTiny, rng.next()));
           r.acc = 0.0f; r.target = tau;
-          if (rayTracing) { startedTrace = true; r.set_direction(); }
+          if (rayTracing) { startedTrace = true; r.set_direction(L); }
           else {                                                          // :494-496 max cross-section move
             r.x = make_periodic(r.x + r.dx * tau / P.maxExt, P.x0, P.xMax);
             r.y = make_periodic(r.y + r.dy * tau / P.maxExt, P.y0, P.yMax);
@@ -679,7 +680,7 @@ __global__ void __launch_bounds__(256) trace_rays_kernel(const DevProblem P, lon
   r.x = pos[3 * i]; r.y = pos[3 * i + 1]; r.z = pos[3 * i + 2];
   r.dx = dir[3 * i]; r.dy = dir[3 * i + 1]; r.dz = dir[3 * i + 2];
   r.ix = idx[3 * i]; r.iy = idx[3 * i + 1]; r.iz = idx[3 * i + 2];
-  r.set_direction();
+  r.set_direction(L);
   r.acc = 0.0f;
   const bool hasTarget = target[i] >= 0.0f;
   r.target = target[i];

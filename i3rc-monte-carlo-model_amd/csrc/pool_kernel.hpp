@@ -107,6 +107,12 @@ __global__ void __launch_bounds__(256, 4) photon_pool_kernel(const DevProblem P,
         r.acc = ph[F_ACC * kPool]; r.target = ph[F_TARGET * kPool];
         // a direction cosine below 1e-20 (or zero: reciprocal inf / NaN) takes the tracer's guarded IEEE divisions
         r.slow = !(fabsf(r.rx) <= 1e20f) || !(fabsf(r.ry) <= 1e20f) || !(fabsf(r.rz) <= 1e20f);
+        {   // the per-trace constants of trace_step (this experiment keeps them out of the pool)
+          const bool px = r.dx >= 0.0f, py = r.dy >= 0.0f, pz = r.dz >= 0.0f;
+          r.ex = lds_address(L.xE) - (px ? 0 : 4); r.ey = lds_address(L.yE) - (py ? 0 : 4); r.ez = lds_address(L.zE) - (pz ? 0 : 4);
+          r.cx = px ? 1 : -1; r.cy = py ? 1 : -1; r.cz = pz ? 1 : -1;
+          r.nudge = px ? 2.0f : -2.0f;
+        }
         const StepResult s = trace_step(P, L, r, true);
         ph[F_X * kPool] = r.x; ph[F_Y * kPool] = r.y; ph[F_Z * kPool] = r.z;
         ph[F_IX * kPool] = __int_as_float(r.ix); ph[F_IY * kPool] = __int_as_float(r.iy); ph[F_IZ * kPool] = __int_as_float(r.iz);

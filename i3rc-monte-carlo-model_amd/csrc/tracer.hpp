@@ -168,6 +168,10 @@ __device__ __forceinline__ void make_dircos(float mu, float phi, float &dx, floa
   dx = sinTheta * c; dy = sinTheta * s; dz = mu;
 }
 
+// LDS byte address of an LDS pointer and back (LDS pointers are 32 bits wide)
+__device__ __forceinline__ int lds_address(const lds_float *p) { return (int)(__UINTPTR_TYPE__)p; }
+__device__ __forceinline__ float lds_read(int byteAddress) { return *(const lds_float *)(__UINTPTR_TYPE__)(unsigned)byteAddress; }
+
 struct Ray {
   float x, y, z;
   float dx, dy, dz;
@@ -175,9 +179,18 @@ struct Ray {
   int slow;           // 1: some |direction cosine| < 1e-20 -> plain IEEE division (and the 2*tiny test) per step
   int ix, iy, iz;
   float acc, target;
-  __device__ __forceinline__ void set_direction() {
+  // what a trace needs of its direction at every voxel step, worked out once per trace (set_direction):
+  int ex, ey, ez;     // LDS byte address of edge 0 of the face the ray moves towards: face coordinate = [e + 4 index]
+  int cx, cy, cz;     // cell increment (+1 / -1) along each axis
+  float nudge;        // 2 cx as a float: the periodic wrap moves the position by nudge * spacing() (:1774-1788)
+  __device__ __forceinline__ void set_direction(const Lds &L) {
     slow = fminf(fminf(fabsf(dx), fabsf(dy)), fabsf(dz)) < 1e-20f;
     rx = refined_rcp(dx); ry = refined_rcp(dy); rz = refined_rcp(dz);
+    const bool px = dx >= 0.0f, py = dy >= 0.0f, pz = dz >= 0.0f;
+    // edges are stored from index 0; cell i (1-based) lies between edge i - 1 and edge i
+    ex = lds_address(L.xE) - (px ? 0 : 4); ey = lds_address(L.yE) - (py ? 0 : 4); ez = lds_address(L.zE) - (pz ? 0 : 4);
+    cx = px ? 1 : -1; cy = py ? 1 : -1; cz = pz ? 1 : -1;
+    nudge = px ? 2.0f : -2.0f;
   }
 };
 
@@ -224,9 +237,8 @@ __device__ __forceinline__ StepResult trace_step(const DevProblem &P, const Lds 
   // the extinction of the current cell is requested first: its latency (LDS, or L2 / HBM for grids that do not fit
   // in LDS) is covered by the three face-distance divisions below
   const float ext = cell_extinction<GRID>(P, L, r.ix, r.iy, r.iz);
-  const bool px = r.dx >= 0.0f, py = r.dy >= 0.0f, pz = r.dz >= 0.0f;
-  const int cx = px ? 1 : -1, cy = py ? 1 : -1, cz = pz ? 1 : -1;
-  const float ex = L.xE[r.ix - (px ? 0 : 1)], ey = L.yE[r.iy - (py ? 0 : 1)], ez = L.zE[r.iz - (pz ? 0 : 1)];
+  const int cx = r.cx, cy = r.cy, cz = r.cz;
+  const float ex = lds_read(r.ex + (r.ix << 2)), ey = lds_read(r.ey + (r.iy << 2)), ez = lds_read(r.ez + (r.iz << 2));
   float stx, sty, stz;
   if (__builtin_expect(r.slow, 0)) {   // a direction cosine of (almost) zero: the reference's guarded division
     stx = fabsf(r.dx) >= 2.0f * kTiny ? (ex - r.x) / r.dx : kHuge;
@@ -264,7 +276,7 @@ __device__ __forceinline__ StepResult trace_step(const DevProblem &P, const Lds 
   r.ix += bx ? cx : 0; r.iy += by ? cy : 0; r.iz += bz ? cz : 0;
 
   // periodic wrap :1774-1788 (y uses x's sign, as the reference does)
-  const float nudge = (float)(cx * 2);
+  const float nudge = r.nudge;
   const bool xLo = r.ix <= 0, xHi = r.ix >= P.nx + 1, yLo = r.iy <= 0, yHi = r.iy >= P.ny + 1;
   const float sxp = nudge * spacingf(r.x), syp = nudge * spacingf(r.y);
   r.x = xLo ? P.xMax + sxp : (xHi ? P.x0 + sxp : r.x);
