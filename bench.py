@@ -183,7 +183,7 @@ def main():
                        "rng": "Philox4x32-10 per photon, key (iseed=10, batch)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "photon_kernel<PhiloxStream,false>", "kernel_ms_avg": avg_ms,
+                         "kernel": "photon_kernel<PhiloxStream, false, false, GRID_LDS>", "kernel_ms_avg": avg_ms,
                          "algorithmic_bytes_per_photon": bpp, "per_photon": skd,
                          "note": "working set is LDS/L2 resident: the path is latency/issue bound, not HBM bound (DESIGN.md)"},
             "cpu_baseline": cpu_baseline,
