@@ -109,6 +109,45 @@ contains
     call reportResults(mc, fluxUp = fluxUp, fluxDown = fluxDown, meanIntensity = meanI, status = status)
     print '(a, 4f10.5, l2)', "surface   ", fluxUp(1, 1), fluxDown(1, 1), meanI, stateIsFailure(status)
     call finalize_Integrator(mc)
+    call otherSources(slab)
     print '(a)', "gpu checks done"
   end subroutine gpuChecks
+
+  ! The photon sources that hand the kernel explicit start positions and directions (monteCarloIllumination.f95
+  ! :106-424): on a horizontally uniform slab the azimuth and the place of entry do not matter, so RandomAzimuth and
+  ! Spotlight must give the Directional fluxes; Flux and the internal (detector) sources must conserve energy.
+  subroutine otherSources(slab)
+    type(domain), intent(in) :: slab
+    type(integrator)           :: mc
+    type(randomNumberSequence) :: randoms
+    type(photonStream)         :: photons
+    integer, parameter :: nPhotons = 400000
+    real    :: fluxUp(1, 1), fluxDown(1, 1), results(2, 4)
+    integer :: kind
+
+    mc = new_Integrator(slab, status)
+    call specifyParameters(mc, surfaceAlbedo = 0., status = status)
+    do kind = 1, 4
+      randoms = new_RandomNumberSequence(seed = (/ 20 + kind, 3 /))
+      select case(kind)
+        case(1); photons = new_PhotonStream(0.5, numberOfPhotons = nPhotons, randomNumbers = randoms, status = status)
+        case(2); photons = new_PhotonStream(0.5, 0., 0.2, 0.4, numberOfPhotons = nPhotons, randomNumbers = randoms, status = status)
+        case(3); photons = new_PhotonStream(numberOfPhotons = nPhotons, randomNumbers = randoms, status = status)
+        case(4); photons = new_PhotonStream(0.5, 0.5, 0.5, .true., numberOfPhotons = nPhotons, randomNumbers = randoms, &
+                                            status = status)
+      end select
+      if(stateIsFailure(status)) then
+        print *, "photon source ", kind, " failed"; stop 1
+      end if
+      call computeRadiativeTransfer(mc, randoms, photons, status)
+      if(stateIsFailure(status)) then
+        print *, "computeRadiativeTransfer failed for photon source ", kind; stop 1
+      end if
+      call reportResults(mc, fluxUp = fluxUp, fluxDown = fluxDown, status = status)
+      results(:, kind) = (/ fluxUp(1, 1), fluxDown(1, 1) /)
+      call finalize_PhotonStream(photons)
+    end do
+    print '(a, 8f10.5)', "sources   ", results
+    call finalize_Integrator(mc)
+  end subroutine otherSources
 end program shellSelfTest

@@ -235,6 +235,15 @@ def test_shell_integrator_on_gpu():
     assert abs(float(up) + float(down) - 1.0) < 1e-4
     s = _fields(r.stdout, "surface")
     assert float(s[0]) > float(up) and 0 < float(s[2]) < 1 and 0 < float(s[3]) < 1 and s[4] == "F"
+    # photon sources with explicit start positions / directions (RandomAzimuth, Spotlight, Flux, internal detector)
+    src = [float(v) for v in _fields(r.stdout, "sources")]
+    ra, spot, flux, internal = src[0:2], src[2:4], src[4:6], src[6:8]
+    for f_up, f_dn in (ra, spot):      # a horizontally uniform slab: same fluxes as the Directional stream (4e5 photons)
+        assert abs(f_up - float(up)) < 0.004 and abs(f_dn - float(down)) < 0.004
+    for f_up, f_dn in (ra, spot, flux, internal):
+        assert abs(f_up + f_dn - 1.0) < 2e-4
+    assert float(up) * 0.5 < flux[0] < 0.5          # isotropic-flux illumination: between overhead and grazing sun
+    assert 0.5 < internal[0] < 1.0                   # upward-looking detector in mid-slab: most photons leave through the top
 
 
 @pytest.mark.gpu
