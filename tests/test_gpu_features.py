@@ -182,3 +182,30 @@ def test_bound_tally_buffer_follows_the_callers_stream():
     assert lib.i3rc_hip_bind_tally_buffer(g._h, None, 0) == 0 and lib.i3rc_hip_use_own_stream(g._h) == 0
     again = g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 2)), M.new_PhotonStream(1.0, 0.0, n))
     assert again["counters"] == ref["counters"]
+
+
+def test_radiance_on_irregular_grid_with_two_components(oracle):
+    # the general kernel's radiance state machine (shadow rays as lane states) where nothing is special: irregular
+    # grid (cell searches), two components with their own forward tables, reflecting surface
+    d = cases.two_component()
+    t_cloud = M.PhaseFunctionTable([M.henyey_greenstein(0.85, 32), M.henyey_greenstein(0.6, 16)])
+    t_gas = M.PhaseFunctionTable([M.PhaseFunction(legendre=np.array([0.0, 0.1], np.float32))])
+    gp = dict(surfaceAlbedo=0.25, useRussianRouletteForIntensity=True, zetaMin=0.3)
+    op = dict(surfaceAlbedo=0.25, useRRForIntensity=1, zetaMin=0.3)
+    g, o = _intensity_pair(oracle, d, [t_cloud, t_gas], gpu_params=gp, oracle_params=op, mus=[1.0, 0.4, -0.7], phis=[0.0, 60.0, 200.0])
+    _parity(oracle, g, o, 8, 8000, 0.6, az=70.0, keys=("fluxUp", "fluxDown", "intensity"), floor=1e-6)
+    d = cases.irregular_domain()
+    gp = dict(surfaceAlbedo=0.5)
+    g, o = _intensity_pair(oracle, d, hg_table(), gpu_params=gp, oracle_params=gp, mus=[0.9, 0.3], phis=[10.0, 250.0])
+    _parity(oracle, g, o, 8, 8000, 0.4, az=130.0, keys=("fluxUp", "fluxDown", "intensity"), floor=1e-6)
+
+
+def test_max_cross_section_with_radiances(oracle):
+    # max cross-section transport keeps the reference's nested order of the local estimate (the photon moves inside
+    # the event), the one place where production builds still run intensity_contribution
+    d = cases.step_cloud(ssa=0.98, nlayers=8)
+    gp = dict(useRayTracing=False, surfaceAlbedo=0.2)
+    op = dict(useRayTracing=0, surfaceAlbedo=0.2)
+    g, o = _intensity_pair(oracle, d, hg_table(), gpu_params=gp, oracle_params=op, mus=[1.0, 0.5], phis=[0.0, 90.0])
+    gr, orr = _parity(oracle, g, o, 8, 6000, 0.8, az=15.0, keys=("fluxUp", "fluxDown", "fluxAbsorbed", "intensity"))
+    assert sum(r["counters"]["shadowSteps"] for r in gr) > 0
