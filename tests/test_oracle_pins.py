@@ -113,3 +113,77 @@ def test_step_cloud_work_counters_and_fluxes(oracle):
     assert abs(np.mean(fd) - 0.6746) < 3 * 4.7e-4 * np.sqrt(10 / nb)
     # energy closure with the dropped-photon deficit (quirk Q4)
     assert abs((np.mean(fu) + np.mean(fd)) - (1 - tot["nBad"] / n)) < 2e-6
+
+
+def _oracle_run(oracle, d, inv, mu0, nb, n, fwd=None, specify=None, tables=None):
+    kw = {}
+    integ = oracle.Integrator(d["xe"], d["ye"], d["ze"], d["ext"], d["ssa"], np.maximum(d["pf"], 1), [inv], *([[fwd], [fwd]] if fwd is not None else []))
+    if specify:
+        integ.specify(**specify)
+    tot, flux = {}, {"fluxUp": [], "fluxDown": [], "fluxAbsorbed": [], "intensity": []}
+    for b in range(1, nb + 1):
+        rng = oracle.RandomNumberSequence([10, b])
+        r = integ.compute(rng, *oracle.photons_directional(rng, mu0, 0.0, n))
+        for k in ("nPhotons", "nBad", "tracerCalls", "cellSteps", "scatterings"):
+            tot[k] = tot.get(k, 0) + r[k]
+        for k in flux:
+            if k in r:
+                flux[k].append(np.asarray(r[k], np.float64).reshape(r[k].shape[0] if k == "intensity" else 1, -1).mean(1))
+    per = {k: tot[k] / tot["nPhotons"] for k in tot}
+    return per, {k: np.mean(v, axis=0) for k, v in flux.items() if v}
+
+
+def _near(value, recorded, n, extra=0.0):
+    """Recorded reference result (4 digits) against an independent sample of n photons: 3 sigma of a [0, 1] tally."""
+    return abs(value - recorded) < 3 * np.sqrt(max(recorded * (1 - min(recorded, 1.0)), 1e-3) / n) * np.sqrt(2) + 5e-5 + extra
+
+
+# SURVEY.md 6: the reference's own code run at survey time on the I3RC cases -- tracer calls / cell steps / scatterings
+# per photon and domain-mean fluxes.  The work counters are properties of the algorithm (how the tracer counts
+# iterations, when it stops, what a scattering is): a restatement that walks a different path does not reproduce them
+# to three digits; the fluxes pin the physics of each variant.
+def test_step_cloud_slant_sun_and_absorbing_variants(oracle):
+    inv = oracle.inverse_table_legendre(cases.hg_coefficients(0.85, 64), 10001)
+    per, flux = _oracle_run(oracle, cases.step_cloud(), inv, 0.5, 3, 100000)
+    assert abs(per["tracerCalls"] - 25.1) < 0.2 and abs(per["cellSteps"] - 77.5) < 0.5 and abs(per["scatterings"] - 24.1) < 0.2
+    assert _near(flux["fluxUp"][0], 0.5793, 3e5) and _near(flux["fluxDown"][0], 0.4206, 3e5)
+    per, flux = _oracle_run(oracle, cases.step_cloud(ssa=0.99), inv, 1.0, 3, 100000)
+    assert abs(per["tracerCalls"] - 17.7) < 0.2 and abs(per["cellSteps"] - 62.0) < 0.5 and abs(per["scatterings"] - 16.7) < 0.2
+    assert _near(flux["fluxUp"][0], 0.2587, 3e5) and _near(flux["fluxDown"][0], 0.6004, 3e5)
+    assert _near(flux["fluxAbsorbed"][0], 0.1408, 3e5)
+
+
+def test_radar_cloud_recorded_results(oracle):
+    inv = oracle.inverse_table_legendre(cases.hg_coefficients(0.85, 299), 10001)
+    d = cases.radar_cloud()
+    per, flux = _oracle_run(oracle, d, inv, 1.0, 2, 50000)
+    assert abs(per["tracerCalls"] - 45.3) < 0.5 and abs(per["cellSteps"] - 119.0) < 1.2 and abs(per["scatterings"] - 44.3) < 0.5
+    assert _near(flux["fluxUp"][0], 0.5579, 1e5, 1e-3) and _near(flux["fluxDown"][0], 0.4414, 1e5, 1e-3)
+    assert 4e-4 < per["nBad"] < 1.1e-3                                  # SURVEY.md quirk Q4: 7.0e-4 on the radar field
+    # + nadir radiance with Iwabuchi roulette (zeta_min 0.3): 92.6 tracer calls / 222.8 cell steps, I(mu=1) = 0.1821
+    fwd = oracle.forward_table_legendre(cases.hg_coefficients(0.85, 299), 10001)
+    per, flux = _oracle_run(oracle, d, inv, 1.0, 2, 40000, fwd=fwd,
+                            specify=dict(intensityMus=[1.0], intensityPhis=[0.0], useRRForIntensity=1, zetaMin=0.3))
+    assert abs(per["tracerCalls"] - 92.6) < 1.0 and abs(per["cellSteps"] - 222.8) < 2.5 and abs(per["scatterings"] - 44.4) < 0.5
+    assert abs(flux["intensity"][0] - 0.1821) < 0.004
+
+
+def test_landsat_scene_recorded_results(oracle):
+    inv = oracle.inverse_table_legendre(cases.hg_coefficients(0.85, 299), 10001)
+    d = cases.landsat_cloud()
+    per, flux = _oracle_run(oracle, d, inv, 1.0, 2, 40000)
+    assert abs(per["tracerCalls"] - 16.7) < 0.2 and abs(per["cellSteps"] - 241.2) < 2.5 and abs(per["scatterings"] - 15.7) < 0.2
+    assert _near(flux["fluxUp"][0], 0.3045, 8e4, 1e-3) and _near(flux["fluxDown"][0], 0.6953, 8e4, 1e-3)
+    assert 5e-5 < per["nBad"] < 3e-4                                    # 1.5e-4
+    per, flux = _oracle_run(oracle, d, inv, 0.5, 2, 40000)
+    assert abs(per["tracerCalls"] - 21.8) < 0.3 and abs(per["cellSteps"] - 343.5) < 3.5 and abs(per["scatterings"] - 20.8) < 0.3
+    assert _near(flux["fluxUp"][0], 0.5170, 8e4, 1e-3) and _near(flux["fluxDown"][0], 0.4828, 8e4, 1e-3)
+    # 7 radiance directions + Lambertian 0.2 through a surface object: 214 tracer calls / 3194 cell steps / 23.1 scatterings
+    fwd = oracle.forward_table_legendre(cases.hg_coefficients(0.85, 299), 10001)
+    huge = np.finfo(np.float32).max
+    per, _ = _oracle_run(oracle, d, inv, 0.5, 1, 16000, fwd=fwd, specify=dict(
+        intensityMus=[1, .5, .5, .8, .8, .3, .3], intensityPhis=[0, 0, 180, 90, 270, 45, 225], useRRForIntensity=1, zetaMin=0.3,
+        surfaceBDRF=(np.array([0.0, huge], np.float32), np.array([0.0, huge], np.float32), np.array([[0.2]], np.float32))))
+    # (cell steps per photon scatter with a standard deviation of ~2000: +-16 at this sample size, +-10 in the recorded run;
+    # the GPU's 2e7-photon mean is 3205)
+    assert abs(per["tracerCalls"] - 214) < 4 and abs(per["cellSteps"] - 3194) < 60 and abs(per["scatterings"] - 23.1) < 0.5
