@@ -74,8 +74,8 @@ struct i3rc_hip_integrator {
   hipEvent_t evStart[kEventRing] = {}, evStop[kEventRing] = {};
   long long timedLaunches = 0;
   int numCU = 256;
-  int evThreshold = 0;        // lanes waiting before a wave runs its event phase; 0 = default (40 flux-only, 24 with radiances)
-  int lightThreshold = 0;     // lanes with an ended shadow ray before a wave runs its light phase; 0 = default (24, or 8 from 3 directions on)
+  int evThreshold = 0;        // lanes waiting before a wave runs its event phase; 0 = adapted per wave
+  int lightThreshold = 0;     // lanes with an ended shadow ray before a wave runs its light phase; 0 = adapted per wave
   int blocksPerCU = 0;  // 0 = from occupancy query
   int kernelVariant = I3RC_KERNEL_AUTO;  // test / tuning knob (i3rc_hip_select_kernel)
   std::string err;
@@ -555,13 +555,9 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
   if (timeIt) HIPCHK(h, hipEventRecord(h->evStart[slot], h->stream));
   if (pool) hipLaunchKernelGGL(photon_pool_kernel, dim3((unsigned)blocks), dim3(256), plan.ldsBytes, h->stream, plan.P, B);
   else {
-    // measured optima (tools/quick_bench.py, tools/radiance_sweep.py): photons' own paths alone 40; with shadow rays in
-    // the mix events are a smaller share of the work and waiting for them costs more than a thinner event phase
-    // (radar + 1 direction: 40 / 24 is 8 % faster than 24 / 8; Landsat + 7 directions: 24 / 8 is 34 % faster than 40 / 24)
-    const bool manyRays = h->nDir >= 3;
-    // flux-only launches without a threshold of the caller's adapt it per wave, starting from 40 (negative = adaptive)
-    const int evThreshold = h->evThreshold > 0 ? h->evThreshold : (plan.intensity ? (manyRays ? 24 : 40) : -40);
-    const int lightThreshold = h->lightThreshold > 0 ? h->lightThreshold : (manyRays ? 8 : 24);
+    // thresholds the caller did not fix are adapted per wave (photon_kernel); negative = adaptive, starting value
+    const int evThreshold = h->evThreshold > 0 ? h->evThreshold : -40;
+    const int lightThreshold = h->lightThreshold > 0 ? h->lightThreshold : -24;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), plan.ldsBytes, h->stream, plan.P, B, evThreshold, lightThreshold);
   }
   HIPCHK(h, hipGetLastError());

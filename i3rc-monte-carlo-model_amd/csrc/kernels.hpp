@@ -206,6 +206,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
   __syncthreads();
 
   constexpr bool REPLAY = Rng::kReplay;        // per-photon fates are recorded by i3rc_hip_run_replay only
+  constexpr bool DEFER_BUILD = INTENSITY && !Rng::kReplay;   // radiances through the lane state machine (see DEFER below)
   constexpr bool NEED_PID = REPLAY || GENERAL; // explicit photon sources are indexed by photon number
   const Tally tally{P, L};
   const size_t ncell = (size_t)P.nx * P.ny * P.nz;
@@ -246,20 +247,31 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
   bool pendingShadow = false;
   const bool defer = DEFER && rayTracing;            // max cross-section moves the photon inside the event: keep the nested order there
 
-  // Event threshold: fixed when the caller asks for one (evThreshold > 0), else adapted by every wave to its own
-  // photons: the longer the traces (voxel steps per event), the more a lane loses by waiting for others, so the
-  // threshold falls as 64 / sqrt(steps per event) (measured optima: 40 at 2.5 steps per event, 32 at 3.5, 24 at 9,
-  // 16 at 14).  It only schedules work: a photon's path does not depend on it.
+  // Thresholds: fixed when the caller asks for them (> 0), else adapted by every wave to its own photons at every
+  // reservoir refill.  Event phase: the longer the photons' own traces (voxel steps per event), the more a
+  // lane loses by waiting for others, so the threshold falls as 64 / sqrt(steps per event) (measured optima: 40 at
+  // 2.5 steps per event, 32 at 3.5, 24 at 9, 16 at 14 ... 16, with or without shadow rays in the mix).  Light phase: likewise with
+  // the length of the shadow rays, 70 / sqrt(steps per ray) within 16..32 (measured: 32 for the radar case's 2-step
+  // nadir rays, 16 for the Landsat case's 19-step rays).  Thresholds only schedule work: no photon path depends on them.
   int evThr = evThreshold > 0 ? evThreshold : -evThreshold;
-  const bool adaptive = evThreshold < 0 && !INTENSITY;
+  int liThr = lightThreshold > 0 ? lightThreshold : -lightThreshold;
+  const bool adaptEvent = evThreshold < 0, adaptLight = DEFER_BUILD && lightThreshold < 0;
+  uint32_t raysStarted = 0;   // shadow rays since the last refill (wave-uniform)
   // hands the wave's work counters over to the tally buffer (uniform control flow only)
   auto flush_counters = [&]() {
-    if (adaptive) {
+    if (adaptEvent) {
       const float events = (float)(wc.scat + wc.photons + wc.surf), steps = (float)wc.steps;
       if (events > 0.0f && steps > 0.0f) {
         const int t = (int)(64.0f * __builtin_amdgcn_rsqf(steps * __builtin_amdgcn_rcpf(events)));
         evThr = __builtin_amdgcn_readfirstlane(t < 12 ? 12 : (t > 44 ? 44 : t));
       }
+    }
+    if (adaptLight) {
+      if (raysStarted > 0u && wc.shadow > 0u) {
+        const int t = (int)(70.0f * __builtin_amdgcn_rsqf((float)wc.shadow * __builtin_amdgcn_rcpf((float)raysStarted)));
+        liThr = __builtin_amdgcn_readfirstlane(t < 16 ? 16 : (t > 32 ? 32 : t));
+      }
+      raysStarted = 0u;
     }
     if ((threadIdx.x & 63) == 0) {
       const uint32_t c[9] = {wc.photons, wc.dropped, wc.steps, wc.scat, wc.surf, wc.top, wc.roul, wc.shadow, wc.calls};
@@ -301,7 +313,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
     if (DEFER) {
       liMask = __ballot(st == ST_LIGHT);
       // ------------------------------------------------------------ LIGHT phase (shadow-ray ends and starts)
-      if (liMask != 0ull && (__popcll(liMask) >= lightThreshold || trMask == 0ull)) {
+      if (liMask != 0ull && (__popcll(liMask) >= liThr || trMask == 0ull)) {
         if (st == ST_LIGHT) {
           lds_float *park = L.park + threadIdx.x;
           if (stage >= 0) {                                              // the ray that just ended (:1517-1596)
@@ -367,7 +379,9 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
           }
         }
         // every lane that entered as ST_LIGHT and leaves as ST_SHADOW has started exactly one tracer call
-        wc.calls += (unsigned)__popcll(__ballot(st == ST_SHADOW) & liMask);
+        const unsigned started = (unsigned)__popcll(__ballot(st == ST_SHADOW) & liMask);
+        wc.calls += started;
+        raysStarted += started;
       }
     }
     if (evMask == 0ull && trMask == 0ull && liMask == 0ull) break;

@@ -180,11 +180,11 @@ int i3rc_hip_last_kernel_ms(i3rc_hip_integrator *h, float *ms);
 int i3rc_hip_kernel_ms_history(i3rc_hip_integrator *h, int n, float *ms);
 
 /* Experiment knobs (not part of the reference API): lanes that must be waiting before a wavefront runs its
- * event phase (1..64; 0 = default: flux-only runs adapt it per wave to the photons' voxel steps per event, 64 / sqrt(steps per event)
- * within 12..44; radiance runs use 40, or 24 from 3 directions on) and workgroups per CU (0 = occupancy query). */
+ * event phase (1..64; 0 = default: every wave adapts it to its photons' voxel steps per event, 64 / sqrt(steps per
+ * event) within 12..44) and workgroups per CU (0 = occupancy query). */
 int i3rc_hip_set_tuning(i3rc_hip_integrator *h, int evThreshold, int blocksPerCU);
-/* ... and lanes whose local-estimate (shadow) ray has ended before the wavefront runs its light phase (1..64,
- * 0 = default: 24, or 8 from 3 directions on; radiance runs only). */
+/* ... and lanes whose local-estimate (shadow) ray has ended before the wavefront runs its light phase (1..64;
+ * 0 = default: adapted to the length of the rays, 70 / sqrt(steps per ray) within 16..32; radiance runs only). */
 int i3rc_hip_set_light_threshold(i3rc_hip_integrator *h, int lanes);
 
 /* Test / tuning knob.  A launch normally (AUTO) runs the one-photon-per-lane kernel specialised for the common
