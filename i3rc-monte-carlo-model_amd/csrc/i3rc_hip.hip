@@ -78,6 +78,7 @@ struct i3rc_hip_integrator {
   int lightThreshold = 0;     // lanes with an ended shadow ray before a wave runs its light phase; 0 = adapted per wave
   int blocksPerCU = 0;  // 0 = from occupancy query
   int kernelVariant = I3RC_KERNEL_AUTO;  // test / tuning knob (i3rc_hip_select_kernel)
+  int64_t launchLimit = 0;               // photons per kernel launch (i3rc_hip_set_launch_limit); 0 = numCU * 2^22
   std::string err;
 
   int fail(const std::string &m) { err = m; return 1; }
@@ -395,6 +396,13 @@ int i3rc_hip_set_light_threshold(i3rc_hip_integrator *h, int lanes) {
   return 0;
 }
 
+int i3rc_hip_set_launch_limit(i3rc_hip_integrator *h, int64_t photons) {
+  if (!h) return 1;
+  if (photons < 0) return h->fail("i3rc_hip_set_launch_limit: negative limit");
+  h->launchLimit = photons;
+  return 0;
+}
+
 int i3rc_hip_select_kernel(i3rc_hip_integrator *h, int variant) {
   if (!h) return 1;
   if (variant < I3RC_KERNEL_AUTO || variant > I3RC_KERNEL_POOL) return h->fail("i3rc_hip_select_kernel: unknown variant");
@@ -584,7 +592,19 @@ int i3rc_hip_launch_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1
   A.seed0 = seed0; A.seed1 = seed1; A.firstPhoton = firstPhoton; A.nPhotons = nPhotons;
   A.workCounter = (unsigned long long *)h->workCounter.p;
   if (upload_source(h, src, nPhotons, A)) return 1;
-  return launch<PhiloxStream>(h, plan, A, true);
+  // Workgroups keep their partial flux / radiance sums in float32 (LDS): a workgroup must not see so many photons
+  // that a column's sum could leave the range where float32 still counts (2^24).  Per-photon random streams make a
+  // long batch the same as several launches over consecutive photon ranges, so very long Directional batches are cut
+  // into launches of at most 2^22 photons per compute unit (about 1e9 photons on an MI355X).
+  const int64_t perLaunch = h->launchLimit > 0 ? h->launchLimit : (int64_t)h->numCU << 22;
+  if (src->kind != 0 || nPhotons <= perLaunch) return launch<PhiloxStream>(h, plan, A, true);
+  for (int64_t done = 0; done < nPhotons; done += perLaunch) {
+    RunArgs part = A;
+    part.firstPhoton = firstPhoton + done;
+    part.nPhotons = std::min(perLaunch, nPhotons - done);
+    if (launch<PhiloxStream>(h, plan, part, true)) return 1;
+  }
+  return 0;
 }
 
 int i3rc_hip_run_replay(i3rc_hip_integrator *h, int64_t nPhotons, const i3rc_source *src, const float *randoms,

@@ -187,6 +187,11 @@ int i3rc_hip_set_tuning(i3rc_hip_integrator *h, int evThreshold, int blocksPerCU
  * 0 = default: adapted to the length of the rays, 70 / sqrt(steps per ray) within 16..32; radiance runs only). */
 int i3rc_hip_set_light_threshold(i3rc_hip_integrator *h, int lanes);
 
+/* A Directional batch longer than this many photons is cut into several kernel launches over consecutive photon
+ * ranges (same result: every photon has its own random stream).  0 = default, 2^22 photons per compute unit (about
+ * 1e9 on an MI355X): workgroups keep partial sums in float32, which stops counting at 2^24. */
+int i3rc_hip_set_launch_limit(i3rc_hip_integrator *h, int64_t photons);
+
 /* Test / tuning knob.  A launch normally (AUTO) runs the one-photon-per-lane kernel specialised for the common
  * problem class (regular grid, ray tracing, one component, no BRDF grid, Directional source) when the problem is
  * in it, else the general kernel.  All kernels trace the same photon paths from the same per-photon random streams,
