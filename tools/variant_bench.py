@@ -29,9 +29,9 @@ else:
         dom = M.new_Domain(d["xe"], d["ye"], d["ze"]); dom.addOpticalComponent("c", d["ext"], d["ssa"], d["pf"], M.PhaseFunctionTable([M.henyey_greenstein(0.85, 64)]))
         g = M.new_Integrator(dom); g.specifyParameters(minInverseTableSize=10001)
         g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 0)), M.new_PhotonStream(1.0, 0.0, 100000))
-        n = 50_000_000
+        n = 100_000_000
         out = []
-        for thr in (32, 40, 48):
+        for thr in (0, 0):
             g.set_tuning(thr, 0)
             r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 1)), M.new_PhotonStream(1.0, 0.0, n))
             out.append(f"thr{thr} {n / g.kernel_ms() * 1e3:.3e}")
