@@ -17,7 +17,7 @@ d = cases.step_cloud(nlayers=nl)
 dom = M.new_Domain(d["xe"], d["ye"], d["ze"]); dom.addOpticalComponent("c", d["ext"], d["ssa"], d["pf"], M.PhaseFunctionTable([M.henyey_greenstein(0.85, 64)]))
 g = M.new_Integrator(dom); g.specifyParameters(minInverseTableSize=10001)
 n = 20_000_000
-for thr in (32, 40, 48):
+for thr in (40,):
     g.set_tuning(thr, 0)
     r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 1)), M.new_PhotonStream(1.0, 0.0, n))
     raw = r["raw"]; lay = g.layout(); c = raw[lay.counters:lay.counters + 16]
