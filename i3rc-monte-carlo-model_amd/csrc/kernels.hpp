@@ -314,6 +314,11 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
       liMask = __ballot(st == ST_LIGHT);
       // ------------------------------------------------------------ LIGHT phase (shadow-ray ends and starts)
       if (liMask != 0ull && (__popcll(liMask) >= liThr || trMask == 0ull)) {
+#ifdef I3RC_PROFILE_PHASES
+        const unsigned long long profL0 = __builtin_amdgcn_s_memtime();
+        profSeg[6] += (unsigned long long)__popcll(liMask);   // lanes served by light phases
+        profNew++;                                            // light phases
+#endif
         if (st == ST_LIGHT) {
           lds_float *park = L.park + threadIdx.x;
           if (stage >= 0) {                                              // the ray that just ended (:1517-1596)
@@ -382,6 +387,9 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
         const unsigned started = (unsigned)__popcll(__ballot(st == ST_SHADOW) & liMask);
         wc.calls += started;
         raysStarted += started;
+#ifdef I3RC_PROFILE_PHASES
+        profSeg[7] += __builtin_amdgcn_s_memtime() - profL0;    // cycles in light phases
+#endif
       }
     }
     if (evMask == 0ull && trMask == 0ull && liMask == 0ull) break;
@@ -620,7 +628,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
     const unsigned long long profT1 = PROF_T();
 #ifdef I3RC_PROFILE_PHASES
     profEv += profT1 - profT0;
-    profNSt++; profLanesSt += __popcll(__ballot(st == ST_TRACE));
+    profNSt++; profLanesSt += __popcll(__ballot(st == ST_TRACE || st == ST_SHADOW));
 #endif
     // ---------------------------------------------------------------- VOXEL-STEP phase
     const bool own = st == ST_TRACE, shadowRay = DEFER && st == ST_SHADOW;
@@ -644,7 +652,8 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
     unsafeAtomicAdd(P.tally + P.oCnt + 14, (double)profLanesEv);
     unsafeAtomicAdd(P.tally + P.oCnt + 15, (double)profLanesSt);
     // segment shares are packed into the volume-absorption tally of cells 0..5 (diagnostic build only, omega = 1 runs)
-    for (int k = 0; k < 6; ++k) unsafeAtomicAdd(P.tally + P.oVol + k, (double)profSeg[k]);
+    for (int k = 0; k < 8; ++k) unsafeAtomicAdd(P.tally + P.oVol + k, (double)profSeg[k]);
+    unsafeAtomicAdd(P.tally + P.oVol + 8, (double)profNew);
   }
 #endif
 
