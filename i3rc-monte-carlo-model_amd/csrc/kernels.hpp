@@ -529,13 +529,18 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
             }
           } else {                                                        // :581-689
             bool scatterThis = true;
-            int cell = cell_index(P, r.ix, r.iy, r.iz);
-            if (!rayTracing) scatterThis = rng.next() < P.totalExt[cell] / P.maxExt;
+            int cell = 0;
+            if (!rayTracing) {
+              cell = cell_index(P, r.ix, r.iy, r.iz);
+              scatterThis = rng.next() < P.totalExt[cell] / P.maxExt;
+            }
             if (scatterThis) {
               order++;
               didScatter = true;
-              const float extHere = cell_extinction<GRID>(P, L, r.ix, r.iy, r.iz);
-              if (extHere <= 0.0f) {                                      // :606-632 (quirk Q2 kept)
+              // :606-632 (quirk Q2 kept): a scattering in a cell without extinction steps back over the cell face.  The
+              // tracer only stops inside a cell whose extinction is positive (acc + step * 0 > target cannot hold), so
+              // with ray tracing the case cannot arise and the look-up is left to the max-cross-section build.
+              if (!rayTracing && cell_extinction<GRID>(P, L, r.ix, r.iy, r.iz) <= 0.0f) {
                 if (r.x - L.xE[r.ix - 1] <= 0.0f && r.dx > 0.0f) {
                   r.x = r.x - spacingf(r.x);
                   r.ix = r.ix - 1;
@@ -547,8 +552,10 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
                   if (r.iy <= 0) { r.iy = P.ny; r.y = L.xE[r.iy - 1]; r.y = r.x - 2.0f * spacingf(r.y); }
                 }
                 if (r.z - L.zE[r.iz - 1] <= 0.0f && r.dz > 0.0f) { r.z = r.z - spacingf(r.z); r.iz = r.iz - 1; }
-                cell = cell_index(P, r.ix, r.iy, r.iz);
               }
+              // the cell's properties are read only where the domain does not share one value (see DevProblem)
+              const bool needCell = GENERAL || !(P.uniformSsa >= 0.0f) || P.uniformSsa < 1.0f || P.uniformPf < 1;
+              if (needCell) cell = cell_index(P, r.ix, r.iy, r.iz);
               int comp = 1;                                               // :637-638
               if (multiComp || REPLAY) {
                 const float rc = rng.next();
