@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
         if (st == ST_NEW) {                                               // :453-470
           float px, py, pz;
           if (directional) {   // newPhotonStream_Directional, Code/monteCarloIllumination.f95:91-99
-            px = rng.next(); py = rng.next();
+            px = rng.first(); py = rng.second();
             pz = 1.0f - spacingf(1.0f);
             r.dx = A.solarDx; r.dy = A.solarDy; r.dz = A.solarDz;
           } else {
@@ -512,9 +512,9 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
             const int c2 = (r.iy - 1) * P.nx + (r.ix - 1);
             tally.down(c2, w);
             if (REPLAY) { fateCol = c2; fateW = w; }
-            float mu;
-            do { mu = exact_sqrt(rng.next()); } while (!(fabsf(mu) > 2.0f * kTiny));
-            const float phi = (2.0f * kPi) * rng.next();
+            float mu = exact_sqrt(rng.first());
+            while (!(fabsf(mu) > 2.0f * kTiny)) mu = exact_sqrt(rng.next());   // :546-549
+            const float phi = (2.0f * kPi) * rng.second();
             if (useBDRF) w = w * surface_reflectance(P, r.x, r.y);
             else w = w * P.albedo;
             if (w <= kTiny) { if (REPLAY) fate = 1; st = ST_NEW; }
@@ -588,12 +588,12 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
                 intensity_contribution(P, L, rng, nested, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, comp, order);
               if (P.useRR && w < 0.5f) {                                  // :673-680
                 didRoulette = true;
-                if (rng.next() >= w / 1.0f) w = 0.0f; else w = 1.0f;
+                if (rng.spare() >= w / 1.0f) w = 0.0f; else w = 1.0f;
               }
               if (w <= kTiny) { if (REPLAY) fate = 2; st = ST_NEW; }
               else {
                 const CompTables ct = GENERAL ? P.comp[comp - 1] : P.comp0;
-                const float cosS = scattering_cosine(rng.next(), ct.invCos + (size_t)(pfi - 1) * ct.nInv, ct.nInv,
+                const float cosS = scattering_cosine(rng.first(), ct.invCos + (size_t)(pfi - 1) * ct.nInv, ct.nInv,
                                                      refined_rcp((float)ct.nInv));
                 next_direct(rng, cosS, r.dx, r.dy, r.dz);                 // :684-687
                 st = ST_TRACE;
@@ -605,7 +605,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
         }
         PROF_SEG(4);
         if (st == ST_TRACE) {                                             // :480
-          const float tau = -sample_log(fmaxf(kTiny, rng.next()));
+          const float tau = -sample_log(fmaxf(kTiny, rng.path()));
           r.acc = 0.0f; r.target = tau;
           if (rayTracing) { startedTrace = true; r.set_direction(L); }
           else {                                                          // :494-496 max cross-section move
@@ -745,9 +745,10 @@ __global__ void philox_kernel(uint32_t seed0, uint32_t seed1, long long firstPho
   for (int b = 0; b < blocksPerPhoton; ++b) {
     const Philox4 o = philox4x32_10(g.id_lo, g.id_hi, (uint32_t)b, 0u, seed0, seed1);
     g.begin_event();   // block b of the stream, as the photon kernel draws it
+    const float roles[4] = {g.first(), g.second(), g.path(), g.spare()};
     for (int k = 0; k < 4; ++k) {
       out[(i * blocksPerPhoton + b) * 4 + k] = o.v[k];
-      outf[(i * blocksPerPhoton + b) * 4 + k] = g.next();
+      outf[(i * blocksPerPhoton + b) * 4 + k] = roles[k];
     }
   }
 }

@@ -39,33 +39,42 @@ __host__ __device__ inline float u32_to_unit_float(uint32_t u) {
 }
 
 // Per-lane stream.  begin_event() makes one Philox block (4 deviates) for the whole wavefront at ONE program point,
-// so the 10-round block function runs once per event with every lane active; next() then only selects from the
-// buffered words.  (Refilling lazily inside next() ran the block function at ~9 % lane utilisation, because lanes
-// drift to different buffer phases and every call site refills for whoever happens to be empty.)  An event that
-// needs a fifth deviate (component choice + roulette + angle + azimuth + optical depth) refills on demand.
+// so the 10-round block function runs once per event with every lane active.  (Refilling lazily ran the block
+// function at ~9 % lane utilisation, because lanes drift to different buffer phases and every call site refills for
+// whoever happens to be empty.)  The four words of an event's block have fixed roles:
+//   first()   scattering angle  | start x of a new photon | cosine of a surface reflection
+//   second()  azimuth           | start y                 | azimuth of a surface reflection
+//   path()    optical depth to the next event
+//   spare()   Russian roulette
+// so that no run-time cursor has to be consulted for them.  Whatever else an event needs (component choice, the
+// max-cross-section test, a retry, the local estimate's roulette) comes from next(), a cursor over further blocks of
+// the same photon.  Which word serves which purpose is this code's own convention: the production streams are not the
+// reference's Mersenne Twister sequence anyway, and every production kernel follows the same convention (tests
+// compare them photon by photon).  The replay stream hands out the reference's deviates in the reference's order.
 struct PhiloxStream {
   static constexpr bool kReplay = false;
   uint32_t k0, k1;           // key: the same for every photon of a launch (wave-uniform, lives in scalar registers)
   uint32_t id_lo, id_hi, block;
-  uint32_t b0, b1, b2, b3;   // current block
-  int have;                  // unused words of the block: next() hands out b[4 - have]
-  uint32_t used;             // deviates consumed by this lane in blocks already retired (all its photons)
+  uint32_t e0, e1, e2, e3;   // the event's block
+  uint32_t b0, b1, b2, b3;   // block behind next()
+  int have;                  // unused words of that block: next() hands out b[4 - have]
+  uint32_t used;             // deviates consumed by this lane (all its photons)
 
   // once per lane, in uniform control flow
   __device__ inline void init(uint32_t seed0, uint32_t seed1) {
     k0 = seed0; k1 = seed1;
-    id_lo = id_hi = 0u; block = 0u; have = 4; used = 0u; b0 = b1 = b2 = b3 = 0u;
+    id_lo = id_hi = 0u; block = 0u; have = 0; used = 0u; b0 = b1 = b2 = b3 = 0u; e0 = e1 = e2 = e3 = 0u;
   }
-  // next photon of this lane; what is left of the previous photon's block is retired by the begin_event() that follows
+  // next photon of this lane
   __device__ inline void start(uint64_t photon) {
     id_lo = (uint32_t)photon; id_hi = (uint32_t)(photon >> 32);
-    block = 0u;
+    block = 0u; have = 0;
   }
   __device__ inline void close() {}
   __device__ inline uint32_t draws_of_photon() const { return 0u; }   // per-photon records are a replay-stream feature
   // deviates consumed by this lane so far (kernel epilogue)
-  __device__ inline uint32_t total() const { return used + (4u - (uint32_t)have); }
-  __device__ inline void refill() {
+  __device__ inline uint32_t total() const { return used; }
+  __device__ inline Philox4 make_block() {
     // The key is wave-uniform; the empty asm makes it opaque here so that the ten round keys (k + r W) are made by
     // scalar adds next to their use instead of being hoisted out of the photon loop into twenty scalar registers
     // (which then spill).
@@ -73,16 +82,25 @@ struct PhiloxStream {
     asm volatile("" : "+s"(s0), "+s"(s1));
     const Philox4 o = philox4x32_10(id_lo, id_hi, block, 0u, s0, s1);
     block++;
-    b0 = o.v[0]; b1 = o.v[1]; b2 = o.v[2]; b3 = o.v[3];
-    have = 4;
+    return o;
   }
-  // fresh block for this event; leftovers of the previous block are dropped (blocks are cheap per lane when the
-  // whole wave computes them together, expensive when a few lanes do)
-  __device__ inline void begin_event() { used += 4u - (uint32_t)have; refill(); }
+  __device__ inline void begin_event() {
+    const Philox4 o = make_block();
+    e0 = o.v[0]; e1 = o.v[1]; e2 = o.v[2]; e3 = o.v[3];
+  }
+  __device__ inline float first()  { used++; return u32_to_unit_float(e0); }
+  __device__ inline float second() { used++; return u32_to_unit_float(e1); }
+  __device__ inline float path()   { used++; return u32_to_unit_float(e2); }
+  __device__ inline float spare()  { used++; return u32_to_unit_float(e3); }
   __device__ inline float next() {
-    if (__builtin_expect(have == 0, 0)) { used += 4u; refill(); }   // inline: an out-of-line call costs scratch spills at every site (measured -13 %)
+    if (__builtin_expect(have == 0, 0)) {   // inline: an out-of-line call costs scratch spills at every site (measured -13 %)
+      const Philox4 o = make_block();
+      b0 = o.v[0]; b1 = o.v[1]; b2 = o.v[2]; b3 = o.v[3];
+      have = 4;
+    }
     const uint32_t u = have == 4 ? b0 : (have == 3 ? b1 : (have == 2 ? b2 : b3));
     have--;
+    used++;
     return u32_to_unit_float(u);
   }
   // Azimuth for next_direct (:2099-2103).  The reference rejection-samples a point of the unit disc (2 deviates per
@@ -90,7 +108,7 @@ struct PhiloxStream {
   // the hardware sin/cos (arguments in revolutions) give the same distribution with no divergent retry loop; d
   // carries the actual squared radius so next_direct's normalisation stays exact.
   __device__ inline void disc_point(float &ax, float &ay, float &d) {
-    const float turn = next();
+    const float turn = second();
     ax = __builtin_amdgcn_cosf(turn);
     ay = __builtin_amdgcn_sinf(turn);
     d = ax * ax + ay * ay;
@@ -102,12 +120,12 @@ struct ReplayStream {
   static constexpr bool kReplay = true;   // consume deviates exactly where the reference does
   const float *buf;
   int64_t pos, end;
-  int64_t first;
+  int64_t photonStart;
   uint32_t closed;           // deviates consumed by the photons this lane has finished
-  __device__ inline void init(const float *b, int64_t e) { buf = b; end = e; pos = first = 0; closed = 0u; }
-  __device__ inline void start(int64_t p) { pos = p; first = p; }
-  __device__ inline uint32_t draws_of_photon() const { return (uint32_t)(pos - first); }
-  __device__ inline void close() { closed += draws_of_photon(); first = pos; }
+  __device__ inline void init(const float *b, int64_t e) { buf = b; end = e; pos = photonStart = 0; closed = 0u; }
+  __device__ inline void start(int64_t p) { pos = p; photonStart = p; }
+  __device__ inline uint32_t draws_of_photon() const { return (uint32_t)(pos - photonStart); }
+  __device__ inline void close() { closed += draws_of_photon(); photonStart = pos; }
   __device__ inline uint32_t total() const { return closed; }
   __device__ inline void begin_event() {}
   __device__ inline float next() {
@@ -115,6 +133,11 @@ struct ReplayStream {
     pos++;
     return r;
   }
+  // the reference draws everything from one sequence: the roles of PhiloxStream are plain draws, in call order
+  __device__ inline float first() { return next(); }
+  __device__ inline float second() { return next(); }
+  __device__ inline float path() { return next(); }
+  __device__ inline float spare() { return next(); }
   // the reference's own rejection sampling, deviate for deviate (next_direct :2098-2103)
   __device__ inline void disc_point(float &ax, float &ay, float &d) {
     d = 2.0f;

@@ -141,6 +141,7 @@ __global__ void __launch_bounds__(256, 4) photon_pool_kernel(const DevProblem P,
       const unsigned long long photon = (unsigned long long)A.firstPhoton + index;
       rng.id_lo = (uint32_t)photon; rng.id_hi = (uint32_t)(photon >> 32);
       rng.block = __float_as_uint(ph[F_BLOCK * kPool]);
+      rng.have = 0;   // next() (retries only) starts on a block of this photon, never on another photon's leftovers
     }
     // ---- part A: endings that need no random number (tracer drop, exit through the top, arrival at a black surface)
     const bool isEv = st == ST_EVENT;
@@ -192,7 +193,7 @@ __global__ void __launch_bounds__(256, 4) photon_pool_kernel(const DevProblem P,
     if (active && st != ST_DONE) {
       rng.begin_event();
       if (st == ST_NEW) {                                               // :453-470, newPhotonStream_Directional :91-99
-        const float px = rng.next(), py = rng.next();
+        const float px = rng.first(), py = rng.second();
         dx = A.solarDx; dy = A.solarDy; dz = A.solarDz;
         w = 1.0f;
         x = P.x0 + px * (P.xMax - P.x0);
@@ -212,9 +213,9 @@ __global__ void __launch_bounds__(256, 4) photon_pool_kernel(const DevProblem P,
           iz = 1;
           z = surfaceZ;
           tally.down((iy - 1) * P.nx + (ix - 1), w);
-          float mu;
-          do { mu = exact_sqrt(rng.next()); } while (!(fabsf(mu) > 2.0f * kTiny));
-          const float phi = (2.0f * kPi) * rng.next();
+          float mu = exact_sqrt(rng.first());
+          while (!(fabsf(mu) > 2.0f * kTiny)) mu = exact_sqrt(rng.next());
+          const float phi = (2.0f * kPi) * rng.second();
           w = w * P.albedo;
           if (w <= kTiny) st = ST_NEW;
           else { make_dircos(mu, phi, dx, dy, dz); st = ST_TRACE; }
@@ -246,14 +247,14 @@ __global__ void __launch_bounds__(256, 4) photon_pool_kernel(const DevProblem P,
           }
           if (P.useRR && w < 0.5f) {                                    // :673-680
             didRoulette = true;
-            if (rng.next() >= w / 1.0f) w = 0.0f; else w = 1.0f;
+            if (rng.spare() >= w / 1.0f) w = 0.0f; else w = 1.0f;
           }
           if (w <= kTiny) st = ST_NEW;
           else {
             int pfi;
             if (P.uniformPf >= 1) pfi = P.uniformPf; else pfi = max(P.pfIndex[cell], 1);
             const CompTables ct = P.comp0;
-            const float cosS = scattering_cosine(rng.next(), ct.invCos + (size_t)(pfi - 1) * ct.nInv, ct.nInv,
+            const float cosS = scattering_cosine(rng.first(), ct.invCos + (size_t)(pfi - 1) * ct.nInv, ct.nInv,
                                                  refined_rcp((float)ct.nInv));
             next_direct(rng, cosS, dx, dy, dz);                         // :684-687
             st = ST_TRACE;
@@ -261,7 +262,7 @@ __global__ void __launch_bounds__(256, 4) photon_pool_kernel(const DevProblem P,
         }
       }
       if (st == ST_TRACE) {                                             // :480
-        target = -sample_log(fmaxf(kTiny, rng.next()));
+        target = -sample_log(fmaxf(kTiny, rng.path()));
         startedTrace = true;
         ph[F_DX * kPool] = dx; ph[F_DY * kPool] = dy; ph[F_DZ * kPool] = dz;
         ph[F_RX * kPool] = refined_rcp(dx); ph[F_RY * kPool] = refined_rcp(dy); ph[F_RZ * kPool] = refined_rcp(dz);
