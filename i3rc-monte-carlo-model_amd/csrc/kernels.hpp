@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
       // ---- part C: one random block per lane for this event, then the event itself
       bool didScatter = false, didRoulette = false, startedTrace = false;   // per-lane flags -> wave counters below
       if (wantEvent && st != ST_DONE) {
-        rng.begin_event();
+        rng.begin_event(DEFER_BUILD && P.useRRI != 0);   // the local estimate's roulette draws after the event
         PROF_SEG(2);
         if (st == ST_NEW) {                                               // :453-470
           float px, py, pz;

@@ -84,9 +84,16 @@ struct PhiloxStream {
     block++;
     return o;
   }
-  __device__ inline void begin_event() {
+  // withCursor: also fill the block behind next() now, while the whole wave is at it, for the draws that follow the
+  // event at a few lanes a time (the local estimate's roulette in the light phase: refilling there cost 30 %)
+  __device__ inline void begin_event(bool withCursor = false) {
     const Philox4 o = make_block();
     e0 = o.v[0]; e1 = o.v[1]; e2 = o.v[2]; e3 = o.v[3];
+    if (withCursor) {
+      const Philox4 c = make_block();
+      b0 = c.v[0]; b1 = c.v[1]; b2 = c.v[2]; b3 = c.v[3];
+      have = 4;
+    }
   }
   __device__ inline float first()  { used++; return u32_to_unit_float(e0); }
   __device__ inline float second() { used++; return u32_to_unit_float(e1); }
@@ -127,7 +134,7 @@ struct ReplayStream {
   __device__ inline uint32_t draws_of_photon() const { return (uint32_t)(pos - photonStart); }
   __device__ inline void close() { closed += draws_of_photon(); photonStart = pos; }
   __device__ inline uint32_t total() const { return closed; }
-  __device__ inline void begin_event() {}
+  __device__ inline void begin_event(bool = false) {}
   __device__ inline float next() {
     float r = pos < end ? buf[pos] : 0.5f;
     pos++;

@@ -6,7 +6,7 @@ import i3rc_monte_carlo_model_amd as M
 from i3rc_monte_carlo_model_amd import build as BLD
 from tests import cases
 
-prof = os.path.join(BLD.CSRC, "libi3rc_hip_prof.so")
+prof = os.path.join(BLD.CSRC, os.environ.get("PROF_LIB", "libi3rc_hip_prof.so"))
 if "--build" in sys.argv or not os.path.exists(prof):
     subprocess.check_call([BLD.hipcc()] + BLD.HIPCC_FLAGS + ["-DI3RC_PROFILE_PHASES", "-o", prof, os.path.join(BLD.CSRC, "i3rc_hip.hip")])
     if "--build" in sys.argv:

@@ -5,6 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import i3rc_monte_carlo_model_amd as M
 from tests import cases
 
+if os.environ.get("I3RC_LIB"):   # another build of the library (A/B comparisons)
+    M.build.LIB = os.path.abspath(os.environ["I3RC_LIB"]); M.build.needs_build = lambda: False
+
 hg64 = lambda: M.PhaseFunctionTable([M.henyey_greenstein(0.85, 64)])
 hg299 = lambda: M.PhaseFunctionTable([M.henyey_greenstein(0.85, 299)])
 nadir = dict(intensityMus=[1.0], intensityPhis=[0.0], useRussianRouletteForIntensity=True, zetaMin=0.3)
@@ -30,6 +33,7 @@ d = make()
 dom = M.new_Domain(d["xe"], d["ye"], d["ze"]); dom.addOpticalComponent("cloud", d["ext"], d["ssa"], d["pf"], table())
 g = M.new_Integrator(dom); g.specifyParameters(minInverseTableSize=10001, minForwardTableSize=10001, **kw)
 g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 0)), M.new_PhotonStream(mu0, 0.0, 1))   # tables
-r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 1)), M.new_PhotonStream(mu0, 0.0, n))
+seed = int(os.environ.get("BATCH", "1"))
+r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, seed)), M.new_PhotonStream(mu0, 0.0, n))
 c = r["counters"]
 print(f"{name}: {n / g.kernel_ms() * 1e3:.3e} photons/s ({g.kernel_ms():.2f} ms, {n} photons) S={(c['cellSteps'] + c['shadowSteps']) / n:.1f} K={c['scatterings'] / n:.1f}")
