@@ -209,3 +209,38 @@ def test_max_cross_section_with_radiances(oracle):
     g, o = _intensity_pair(oracle, d, hg_table(), gpu_params=gp, oracle_params=op, mus=[1.0, 0.5], phis=[0.0, 90.0])
     gr, orr = _parity(oracle, g, o, 8, 6000, 0.8, az=15.0, keys=("fluxUp", "fluxDown", "fluxAbsorbed", "intensity"))
     assert sum(r["counters"]["shadowSteps"] for r in gr) > 0
+
+
+def test_random_general_domains_against_the_oracle(oracle):
+    # the general kernel on random inputs: irregular grids of random size with holes, one or two components with
+    # one or two table entries each, flux and radiance (plain / Iwabuchi roulette), random sun and surface
+    rng = np.random.default_rng(99)
+    t_cloud = M.PhaseFunctionTable([M.henyey_greenstein(0.85, 32), M.henyey_greenstein(0.6, 16)])
+    t_gas = M.PhaseFunctionTable([M.PhaseFunction(legendre=np.array([0.0, 0.1], np.float32))])
+    for case in range(10):
+        seed = int(rng.integers(1, 10 ** 6))
+        two = case % 2 == 1
+        if two:
+            d = cases.two_component(seed=seed, nx=int(rng.integers(2, 9)), ny=int(rng.integers(1, 6)), nz=8)
+            tabs = [t_cloud, t_gas]
+        else:
+            d = cases.irregular_domain(seed=seed, nx=int(rng.integers(1, 12)), ny=int(rng.integers(1, 8)), nz=int(rng.integers(2, 14)),
+                                       ssa=float(rng.choice([1.0, 0.95, 0.7])))
+            tabs = hg_table()
+        albedo, mu0, az = float(rng.choice([0.0, 0.4, 1.0])), float(rng.uniform(0.1, 1.0)), float(rng.uniform(0, 360))
+        if case % 3 == 0:      # flux only
+            g = make_gpu(d, tabs, surfaceAlbedo=albedo)
+            inv = [t.inverse_table(9001) for t in (tabs if isinstance(tabs, list) else [tabs])]
+            for c, t in enumerate(inv):
+                g.set_tables(c + 1, inverse=t)
+            o = make_oracle(oracle, d, inv)
+            o.specify(surfaceAlbedo=albedo)
+            _parity(oracle, g, o, 6, 6000, mu0, az=az, keys=("fluxUp", "fluxDown", "fluxAbsorbed"), floor=1e-6)
+        else:
+            rr = case % 3 == 1
+            mus = [float(v) for v in rng.uniform(0.2, 1.0, 2) * rng.choice([-1, 1], 2)]
+            phis = [float(v) for v in rng.uniform(0, 360, 2)]
+            gp = dict(surfaceAlbedo=albedo, useRussianRouletteForIntensity=rr, zetaMin=0.3)
+            op = dict(surfaceAlbedo=albedo, useRRForIntensity=int(rr), zetaMin=0.3)
+            g, o = _intensity_pair(oracle, d, tabs, gpu_params=gp, oracle_params=op, mus=mus, phis=phis)
+            _parity(oracle, g, o, 6, 6000, mu0, az=az, keys=("fluxUp", "fluxDown", "intensity"), floor=1e-6)
