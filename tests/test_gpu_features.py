@@ -281,8 +281,13 @@ def test_replay_reference_random_stream_with_radiances_components_and_surfaces(o
         ("BRDF grid", cases.step_cloud(ssa=1.0, nlayers=8), hg_table(),
          dict(surfaceBDRF=M.new_SurfaceDescription(alb.T[None].copy(), xs, ys)), dict(surfaceBDRF=(xs, ys, alb)), 0.99),
     ]
+    configs.append(("hybrid phase function + contribution limit", cases.step_cloud(ssa=1.0, nlayers=8), hg_table(0.95, 299),
+                    dict(useHybridPhaseFunsForIntenCalcs=True, hybridPhaseFunWidth=7.0, numOrdersOrigPhaseFunIntenCalcs=1,
+                         limitIntensityContributions=True, maxIntensityContribution=0.5),
+                    dict(useHybrid=1, numOrdersOrig=1, limitContrib=1, maxContrib=0.5), 0.99))
     for name, d, tab, gp, op, agree in configs:
-        g, o = _intensity_pair(oracle, d, tab, gpu_params=gp, oracle_params=op, mus=[1.0, 0.5, -0.6], phis=[0.0, 40.0, 200.0])
+        g, o = _intensity_pair(oracle, d, tab, gpu_params=gp, oracle_params=op, mus=[1.0, 0.5, -0.6], phis=[0.0, 40.0, 200.0],
+                               hybrid_width=7.0 if "hybrid" in name else None)
         n = 6000
         ref, out = _replay_pair(oracle, g, o, n, [10, 3], 0.7, 25.0)
         used_ref = np.diff(ref["drawStart"])
