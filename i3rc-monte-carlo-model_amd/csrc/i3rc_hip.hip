@@ -539,12 +539,19 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
   // the specialised kernels exist once per place of the extinction grid (LDS / global / global in bricks)
   using Kernel = void (*)(DevProblem, RunArgs, int, int);
   const int place = plan.P.ldsGrid ? GRID_LDS : (plan.P.extBrick ? GRID_BRICKS : GRID_GLOBAL);
-  static const Kernel special[2][3] = {
-      {photon_kernel<Rng, false, false, GRID_LDS>, photon_kernel<Rng, false, false, GRID_GLOBAL>, photon_kernel<Rng, false, false, GRID_BRICKS>},
-      {photon_kernel<Rng, true, false, GRID_LDS>, photon_kernel<Rng, true, false, GRID_GLOBAL>, photon_kernel<Rng, true, false, GRID_BRICKS>}};
-  Kernel kern = simple ? special[plan.intensity ? 1 : 0][place]
-                       : (plan.intensity ? photon_kernel<Rng, true, true, GRID_ANY> : photon_kernel<Rng, false, true, GRID_ANY>);
-  const void *fn = pool ? (const void *)photon_pool_kernel : (const void *)kern;
+  static const Kernel general[2][3] = {
+      {photon_kernel<Rng, false, true, GRID_LDS>, photon_kernel<Rng, false, true, GRID_GLOBAL>, photon_kernel<Rng, false, true, GRID_BRICKS>},
+      {photon_kernel<Rng, true, true, GRID_LDS>, photon_kernel<Rng, true, true, GRID_GLOBAL>, photon_kernel<Rng, true, true, GRID_BRICKS>}};
+  Kernel kern = general[plan.intensity ? 1 : 0][place];
+  if constexpr (!Rng::kReplay) {   // (the replay build always runs the general kernel)
+    static const Kernel special[2][3] = {
+        {photon_kernel<Rng, false, false, GRID_LDS>, photon_kernel<Rng, false, false, GRID_GLOBAL>, photon_kernel<Rng, false, false, GRID_BRICKS>},
+        {photon_kernel<Rng, true, false, GRID_LDS>, photon_kernel<Rng, true, false, GRID_GLOBAL>, photon_kernel<Rng, true, false, GRID_BRICKS>}};
+    if (simple) kern = special[plan.intensity ? 1 : 0][place];
+  }
+  using PoolKernel = void (*)(DevProblem, RunArgs);
+  static const PoolKernel pools[3] = {photon_pool_kernel<GRID_LDS>, photon_pool_kernel<GRID_GLOBAL>, photon_pool_kernel<GRID_BRICKS>};
+  const void *fn = pool ? (const void *)pools[place] : (const void *)kern;
   int perCU = h->blocksPerCU;
   if (perCU <= 0) {
     int occ = 0;
@@ -561,7 +568,7 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
   HIPCHK(h, hipMemsetAsync(A.workCounter, 0, sizeof(unsigned long long), h->stream));
   const int slot = (int)(h->timedLaunches % i3rc_hip_integrator::kEventRing);
   if (timeIt) HIPCHK(h, hipEventRecord(h->evStart[slot], h->stream));
-  if (pool) hipLaunchKernelGGL(photon_pool_kernel, dim3((unsigned)blocks), dim3(256), plan.ldsBytes, h->stream, plan.P, B);
+  if (pool) hipLaunchKernelGGL(pools[place], dim3((unsigned)blocks), dim3(256), plan.ldsBytes, h->stream, plan.P, B);
   else {
     // thresholds the caller did not fix are adapted per wave (photon_kernel); negative = adaptive, starting value
     const int evThreshold = h->evThreshold > 0 ? h->evThreshold : -40;

@@ -70,7 +70,7 @@ struct Tally {
 };
 
 // computeIntensityContribution :1419-1611 for one event; adds straight into intensityByComponent.
-template <class Rng>
+template <int GRID, class Rng>
 __device__ __forceinline__ void intensity_contribution(const DevProblem &P, const Lds &L, Rng &rng, NestedCounters &cnt,
                                                        float weight, float x, float y, float z, int ix, int iy, int iz,
                                                        float dx, float dy, float dz, int component, int order) {
@@ -96,32 +96,37 @@ __device__ __forceinline__ void intensity_contribution(const DevProblem &P, cons
     Ray r;
     r.x = x; r.y = y; r.z = z; r.ix = ix; r.iy = iy; r.iz = iz; r.dx = ux; r.dy = uy; r.dz = uz;
     r.set_direction(L);
-    float con;
-    auto run = [&](bool hasTarget, float target) {
-      r.acc = 0.0f; r.target = target;
-      cnt.calls++;
-      StepResult s;
-      do { cnt.shadow++; s = trace_step(P, L, r, hasTarget); } while (s == STEP_CONTINUE);
-      return r.acc;
-    };
-    if (!P.useRRI) {
-      const float tauB = run(false, 0.0f);
-      con = tauB >= 0.0f ? (weight * normPF) * expf(-tauB) : 0.0f;
-    } else {
-      const float tauFree = -logf(fmaxf(kTiny, rng.next()));
-      if (kPi * normPF <= P.zetaMin) {
-        (void)run(true, tauFree);
+    // ONE loop over the voxel steps of all the legs of this direction, the legs told apart by `stage` as in the light
+    // phase of photon_kernel (0: plain local estimate, 1: small contribution, 2 / 3: the two legs of a large one).
+    // Two loops one after the other (first leg, second leg) are what the compiler mishandled: see GridPlace.
+    int stage = 0;
+    float tauFree = 0.0f;
+    r.acc = 0.0f; r.target = 0.0f;
+    if (P.useRRI) {
+      tauFree = -logf(fmaxf(kTiny, rng.next()));
+      if (kPi * normPF <= P.zetaMin) { stage = 1; r.target = tauFree; }
+      else { stage = 2; r.target = -logf(P.zetaMin / fmaxf(kTiny, kPi * normPF)); }   // tauMax
+    }
+    cnt.calls++;
+    float con = 0.0f;
+    for (;;) {
+      cnt.shadow++;
+      if (trace_step<GRID>(P, L, r, stage != 0) == STEP_CONTINUE) continue;
+      const float tauB = r.acc;
+      const bool outTop = r.iz >= zIndexMax;
+      if (stage == 0) con = tauB >= 0.0f ? (weight * normPF) * expf(-tauB) : 0.0f;
+      else if (stage == 1) {
         const float r2 = rng.next();
-        con = (r2 <= kPi * normPF / P.zetaMin && r.iz >= zIndexMax) ? weight * P.zetaMin / kPi : 0.0f;
-      } else {
-        const float tauMax = -logf(P.zetaMin / fmaxf(kTiny, kPi * normPF));
-        float tauB = run(true, tauMax);
-        if (r.iz >= zIndexMax && tauB >= 0.0f) con = (weight * normPF) * expf(-tauB);
-        else if (tauB >= 0.0f) {
-          (void)run(true, tauFree);
-          con = r.iz >= zIndexMax ? weight * P.zetaMin / kPi : 0.0f;
-        } else con = 0.0f;
-      }
+        con = (r2 <= kPi * normPF / P.zetaMin && outTop) ? weight * P.zetaMin / kPi : 0.0f;
+      } else if (stage == 2) {
+        if (outTop && tauB >= 0.0f) con = (weight * normPF) * expf(-tauB);
+        else if (tauB >= 0.0f && r.iz >= 1) {   // second leg, up to the free path (not from below the grid: see the light phase)
+          r.acc = 0.0f; r.target = tauFree; stage = 3;
+          cnt.calls++;
+          continue;
+        }
+      } else con = outTop ? weight * P.zetaMin / kPi : 0.0f;
+      break;
     }
     if (P.limitContrib && con > P.maxContrib) {
       add_global(P.tally + P.oExc + component * P.nDir + d, con - P.maxContrib);
@@ -171,7 +176,7 @@ struct Reservoir {
 // re-wrapping loops, max-cross-section moves, BRDF lookups, component selection) are compiled out, which shrinks the
 // loop's code and its scalar-register pressure.  GENERAL = true keeps every path behind run-time switches.
 // (the general radiance kernel keeps the most state live: 4 waves per SIMD give it 128 vector registers and no spills)
-template <class Rng, bool INTENSITY, bool GENERAL, int GRID = GRID_ANY>
+template <class Rng, bool INTENSITY, bool GENERAL, int GRID>
 __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAVES) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
@@ -197,7 +202,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
   for (int i = threadIdx.x; i <= P.nz; i += blockDim.x) L.zE[i] = P.zE[i];
   if (P.ldsTallies)
     for (int i = threadIdx.x; i < 3 * P.nx * P.ny; i += blockDim.x) L.tUp[i] = 0.0f;
-  if (GRID == GRID_ANY ? (P.ldsGrid != 0) : GRID == GRID_LDS) {
+  if (GRID == GRID_LDS) {
     const int ncell = P.nx * P.ny * P.nz;
     for (int i = threadIdx.x; i < ncell; i += blockDim.x) L.ext[i] = P.totalExt[i];
   }
@@ -331,9 +336,12 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
               con = (r2 <= kPi * normPF / P.zetaMin && outTop) ? wI * P.zetaMin / kPi : 0.0f;
             } else if (stage == 2) {
               if (outTop && tauB >= 0.0f) con = (wI * normPF) * expf(-tauB);
-              else if (tauB >= 0.0f) {                                   // second leg, up to the free path (:1576-1587)
+              else if (tauB >= 0.0f && r.iz >= 1) {                      // second leg, up to the free path (:1576-1587)
                 r.acc = 0.0f; r.target = tauFree; stage = 3; st = ST_SHADOW;
               }
+              // (a first leg that left through the BOTTOM -- a downward radiance direction -- gets no second leg: the
+              // reference starts one from outside the grid, reads zPosition(0) / totalExt(:, :, 0) out of bounds and
+              // discards the outcome, since only an exit through the top counts; the contribution is 0 either way)
             } else con = outTop ? wI * P.zetaMin / kPi : 0.0f;
             if (st == ST_LIGHT) {
               const int comp = __float_as_int(park[13 * 256]) & 0xff;
@@ -524,7 +532,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
                 pendingShadow = true; wI = w;
                 L.park[13 * 256 + threadIdx.x] = __int_as_float(0);     // component 0: the surface
               } else if (INTENSITY)
-                intensity_contribution(P, L, rng, nested, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, 0, order);
+                intensity_contribution<GRID>(P, L, rng, nested, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, 0, order);
               st = ST_TRACE;
             }
           } else {                                                        // :581-689
@@ -585,7 +593,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
                 park[13 * 256] = __int_as_float(comp | useOrig);
                 park[14 * 256] = __int_as_float(pfi);
               } else if (INTENSITY)
-                intensity_contribution(P, L, rng, nested, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, comp, order);
+                intensity_contribution<GRID>(P, L, rng, nested, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, comp, order);
               if (P.useRR && w < 0.5f) {                                  // :673-680
                 didRoulette = true;
                 if (rng.spare() >= w / 1.0f) w = 0.0f; else w = 1.0f;
@@ -716,7 +724,7 @@ __global__ void __launch_bounds__(256) trace_rays_kernel(const DevProblem P, lon
   r.target = target[i];
   int ns = 0;
   StepResult s;
-  do { ns++; s = trace_step(P, L, r, hasTarget); } while (s == STEP_CONTINUE && ns < (1 << 24));
+  do { ns++; s = trace_step<GRID_BRICKS>(P, L, r, hasTarget); } while (s == STEP_CONTINUE && ns < (1 << 24));
   pos[3 * i] = r.x; pos[3 * i + 1] = r.y; pos[3 * i + 2] = r.z;
   idx[3 * i] = r.ix; idx[3 * i + 1] = r.iy; idx[3 * i + 2] = r.iz;
   tau[i] = r.acc;

@@ -29,6 +29,7 @@ enum PoolField { F_X = 0, F_Y, F_Z, F_DX, F_DY, F_DZ, F_RX, F_RY, F_RZ, F_IX, F_
 constexpr int kPoolWordsPerWave = kPoolFields * kPool;
 constexpr int kPoolBytesPerBlock = 4 * kPoolWordsPerWave * 4;   // 4 waves
 
+template <int GRID>
 __global__ void __launch_bounds__(256, 4) photon_pool_kernel(const DevProblem P, const RunArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
@@ -113,7 +114,7 @@ __global__ void __launch_bounds__(256, 4) photon_pool_kernel(const DevProblem P,
           r.cx = px ? 1 : -1; r.cy = py ? 1 : -1; r.cz = pz ? 1 : -1;
           r.nudge = px ? 2.0f : -2.0f;
         }
-        const StepResult s = trace_step(P, L, r, true);
+        const StepResult s = trace_step<GRID>(P, L, r, true);
         ph[F_X * kPool] = r.x; ph[F_Y * kPool] = r.y; ph[F_Z * kPool] = r.z;
         ph[F_IX * kPool] = __int_as_float(r.ix); ph[F_IY * kPool] = __int_as_float(r.iy); ph[F_IZ * kPool] = __int_as_float(r.iz);
         ph[F_ACC * kPool] = r.acc;
@@ -222,7 +223,7 @@ __global__ void __launch_bounds__(256, 4) photon_pool_kernel(const DevProblem P,
         } else {                                                        // :581-689
           didScatter = true;
           int cell = cell_index(P, ix, iy, iz);
-          const float extHere = cell_extinction(P, L, ix, iy, iz);
+          const float extHere = cell_extinction<GRID>(P, L, ix, iy, iz);
           if (extHere <= 0.0f) {                                        // :606-632 (quirk Q2 kept)
             x = ph[F_X * kPool]; y = ph[F_Y * kPool];
             movedXY = true;

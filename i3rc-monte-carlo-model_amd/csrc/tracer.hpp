@@ -212,18 +212,19 @@ __device__ __forceinline__ int brick_index(const DevProblem &P, int ix, int iy, 
 // extinction of the cell a ray is in: LDS copy when the grid fits; else global memory -- the plain field while it
 // fits in an XCD's L2, the bricked copy beyond that (measured: Landsat 128x128x119, 7.8 MB, +29 % with bricks, fabric
 // traffic 18 KB -> per photon; radar 138 KB and Landsat-36 2.4 MB are 8-11 % faster without the longer index)
-// GRID says where at compile time (the specialised kernels are instantiated once per place, which takes the choice
-// and its scalar registers out of the voxel-step loop); GRID_ANY decides at run time.
-enum GridPlace { GRID_ANY = -1, GRID_LDS = 0, GRID_GLOBAL = 1, GRID_BRICKS = 2 };
-template <int GRID = GRID_ANY>
+// GRID says where, at COMPILE time: every kernel is instantiated once per place.  That takes the choice and its scalar
+// registers out of the voxel-step loop -- and it is a matter of correctness, not only of speed: with a run-time flag
+// tested inside the shadow-ray loops of the nested local estimate, the compiler (ROCm 7.2 LLVM, -O1 and -O3 alike)
+// materialised the flag's negation as a LANE MASK under the exec mask of one loop (v_cndmask 0/1 + v_cmp_ne) and
+// reused it in the next loop, whose active lanes were not all active there: those lanes took the LDS branch on a
+// grid that lives in global memory and read zeros (found by the replay tests on the I3RC radar / Landsat fields;
+// tests/test_build_isa.py keeps the pattern out of the kernels).
+enum GridPlace { GRID_LDS = 0, GRID_GLOBAL = 1, GRID_BRICKS = 2 };
+template <int GRID>
 __device__ __forceinline__ float cell_extinction(const DevProblem &P, const Lds &L, int ix, int iy, int iz) {
-  float ext;
-  const bool inLds = GRID == GRID_ANY ? (P.ldsGrid != 0) : GRID == GRID_LDS;
-  const bool bricks = GRID == GRID_ANY ? (P.extBrick != nullptr) : GRID == GRID_BRICKS;
-  if (inLds) ext = L.ext[cell_index(P, ix, iy, iz)];   // ds_read; a pointer select here would turn both into flat loads
-  else if (bricks) ext = P.extBrick[brick_index(P, ix, iy, iz)];
-  else ext = P.totalExt[cell_index(P, ix, iy, iz)];
-  return ext;
+  if (GRID == GRID_LDS) return L.ext[cell_index(P, ix, iy, iz)];   // ds_read
+  if (GRID == GRID_BRICKS) return P.extBrick[brick_index(P, ix, iy, iz)];
+  return P.totalExt[cell_index(P, ix, iy, iz)];
 }
 
 
@@ -232,7 +233,7 @@ __device__ __forceinline__ float cell_extinction(const DevProblem &P, const Lds 
 // escapes): on a 64-lane wavefront the lanes take the reference's if/else arms in every combination at every step,
 // so branches would execute both arms anyway and add exec-mask bookkeeping on top.  The arithmetic of each arm is
 // exactly the reference's (checked bit for bit against the oracle by the tracer tests).
-template <int GRID = GRID_ANY>
+template <int GRID>
 __device__ __forceinline__ StepResult trace_step(const DevProblem &P, const Lds &L, Ray &r, bool hasTarget) {
   // the extinction of the current cell is requested first: its latency (LDS, or L2 / HBM for grids that do not fit
   // in LDS) is covered by the three face-distance divisions below

@@ -248,11 +248,16 @@ static void intensity_contribution(const ctx_t *c, orc_tallies *t, float weight,
         tauB = orc_trace(p, dI, pos, idx, 1, tauMax, &t->cellSteps);
         if (idx[2] >= zIndexMax && tauB >= 0.0f) {
           con = (weight * normPF) * expf(-tauB);
-        } else if (tauB >= 0.0f) {
+        } else if (tauB >= 0.0f && idx[2] >= 1) {
           t->tracerCalls++;
           tauB = orc_trace(p, dI, pos, idx, 1, tauFree, &t->cellSteps);
           con = idx[2] >= zIndexMax ? weight * p->zetaMin / kPi : 0.0f;
         } else {
+          /* Tracer error, or the first leg left through the BOTTOM (idx[2] == 0, a radiance direction pointing down).
+             The reference starts its second leg from there all the same (:1576-1587) -- with zIndex 0 it indexes
+             zPosition(0) and totalExt(:, :, 0), out of bounds -- and then discards the outcome, because only an exit
+             through the top counts (:1583, quirk Q8).  The contribution is 0 either way; this restatement does not
+             reproduce the out-of-bounds reads. */
           con = 0.0f;
         }
       }

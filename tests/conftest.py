@@ -7,6 +7,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# One HIP / HSA runtime per process: PyTorch ships its own libamdhip64 + libhsa-runtime64, libi3rc_hip.so links
+# /opt/rocm's.  Whichever is loaded first serves both (same SONAMEs) -- but only torch-first works: with ROCm's
+# runtime already holding the device, torch's later initialisation finds "No HIP GPUs".  The tests that hand torch
+# tensors / streams to the C ABI (and bench.py, multigpu.py) therefore import torch before the library is loaded.
+try:
+    import torch  # noqa: F401
+except ImportError:   # the library itself does not need it
+    pass
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")

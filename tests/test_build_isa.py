@@ -1,0 +1,53 @@
+"""Build-time audit of the gfx950 code (no GPU needed: hipcc cross-compiles).
+
+ROCm 7.2's LLVM lowers the negation of a wave-uniform run-time flag that is tested in divergent code to a LANE MASK
+computed by VALU under the current exec mask (v_cndmask_b32 v, 0, 1, flag ; v_cmp_ne_u32 mask, 1, v): lanes that
+are inactive there get a 0 bit.  That is harmless while every use sits under a subset of that exec mask.  It is
+wrong when the pair is emitted inside an inner loop (whose exec mask shrinks as lanes leave it) and the mask is used
+after the loop: this happened to the nested local estimate when its two shadow-ray legs were two loops and the place
+of the extinction grid a run-time flag -- lanes that had left the first loop early took the LDS branch in the second
+one and read zeros (tests/test_gpu_features.py replay cases on the radar / Landsat fields).  The kernels are written
+so that the pattern does not arise in inner loops (grid place as a template parameter, one loop for all legs); this
+test keeps it that way."""
+import os
+import re
+import subprocess
+
+import i3rc_monte_carlo_model_amd as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _device_asm(tmp_path):
+    out = tmp_path / "i3rc_hip.s"
+    flags = [f for f in M.build.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    cmd = [M.build.hipcc()] + flags + ["--cuda-device-only", "-S", "-I", os.path.join(ROOT, "include"), "-o", str(out),
+                                       os.path.join(M.build.CSRC, "i3rc_hip.hip")]
+    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+    return out.read_text().split("\n")
+
+
+def test_no_exec_dependent_flag_masks_in_inner_loops(tmp_path):
+    lines = _device_asm(tmp_path)
+    kernel, depth, found, kernels = None, 0, [], 0
+    select = re.compile(r"v_cndmask_b32_e64 (v\d+), 0, 1, s\[\d+:\d+\]")
+    for i, line in enumerate(lines):
+        m = re.match(r"^(_ZN4i3rc\w+):", line)
+        if m:
+            kernel, depth = m.group(1), 0
+            kernels += 1
+        m = re.match(r"^\.LBB\d+_\d+:\s*(;.*)?$", line)
+        if m:   # a basic block: its loop depth is in the comment on the label (".LBBn_m: ; in Loop: Header=BBn_k
+            # Depth=d"; a loop header lists its parents first and itself last, over several comment lines)
+            depths, j = [int(x) for x in re.findall(r"Depth=(\d+)", line)], i + 1
+            while j < len(lines) and lines[j].lstrip().startswith(";"):
+                depths += [int(x) for x in re.findall(r"Depth=(\d+)", lines[j])]
+                j += 1
+            depth = max(depths) if depths else 0
+        m = select.search(line)
+        if m and kernel:
+            for nxt in lines[i + 1:i + 3]:
+                if re.search(r"v_cmp_ne_u32_e64 s\[\d+:\d+\], 1, " + m.group(1) + r"\b", nxt) and depth >= 2:
+                    found.append((kernel[:70], i + 1, depth))
+    assert kernels >= 20, kernels          # the scan saw the kernels at all
+    assert not found, found
