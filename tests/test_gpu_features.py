@@ -308,10 +308,8 @@ def test_replay_reference_random_stream_with_radiances_components_and_surfaces(o
         nd, ncol = 3, g.nx * g.ny
         gi = out["raw"][lay.intensityByComponent:lay.intensityByComponent + (g.ncomp + 1) * nd * ncol].sum()
         ri = float(np.asarray(ref["intensityByComp"], np.float64).sum())
-        # (not for the C1 phase function: its forward peak, P(0) = 1712, makes the sum a matter of a few rare events,
-        # and the handful of photons that part ways carry some of them)
-        if "C1" not in name:
-            assert abs(gi - ri) <= 0.01 * max(ri, 1e-3), (name, gi, ri)
+        print(f"   radiance sums gpu {gi:.6g} ref {ri:.6g}")
+        assert abs(gi - ri) <= 0.01 * max(ri, 1e-3), (name, gi, ri)
 
 
 def test_roulette_radiance_in_a_downward_direction_with_the_grid_in_global_memory(oracle):
