@@ -231,8 +231,8 @@ int i3rc_comm_init(int *numProcs, int *thisProc) {
     g_rank = env_int("RANK", "OMPI_COMM_WORLD_RANK", 0);
     g_local = env_int("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", g_rank);
     if (g_size < 1 || g_rank < 0 || g_rank >= g_size) return fail("i3rc_comm_init: inconsistent RANK / WORLD_SIZE");
-    if (g_size == 1) {
-      g_backend = NONE;
+    if (g_size == 1 && env_str("I3RC_COMM_BACKEND", "") != "rccl") {
+      g_backend = NONE;   // (a one-rank RCCL communicator on explicit request only: the GPU test of this backend)
     } else if (env_str("I3RC_COMM_BACKEND", "rccl") == "shm") {
       g_backend = SHM;
       if (shm_init()) return 1;
@@ -250,13 +250,13 @@ int i3rc_comm_init(int *numProcs, int *thisProc) {
 int i3rc_comm_local_device(void) { return g_backend == SHM ? 0 : g_local; }
 
 int i3rc_comm_sum_float(float *values, int64_t n) {
-  if (n <= 0 || g_size == 1 || !g_ready) return 0;
+  if (n <= 0 || g_backend == NONE || !g_ready) return 0;
   if (!values) return fail("i3rc_comm_sum_float: null buffer");
   return g_backend == RCCL ? rccl_sum(values, n) : shm_sum(values, n);
 }
 
 int i3rc_comm_barrier(void) {
-  if (g_size == 1 || !g_ready) return 0;
+  if (g_backend == NONE || !g_ready) return 0;
   if (g_backend == SHM) return shm_barrier();
   float one = 1.0f;
   return rccl_sum(&one, 1);

@@ -247,6 +247,17 @@ def test_shell_integrator_on_gpu():
 
 
 @pytest.mark.gpu
+def test_multiple_processes_module_over_rccl_one_rank():
+    # the RCCL backend of module MultipleProcesses on the real thing, as far as one GPU goes: a launcher environment of
+    # one rank -> TCP rendezvous with itself, ncclCommInitRank, every sumAcrossProcesses one ncclAllReduce on the GPU
+    exe = os.path.join(BUILD, "commSelfTest")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran shell not built")
+    rcs, outs = _spawn_ranks([exe], 1, 29641, extra_env=dict(I3RC_COMM_BACKEND="rccl"))
+    assert rcs == [0] and "rank 0 of 1 sums ok master=T" in outs[0], outs
+
+
+@pytest.mark.gpu
 def test_reference_drivers_run_unchanged_on_gpu(tmp_path):
     pp = os.path.join(BUILD, "planeParallel_ref")
     mc = os.path.join(BUILD, "monteCarloDriver_ref")
