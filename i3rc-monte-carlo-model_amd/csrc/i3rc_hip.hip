@@ -2,6 +2,7 @@
 #include "../../include/i3rc_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cmath>
@@ -19,14 +20,17 @@ namespace {
 
 thread_local std::string g_createError;
 
+// I3RC_POISON=1 (debugging aid): fresh device memory is filled with 0xFF bytes -- NaNs as floats, -1 as integers, wild
+// as pointers -- so that a read of memory nobody wrote shows in a fresh process and not only after other
+// allocations have left their contents behind.
+bool poison() { static const bool on = std::getenv("I3RC_POISON") != nullptr; return on; }
+
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
   ~DevBuf() { if (p) (void)hipFree(p); }
   hipError_t upload(const void *src, size_t n) {
-    if (p) { (void)hipFree(p); p = nullptr; }
-    bytes = n;
-    hipError_t e = hipMalloc(&p, n ? n : 4);
+    hipError_t e = alloc(n);
     if (e != hipSuccess) return e;
     if (n) e = hipMemcpy(p, src, n, hipMemcpyHostToDevice);
     return e;
@@ -34,7 +38,9 @@ struct DevBuf {
   hipError_t alloc(size_t n) {
     if (p) { (void)hipFree(p); p = nullptr; }
     bytes = n;
-    return hipMalloc(&p, n ? n : 4);
+    hipError_t e = hipMalloc(&p, n ? n : 4);
+    if (e == hipSuccess && poison()) e = hipMemset(p, 0xFF, n ? n : 4);
+    return e;
   }
 };
 
@@ -46,6 +52,7 @@ struct i3rc_hip_integrator {
   std::vector<float> xE, yE, zE;  // host copies (normalisation, checks)
   DevBuf dxE, dyE, dzE, dExt, dCum, dSsa, dPf;
   DevBuf dExtBrick;              // totalExt in bricks of 32 cells (DevProblem::extBrick)
+  bool compDirty = true;         // comp[] changed since its device copy (dComp) was made
   int bsx = 0, bsy = 0, bsz = 0, nbx = 0, nby = 0, nbz = 0;
   DevBuf dInv[I3RC_MAX_COMPONENTS], dInvCos[I3RC_MAX_COMPONENTS], dFwd[I3RC_MAX_COMPONENTS], dFwdOrig[I3RC_MAX_COMPONENTS];
   CompTables comp[I3RC_MAX_COMPONENTS] = {};
@@ -184,7 +191,13 @@ int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int n
   CCHK(h->dxE.upload(xEdges, sizeof(float) * (nx + 1)));
   CCHK(h->dyE.upload(yEdges, sizeof(float) * (ny + 1)));
   CCHK(h->dzE.upload(zEdges, sizeof(float) * (nz + 1)));
-  CCHK(h->dExt.upload(totalExt, sizeof(float) * ncell));
+  {
+    // one layer of zeros on top: the tracer asks for the extinction of its cell before it looks at the step, and a
+    // photon that starts within spacing() of the domain top has zIndex nz + 1 (it is dropped by that very step)
+    std::vector<float> padded(ncell + (size_t)nx * ny, 0.0f);
+    std::copy(totalExt, totalExt + ncell, padded.begin());
+    CCHK(h->dExt.upload(padded.data(), sizeof(float) * padded.size()));
+  }
   {
     // bricks of 32 cells: 8 deep where the grid has the layers for it (photon paths and shadow rays cross z faces
     // most often in cloud fields, whose cells are flatter than wide), the rest shared by x and y
@@ -192,7 +205,8 @@ int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int n
     h->bsz = log2le(nz, 3);
     h->bsy = log2le(ny, (5 - h->bsz) / 2);
     h->bsx = 5 - h->bsz - h->bsy;
-    h->nbx = (nx + (1 << h->bsx) - 1) >> h->bsx; h->nby = (ny + (1 << h->bsy) - 1) >> h->bsy; h->nbz = (nz + (1 << h->bsz) - 1) >> h->bsz;
+    h->nbx = (nx + (1 << h->bsx) - 1) >> h->bsx; h->nby = (ny + (1 << h->bsy) - 1) >> h->bsy;
+    h->nbz = (nz + 1 + (1 << h->bsz) - 1) >> h->bsz;   // (room for the layer nz + 1 of zeros, as in dExt)
     if ((int64_t)h->nbx * h->nby >= ((int64_t)1 << 24) || (int64_t)h->nbx * h->nby * h->nbz >= ((int64_t)1 << 26)) {
       g_createError = "i3rc_hip_create: domain too large for the bricked extinction copy";
       delete h;
@@ -283,6 +297,7 @@ int i3rc_hip_set_inverse_table(i3rc_hip_integrator *h, int comp, int nSteps, int
   h->comp[comp - 1].inv = (const float *)h->dInv[comp - 1].p;
   h->comp[comp - 1].invCos = (const float *)h->dInvCos[comp - 1].p;
   h->comp[comp - 1].nInv = nSteps;
+  h->compDirty = true;
   h->nInvEntries[comp - 1] = nEntries;
   return 0;
 }
@@ -299,6 +314,7 @@ int i3rc_hip_set_forward_tables(i3rc_hip_integrator *h, int comp, int nSteps, in
   h->comp[comp - 1].fwd = (const float *)h->dFwd[comp - 1].p;
   h->comp[comp - 1].fwdOrig = (const float *)h->dFwdOrig[comp - 1].p;
   h->comp[comp - 1].nFwd = nSteps;
+  h->compDirty = true;
   h->nFwdEntries[comp - 1] = nEntries;
   return 0;
 }
@@ -462,8 +478,15 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool wantPool = false
   P.bsx = h->bsx; P.bsy = h->bsy; P.bsz = h->bsz; P.nbx = h->nbx; P.nbxy = h->nbx * h->nby;
   P.totalExt = (const float *)h->dExt.p; P.cumExt = (const float *)h->dCum.p; P.ssa = (const float *)h->dSsa.p;
   P.pfIndex = (const int32_t *)h->dPf.p;
-  if (hipMemcpyAsync(h->dComp.p, h->comp, sizeof(CompTables) * I3RC_MAX_COMPONENTS, hipMemcpyHostToDevice, h->stream) != hipSuccess)
-    return h->fail("hipMemcpyAsync(component tables) failed");
+  if (h->compDirty) {
+    // the device copy of the table descriptors follows the host copy when a table was (re)set: a blocking copy after
+    // the stream has drained (launches in flight read the old descriptors), not an asynchronous copy from the
+    // pageable handle per launch
+    if (hipStreamSynchronize(h->stream) != hipSuccess ||
+        hipMemcpy(h->dComp.p, h->comp, sizeof(CompTables) * I3RC_MAX_COMPONENTS, hipMemcpyHostToDevice) != hipSuccess)
+      return h->fail("copying the component table descriptors failed");
+    h->compDirty = false;
+  }
   P.comp = (const CompTables *)h->dComp.p;
   P.comp0 = h->comp[0];
   P.albedo = h->params.surfaceAlbedo; P.useBDRF = h->params.useSurfaceBDRF;
@@ -672,6 +695,7 @@ int i3rc_hip_trace_rays(i3rc_hip_integrator *h, int64_t n, const float *dir, flo
   const int rc = make_problem(h, plan);
   h->nDir = savedDir;
   std::memcpy(h->comp, saved, sizeof(saved));
+  h->compDirty = true;
   if (rc) return 1;
   plan.P.ldsGrid = 0; plan.P.ldsTallies = 0;
   plan.P.extBrick = (const float *)h->dExtBrick.p;   // the test hook always reads the bricked copy (its index is checked bit for bit)

@@ -177,7 +177,7 @@ struct Reservoir {
 // loop's code and its scalar-register pressure.  GENERAL = true keeps every path behind run-time switches.
 // (the general radiance kernel keeps the most state live: 4 waves per SIMD give it 128 vector registers and no spills)
 template <class Rng, bool INTENSITY, bool GENERAL, int GRID>
-__global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAVES) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
+__global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 2 : I3RC_MIN_WAVES) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   {
@@ -539,8 +539,14 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
             bool scatterThis = true;
             int cell = 0;
             if (!rayTracing) {
-              cell = cell_index(P, r.ix, r.iy, r.iz);
-              scatterThis = rng.next() < P.totalExt[cell] / P.maxExt;
+              // max cross-section never updates the cell indices after a move (:494-496 has no index search): they are
+              // those of the photon's start or of its last surface hit.  A start index of nz + 1 (a photon that starts
+              // within spacing() of the domain top: thin elevated domains) is outside the grid; the reference reads
+              // totalExt out of bounds there.  Here: no extinction outside the grid, hence never a scattering.
+              const bool inGrid = (unsigned)(r.iz - 1) < (unsigned)P.nz;
+              cell = inGrid ? cell_index(P, r.ix, r.iy, r.iz) : 0;
+              const float extHere = inGrid ? P.totalExt[cell] : 0.0f;
+              scatterThis = rng.next() < extHere / P.maxExt;
             }
             if (scatterThis) {
               order++;

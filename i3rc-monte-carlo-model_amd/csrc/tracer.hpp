@@ -305,6 +305,10 @@ __device__ __forceinline__ void find_xy(const DevProblem &P, const Lds &L, float
     const lds_float *xe = L.xE, *ye = L.yE;
     ix = find_index(x, [xe](int k) { return xe[k - 1]; }, P.nx + 1, ix);
     iy = find_index(y, [ye](int k) { return ye[k - 1]; }, P.ny + 1, iy);
+    // x == xMax exactly (makePeriodic lets it through) gives nx + 1: the reference's regular branch wraps that to 1
+    // (:1366-1367), its irregular branch does not and then indexes out of bounds; here both wrap
+    if (ix == P.nx + 1) ix = 1;
+    if (iy == P.ny + 1) iy = 1;
   }
 }
 template <bool GENERAL = true>

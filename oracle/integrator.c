@@ -71,6 +71,10 @@ static void find_xy(const ctx_t *c, float xPos, float yPos, int *ix, int *iy) {
   } else {
     *ix = orc_find_index(xPos, p->xEdges, p->nx + 1, *ix);
     *iy = orc_find_index(yPos, p->yEdges, p->ny + 1, *iy);
+    /* xPos == xMax exactly gives nx + 1: the regular branch wraps it (:1366-1367), the reference's irregular branch
+       does not and indexes out of bounds afterwards; this restatement wraps in both (as the kernels do) */
+    if (*ix == p->nx + 1) *ix = 1;
+    if (*iy == p->ny + 1) *iy = 1;
   }
 }
 
@@ -375,7 +379,13 @@ int64_t orc_compute_rt(const orc_problem *p, orc_mt *rng, int64_t n,
         }
       } else { /* scattering event :581-689 */
         int scatterThis = 1;
-        if (!useRay) scatterThis = orc_mt_real(rng) < p->totalExt[CELL(ix, iy, iz)] / maxExt;
+        if (!useRay) {
+          /* the indices are stale in this mode (no index search after the move, :494-496): those of the start or of
+             the last surface hit.  A start index of nz + 1 (photon starting within spacing() of the top) is outside
+             the grid and the reference reads totalExt out of bounds; here: no extinction outside the grid. */
+          float extHere = (iz >= 1 && iz <= p->nz) ? p->totalExt[CELL(ix, iy, iz)] : 0.0f;
+          scatterThis = orc_mt_real(rng) < extHere / maxExt;
+        }
         if (useRay || scatterThis) {
           order++;
           t->scatterings++;

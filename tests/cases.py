@@ -44,12 +44,15 @@ def step_cloud(ssa=1.0, nlayers=32, ncolumns=32):
     return dict(xe=xe, ye=ye, ze=ze, ext=ext, ssa=np.full_like(ext, f32(ssa)), pf=np.ones(ext.shape, np.int32))
 
 
-def irregular_domain(seed=3, nx=7, ny=5, nz=9, ssa=0.95):
-    """Small irregularly spaced domain with empty cells: exercises findIndex paths and zero-extinction steps."""
+def irregular_domain(seed=3, nx=7, ny=5, nz=9, ssa=0.95, z0=0.0):
+    """Small irregularly spaced domain with empty cells: exercises findIndex paths and zero-extinction steps.
+    z0 = 100 gives the THIN ELEVATED domain of the reference's start-of-photon quirk: photons start at
+    z0 + (1 - spacing(1)) (zMax - z0), which rounds to zMax itself, findZIndex answers nz + 1, the first tracer step
+    is 0 and every photon is dropped (ray tracing); with z0 = 0 the photons enter the domain."""
     rng = np.random.default_rng(seed)
     xe = np.concatenate([[0.0], np.cumsum(rng.uniform(5, 40, nx))]).astype(np.float32)
     ye = np.concatenate([[0.0], np.cumsum(rng.uniform(5, 40, ny))]).astype(np.float32)
-    ze = (np.concatenate([[0.0], np.cumsum(rng.uniform(5, 30, nz))]) + 100.0).astype(np.float32)
+    ze = (np.concatenate([[0.0], np.cumsum(rng.uniform(5, 30, nz))]) + z0).astype(np.float32)
     ext = rng.uniform(0.0, 0.08, (nz, ny, nx)).astype(np.float32)
     ext[rng.random(ext.shape) < 0.3] = 0.0
     pf = np.where(ext > 0, 1, 0).astype(np.int32)

@@ -93,11 +93,14 @@ def test_two_components_two_table_entries(oracle):
 
 
 def test_irregular_grid_flux(oracle):
-    d = cases.irregular_domain()
-    g = make_gpu(d, hg_table(), surfaceAlbedo=0.5)
-    o = make_oracle(oracle, d, [hg_table().inverse_table(9001)])
-    o.specify(surfaceAlbedo=0.5)
-    _parity(oracle, g, o, 8, 20000, 0.4, az=130.0, keys=("fluxUp", "fluxDown", "fluxAbsorbed", "volumeAbsorption"), floor=1e-6)
+    for z0 in (0.0, 100.0):   # on the ground; thin and elevated (every photon dropped at its start: cases.irregular_domain)
+        d = cases.irregular_domain(z0=z0)
+        g = make_gpu(d, hg_table(), surfaceAlbedo=0.5)
+        o = make_oracle(oracle, d, [hg_table().inverse_table(9001)])
+        o.specify(surfaceAlbedo=0.5)
+        gr, orr = _parity(oracle, g, o, 8, 20000, 0.4, az=130.0, keys=("fluxUp", "fluxDown", "fluxAbsorbed", "volumeAbsorption"), floor=1e-6)
+        dropped = sum(r["counters"]["dropped"] for r in gr)
+        assert (dropped == 8 * 20000) if z0 > 0 else (dropped < 800), (z0, dropped)
 
 
 def test_radar_cloud_c1_tabulated_flux_and_nadir_radiance(oracle):
@@ -194,10 +197,12 @@ def test_radiance_on_irregular_grid_with_two_components(oracle):
     op = dict(surfaceAlbedo=0.25, useRRForIntensity=1, zetaMin=0.3)
     g, o = _intensity_pair(oracle, d, [t_cloud, t_gas], gpu_params=gp, oracle_params=op, mus=[1.0, 0.4, -0.7], phis=[0.0, 60.0, 200.0])
     _parity(oracle, g, o, 8, 8000, 0.6, az=70.0, keys=("fluxUp", "fluxDown", "intensity"), floor=1e-6)
-    d = cases.irregular_domain()
-    gp = dict(surfaceAlbedo=0.5)
-    g, o = _intensity_pair(oracle, d, hg_table(), gpu_params=gp, oracle_params=gp, mus=[0.9, 0.3], phis=[10.0, 250.0])
-    _parity(oracle, g, o, 8, 8000, 0.4, az=130.0, keys=("fluxUp", "fluxDown", "intensity"), floor=1e-6)
+    for z0 in (0.0, 100.0):
+        d = cases.irregular_domain(z0=z0)
+        gp = dict(surfaceAlbedo=0.5)
+        g, o = _intensity_pair(oracle, d, hg_table(), gpu_params=gp, oracle_params=gp, mus=[0.9, 0.3], phis=[10.0, 250.0])
+        gr, orr = _parity(oracle, g, o, 8, 8000, 0.4, az=130.0, keys=("fluxUp", "fluxDown", "intensity"), floor=1e-6)
+        assert (sum(r["counters"]["shadowSteps"] for r in gr) > 0) == (z0 == 0.0)
 
 
 def test_max_cross_section_with_radiances(oracle):
@@ -225,7 +230,7 @@ def test_random_general_domains_against_the_oracle(oracle):
             tabs = [t_cloud, t_gas]
         else:
             d = cases.irregular_domain(seed=seed, nx=int(rng.integers(1, 12)), ny=int(rng.integers(1, 8)), nz=int(rng.integers(2, 14)),
-                                       ssa=float(rng.choice([1.0, 0.95, 0.7])))
+                                       ssa=float(rng.choice([1.0, 0.95, 0.7])), z0=0.0 if case % 4 else 100.0)
             tabs = hg_table()
         albedo, mu0, az = float(rng.choice([0.0, 0.4, 1.0])), float(rng.uniform(0.1, 1.0)), float(rng.uniform(0, 360))
         if case % 3 == 0:      # flux only
@@ -276,6 +281,8 @@ def test_replay_reference_random_stream_with_radiances_components_and_surfaces(o
         ("two components + roulette", cases.two_component(), t2, dict(surfaceAlbedo=0.25, useRussianRouletteForIntensity=True, zetaMin=0.3),
          dict(surfaceAlbedo=0.25, useRRForIntensity=1, zetaMin=0.3), 0.99),
         ("irregular grid", cases.irregular_domain(), hg_table(), dict(surfaceAlbedo=0.5), dict(surfaceAlbedo=0.5), 0.99),
+        ("irregular grid, thin and elevated, max cross-section", cases.irregular_domain(z0=100.0), hg_table(),
+         dict(surfaceAlbedo=0.5, useRayTracing=False), dict(surfaceAlbedo=0.5, useRayTracing=0), 0.99),
         ("max cross-section", cases.step_cloud(ssa=0.98, nlayers=8), hg_table(), dict(useRayTracing=False, surfaceAlbedo=0.2),
          dict(useRayTracing=0, surfaceAlbedo=0.2), 0.99),
         ("BRDF grid", cases.step_cloud(ssa=1.0, nlayers=8), hg_table(),
@@ -310,6 +317,12 @@ def test_replay_reference_random_stream_with_radiances_components_and_surfaces(o
         ri = float(np.asarray(ref["intensityByComp"], np.float64).sum())
         print(f"   radiance sums gpu {gi:.6g} ref {ri:.6g}")
         assert abs(gi - ri) <= 0.01 * max(ri, 1e-3), (name, gi, ri)
+        # and the same photon for photon under another schedule (every event on its own instead of in groups)
+        g.set_tuning(evThreshold=1)
+        _, again = _replay_pair(oracle, g, o, n, [10, 3], 0.7, 25.0)
+        for key in ("fate", "fateColumn", "fateOrder", "drawsUsed", "fateWeight"):
+            assert np.array_equal(out[key], again[key]), (name, key)
+        assert again["counters"] == out["counters"], (name, again["counters"], out["counters"])
 
 
 def test_roulette_radiance_in_a_downward_direction_with_the_grid_in_global_memory(oracle):
@@ -347,6 +360,21 @@ def test_results_do_not_depend_on_the_schedule(oracle):
             seen = []
             for tune in tunings:
                 g = make_gpu(d, hg_table(0.85, 299), **params)
+                g.set_tuning(**tune)
+                r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 1)), M.new_PhotonStream(0.7, 25.0, 100000))
+                seen.append({k: r["counters"][k] for k in keys})
+            assert all(c == seen[0] for c in seen), (name, params, seen)
+    # features only the general kernel has: two components, irregular grid, BRDF grid, hybrid phase function + limit
+    t2 = [M.PhaseFunctionTable([M.henyey_greenstein(0.85, 32), M.henyey_greenstein(0.6, 16)]),
+          M.PhaseFunctionTable([M.PhaseFunction(legendre=np.array([0.0, 0.1], np.float32))])]
+    full = dict(rad, surfaceAlbedo=0.3, useHybridPhaseFunsForIntenCalcs=True, hybridPhaseFunWidth=7.0,
+                numOrdersOrigPhaseFunIntenCalcs=1, limitIntensityContributions=True, maxIntensityContribution=0.5)
+    for name, d, tab in (("two components", cases.two_component(), t2), ("irregular", cases.irregular_domain(), hg_table()),
+                         ("irregular, thin and elevated", cases.irregular_domain(z0=100.0), hg_table())):
+        for params in (full, dict(full, useRayTracing=False)):
+            seen = []
+            for tune in tunings[:4] + [dict(evThreshold=24, lightThreshold=8)]:
+                g = make_gpu(d, tab, **params)
                 g.set_tuning(**tune)
                 r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 1)), M.new_PhotonStream(0.7, 25.0, 100000))
                 seen.append({k: r["counters"][k] for k in keys})
