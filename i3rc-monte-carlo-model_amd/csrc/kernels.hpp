@@ -177,7 +177,7 @@ struct Reservoir {
 // loop's code and its scalar-register pressure.  GENERAL = true keeps every path behind run-time switches.
 // (the general radiance kernel keeps the most state live: 4 waves per SIMD give it 128 vector registers and no spills)
 template <class Rng, bool INTENSITY, bool GENERAL, int GRID>
-__global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 2 : I3RC_MIN_WAVES) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
+__global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAVES) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   {
