@@ -453,7 +453,7 @@ bool uniform_surface(const i3rc_hip_integrator *h) { return h->params.useSurface
 
 bool common_class(const i3rc_hip_integrator *h, int srcKind) {
   const bool gridSurface = h->params.useSurfaceBDRF && !uniform_surface(h);
-  return h->xyRegular && h->zRegular && h->params.useRayTracing && !gridSurface && h->ncomp == 1 && srcKind == 0;
+  return h->xyRegular && h->zRegular && (h->params.useRayTracing || !(h->maxExt > 0.0f)) && !gridSurface && h->ncomp == 1 && srcKind == 0;
 }
 
 size_t ncell_bytes(const i3rc_hip_integrator *h) { return sizeof(float) * (size_t)h->nx * h->ny * h->nz; }
@@ -494,7 +494,10 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool wantPool = false
   P.nxs = h->nxs; P.nys = h->nys;
   P.xsE = (const float *)h->dXs.p; P.ysE = (const float *)h->dYs.p; P.brdf = (const float *)h->dBrdf.p;
   if (P.useBDRF && !P.brdf) return h->fail("computeRadiativeTransfer: surfaceBDRF requested but no surface description set");
-  P.useRayTracing = h->params.useRayTracing; P.useRR = h->params.useRussianRoulette;
+  // Max cross-section divides the optical depth by the largest extinction of the domain (:494-496): with no extinction
+  // anywhere that is a step of infinite length and the reference's makePeriodic never returns.  A photon in an empty
+  // domain flies straight to the boundary, which is what ray tracing gives: such a domain is traced.
+  P.useRayTracing = (h->params.useRayTracing || !(h->maxExt > 0.0f)) ? 1 : 0; P.useRR = h->params.useRussianRoulette;
   P.nDir = h->nDir; P.useHybrid = h->params.useHybridPhaseFunsForIntenCalcs;
   P.numOrdersOrig = h->params.numOrdersOrigPhaseFunIntenCalcs; P.useRRI = h->params.useRussianRouletteForIntensity;
   P.limitContrib = h->params.limitIntensityContributions; P.zetaMin = h->params.zetaMin;

@@ -302,6 +302,9 @@ int64_t orc_compute_rt(const orc_problem *p, orc_mt *rng, int64_t n,
     maxExt = p->totalExt[0];
     for (size_t i = 1; i < ncell; i++) if (p->totalExt[i] > maxExt) maxExt = p->totalExt[i];
   }
+  /* no extinction anywhere: tau / maxExt is an infinite step and the reference's makePeriodic never returns (:494-496,
+     :2063-2082).  The photon flies straight to the boundary, which is what ray tracing gives (the kernels do the same). */
+  if (!useRay && !(maxExt > 0.0f)) useRay = 1;
   float x0 = cx.x0, xMax = XE(p->nx + 1), y0 = cx.y0, yMax = YE(p->ny + 1), z0 = cx.z0, zMax = ZE(p->nz + 1);
   float *contrib = NULL; int *ixF = NULL, *iyF = NULL;
   if (p->nDir > 0) {

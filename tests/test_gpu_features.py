@@ -392,3 +392,30 @@ def test_results_do_not_depend_on_the_schedule(oracle):
                      float(out["raw"][lay.intensityByComponent:lay.intensityByComponent + 2 * ncol].sum())))
     assert all(s[:2] == sums[0][:2] for s in sums), sums
     assert all(abs(s[2] - sums[0][2]) <= 1e-6 * sums[0][2] for s in sums), sums
+
+
+def test_max_cross_section_in_an_empty_domain_is_ray_tracing(oracle):
+    # tau / maxExtinction is an infinite step when the domain holds no extinction at all and the reference's makePeriodic
+    # never returns; oracle and kernels trace such a domain instead (the photon flies straight to the boundary)
+    d = cases.step_cloud(nlayers=4)
+    d["ext"] = np.zeros_like(d["ext"])
+    res = {}
+    for mode in (True, False):
+        g = make_gpu(d, hg_table(), useRayTracing=mode, surfaceAlbedo=0.5)
+        o = make_oracle(oracle, d, [hg_table().inverse_table(2001)])
+        o.specify(useRayTracing=int(mode), surfaceAlbedo=0.5)
+        gr, orr = _parity(oracle, g, o, 4, 5000, 0.6, az=40.0, keys=("fluxUp", "fluxDown"))
+        res[mode] = gr
+    assert np.array_equal(res[True][0]["fluxUp"], res[False][0]["fluxUp"])
+    assert abs(float(res[False][0]["fluxDown"].mean()) - 1.0) < 1e-6 and abs(float(res[False][0]["fluxUp"].mean()) - 0.5) < 1e-6
+
+
+def test_fuzz_random_configurations_in_a_process_of_their_own():
+    # tools/fuzz.py: random domains, parameters and sources with fresh device memory poisoned; no fault, no hang, the
+    # same integer work counters under a second schedule, domain-mean fluxes equal to the oracle's within 5 sigma
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "1", "120"], capture_output=True, text=True, timeout=240,
+                       env=dict(os.environ, I3RC_POISON="1", ORACLE="1"))
+    assert r.returncode == 0 and "fuzz done 1 120 problems 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,0 +1,103 @@
+"""Fuzz the C ABI on the GPU box: random domains (regular / irregular, on the ground / thin and elevated, 1-3 D, holes,
+one or two components), random parameters (ray tracing / max cross-section, roulettes, hybrid phase function,
+contribution limit, Lambertian albedo or BRDF grid, radiance directions up and down), random sources (directional or
+explicit photons anywhere in the domain).  Every configuration is written to gpurun_out/fuzz.log BEFORE its launch, so a
+fault names its configuration; run with I3RC_POISON=1 so that reads of unwritten device memory show.  Checked per
+configuration: energy conservation of the tallies, finite radiances, and identical integer work counters under a
+second schedule.  usage: fuzz.py [first seed] [count]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch  # noqa: F401
+import i3rc_monte_carlo_model_amd as M
+from tests import cases
+from tests.test_gpu_parity import hg_table, make_gpu
+
+first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 1), (int(sys.argv[2]) if len(sys.argv) > 2 else 200)
+log = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "fuzz.log"), "a")
+def note(*a):
+    print(*a, file=log, flush=True); os.fsync(log.fileno())
+
+t_cloud = M.PhaseFunctionTable([M.henyey_greenstein(0.85, 32), M.henyey_greenstein(0.6, 16)])
+t_gas = M.PhaseFunctionTable([M.PhaseFunction(legendre=np.array([0.0, 0.1], np.float32))])
+KEYS = ("cellSteps", "scatterings", "surfaceHits", "exitsTop", "roulette", "shadowSteps", "tracerCalls", "dropped")
+bad = 0
+for seed in range(first, first + count):
+    rng = np.random.default_rng(seed)
+    kind = rng.choice(["regular", "irregular", "two"])
+    if kind == "two":
+        d = cases.two_component(seed=seed, nx=int(rng.integers(1, 9)), ny=int(rng.integers(1, 6)), nz=8); tab = [t_cloud, t_gas]
+    elif kind == "irregular":
+        d = cases.irregular_domain(seed=seed, nx=int(rng.integers(1, 12)), ny=int(rng.integers(1, 8)), nz=int(rng.integers(1, 14)),
+                                   ssa=float(rng.choice([1.0, 0.95, 0.5])), z0=float(rng.choice([0.0, 0.0, 100.0, 5000.0])))
+        tab = hg_table(float(rng.choice([0.0, 0.85, 0.95])), 64)
+    else:
+        d = cases.step_cloud(ssa=float(rng.choice([1.0, 0.99, 0.6])), nlayers=int(rng.integers(1, 20)))
+        if rng.random() < 0.3:   # lift it: the thin elevated case on a regular grid
+            d["ze"] = (d["ze"] + np.float32(rng.choice([300.0, 20000.0]))).astype(np.float32)
+        tab = hg_table(float(rng.choice([0.0, 0.85])), 64)
+    p = {}
+    if rng.random() < 0.4: p["useRayTracing"] = False
+    if rng.random() < 0.3: p["useRussianRoulette"] = False
+    nd = int(rng.choice([0, 0, 1, 2, 4]))
+    if nd:
+        p["intensityMus"] = [float(v) for v in rng.uniform(0.05, 1.0, nd) * rng.choice([-1, 1], nd)]
+        p["intensityPhis"] = [float(v) for v in rng.uniform(0, 360, nd)]
+        if rng.random() < 0.5: p.update(useRussianRouletteForIntensity=True, zetaMin=float(rng.choice([0.1, 0.3, 1.0])))
+        if rng.random() < 0.3: p.update(useHybridPhaseFunsForIntenCalcs=True, hybridPhaseFunWidth=7.0, numOrdersOrigPhaseFunIntenCalcs=int(rng.integers(0, 3)))
+        if rng.random() < 0.3: p.update(limitIntensityContributions=True, maxIntensityContribution=float(rng.choice([0.1, 1.0])))
+    s = rng.random()
+    if s < 0.5: p["surfaceAlbedo"] = float(rng.choice([0.0, 0.3, 1.0]))
+    elif s < 0.8:
+        nxs, nys = int(rng.integers(1, 5)), int(rng.integers(1, 4))
+        xs = np.linspace(d["xe"][0], d["xe"][-1], nxs + 1).astype(np.float32); ys = np.linspace(d["ye"][0], d["ye"][-1], nys + 1).astype(np.float32)
+        alb = rng.uniform(0, 1, (1, nxs, nys)).astype(np.float32)
+        p["surfaceBDRF"] = M.new_SurfaceDescription(alb, xs, ys) if nxs * nys > 1 else M.new_SurfaceDescription(alb.reshape(1))
+    n = int(rng.choice([1, 63, 1000, 30000]))
+    mu0, az = float(rng.uniform(0.05, 1.0)), float(rng.uniform(0, 360))
+    explicit = rng.random() < 0.3
+    if explicit:   # photons anywhere: relative positions in [0, 1], any direction but horizontal
+        arr = [rng.random(n), rng.random(n), rng.random(n), rng.uniform(0.05, 1.0, n) * rng.choice([-1, 1], n), rng.uniform(0, 2 * np.pi, n)]
+    note("seed", seed, kind, {k: (v if not hasattr(v, "albedo") else "BRDF") for k, v in p.items()}, "n", n, "explicit" if explicit else (mu0, az),
+         "shape", d["ext"][0].shape if isinstance(d["ext"], list) else d["ext"].shape, "z", float(d["ze"][0]), float(d["ze"][-1]))
+    res = []
+    for tune in (dict(evThreshold=0), dict(evThreshold=int(rng.choice([1, 8, 64])), blocksPerCU=1, lightThreshold=int(rng.choice([1, 16, 64])))):
+        try:
+            g = make_gpu(d, tab, **p)
+        except M.I3RCError as e:
+            note("   rejected:", e); res = None; break
+        g.set_tuning(**tune)
+        src = M.PhotonStream(arrays=arr) if explicit else M.new_PhotonStream(mu0, az, n)
+        r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((seed, 1)), src)
+        res.append(r)
+    if not res: continue
+    r = res[0]
+    c0, c1 = ({k: x["counters"][k] for k in KEYS} for x in res)
+    tot = float(r["fluxUp"].mean() + r["fluxAbsorbed"].mean()) + (float(r["fluxDown"].mean()) * (1.0 - p["surfaceAlbedo"]) if "surfaceAlbedo" in p else 0.0)
+    problems = []
+    if c0 != c1: problems.append(("schedule", c0, c1))
+    if not all(np.isfinite(r[k]).all() for k in ("fluxUp", "fluxDown", "fluxAbsorbed", "volumeAbsorption")): problems.append("non-finite flux")
+    if nd and not np.isfinite(r["intensity"]).all(): problems.append("non-finite radiance")
+    drop = c0["dropped"] / n
+    # (column means add up to the photons' energy on grids of equal columns only: not on the irregular ones)
+    if kind != "irregular" and "surfaceAlbedo" in p and p.get("useRussianRoulette", True) is False and abs(tot + drop - 1.0) > 0.02 + 3.0 / np.sqrt(n):
+        problems.append(("energy", tot, drop))
+    if os.environ.get("ORACLE") == "1" and not explicit and "surfaceBDRF" not in p:
+        # domain-mean fluxes against the CPU oracle (its own MT19937 stream: 5 sigma of the two samples)
+        from oracle import pyoracle as O
+        from tests.test_gpu_parity import make_oracle
+        O.build()
+        tabs = tab if isinstance(tab, list) else [tab]
+        o = make_oracle(O, d, [t.inverse_table(2001) for t in tabs])
+        o.specify(useRayTracing=int(p.get("useRayTracing", True)), useRussianRoulette=int(p.get("useRussianRoulette", True)), surfaceAlbedo=p.get("surfaceAlbedo", 0.0))
+        m = max(n, 4000)
+        rr = O.RandomNumberSequence([seed, 7]); ph = O.photons_directional(rr, mu0, az, m)
+        ro = o.compute(rr, *ph)
+        for k in ("fluxUp", "fluxDown", "fluxAbsorbed"):
+            a, b = float(r[k].mean()), float(ro[k].mean())
+            tol = 5.0 * np.sqrt(max(a, b, 0.02) * (1.0 / n + 1.0 / m)) * (3.0 if kind == "irregular" else 1.0) + 1e-3
+            if abs(a - b) > tol: problems.append(("oracle", k, a, b, tol))
+    note("   ok" if not problems else "   PROBLEM", problems, "up %.4f down %.4f abs %.4f dropped %.4f" % (r["fluxUp"].mean(), r["fluxDown"].mean(), r["fluxAbsorbed"].mean(), drop))
+    bad += bool(problems)
+note("fuzz done", first, count, "problems", bad)
+print("fuzz done", first, count, "problems", bad)
