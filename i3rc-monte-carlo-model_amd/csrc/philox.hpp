@@ -136,7 +136,10 @@ struct ReplayStream {
   __device__ inline uint32_t total() const { return closed; }
   __device__ inline void begin_event(bool = false) {}
   __device__ inline float next() {
-    float r = pos < end ? buf[pos] : 0.5f;
+    // a photon that parts from the reference's path (1-ulp differences of log / cos / ...) may ask for more deviates
+    // than were recorded: past the end the recorded ones are used again from the start (a constant would be
+    // degenerate: a rejection loop fed with 0.5 yields the zero vector and a NaN direction)
+    const float r = buf[end > 0 ? pos % end : 0];
     pos++;
     return r;
   }

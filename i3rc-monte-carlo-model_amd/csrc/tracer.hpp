@@ -253,7 +253,9 @@ __device__ __forceinline__ StepResult trace_step(const DevProblem &P, const Lds 
   float step = stx;
   step = sty < step ? sty : step;
   step = stz < step ? stz : step;
-  if (__builtin_expect(step <= 0.0f, 0)) { r.acc = -2.0f; return STEP_ERROR; }   // :1711-1714
+  // :1711-1714 `if(thisStep <= 0.)`, written so that a NaN step (a NaN direction or position) ends the trace as well:
+  // the reference's comparison lets NaN through and its loop never ends
+  if (__builtin_expect(!(step > 0.0f), 0)) { r.acc = -2.0f; return STEP_ERROR; }
 
   const float tauCell = step * ext;
   bool reach = false;

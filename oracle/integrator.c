@@ -109,7 +109,7 @@ float orc_trace(const orc_problem *p, const float dir[3], float pos[3], int idx[
     float thisStep = step[0];
     if (step[1] < thisStep) thisStep = step[1];
     if (step[2] < thisStep) thisStep = step[2];
-    if (thisStep <= 0.0f) { acc = -2.0f; break; }
+    if (!(thisStep > 0.0f)) { acc = -2.0f; break; }   /* :1711-1714 `thisStep <= 0.`; a NaN step ends the trace too (the reference loops forever) */
 
     float ext = p->totalExt[CELL(ix, iy, iz)];
     if (hasTarget) {

@@ -53,6 +53,12 @@ for seed in range(first, first + count):
         xs = np.linspace(d["xe"][0], d["xe"][-1], nxs + 1).astype(np.float32); ys = np.linspace(d["ye"][0], d["ye"][-1], nys + 1).astype(np.float32)
         alb = rng.uniform(0, 1, (1, nxs, nys)).astype(np.float32)
         p["surfaceBDRF"] = M.new_SurfaceDescription(alb, xs, ys) if nxs * nys > 1 else M.new_SurfaceDescription(alb.reshape(1))
+    for k in os.environ.get("DROP", "").split(","):   # bisecting a configuration: DROP=key,key  NDIRS=k
+        if k == "dirs" and "intensityMus" in p: nd = 0; p.pop("intensityMus"); p.pop("intensityPhis")
+        elif k in p: p.pop(k)
+    if "NDIRS" in os.environ and nd:
+        keep = [int(v) for v in os.environ["NDIRS"].split(",")]
+        p["intensityMus"] = [p["intensityMus"][i] for i in keep]; p["intensityPhis"] = [p["intensityPhis"][i] for i in keep]; nd = len(keep)
     n = int(rng.choice([1, 63, 1000, 30000]))
     mu0, az = float(rng.uniform(0.05, 1.0)), float(rng.uniform(0, 360))
     explicit = rng.random() < 0.3
@@ -60,6 +66,49 @@ for seed in range(first, first + count):
         arr = [rng.random(n), rng.random(n), rng.random(n), rng.uniform(0.05, 1.0, n) * rng.choice([-1, 1], n), rng.uniform(0, 2 * np.pi, n)]
     note("seed", seed, kind, {k: (v if not hasattr(v, "albedo") else "BRDF") for k, v in p.items()}, "n", n, "explicit" if explicit else (mu0, az),
          "shape", d["ext"][0].shape if isinstance(d["ext"], list) else d["ext"].shape, "z", float(d["ze"][0]), float(d["ze"][-1]))
+    if os.environ.get("REPLAY") == "1":
+        # the replay build against the oracle photon by photon (reference deviates in reference order): same fate, exit
+        # column, scattering order, number of deviates; radiance sums within 2 % + the share of diverged photons
+        from oracle import pyoracle as O
+        from tests.test_gpu_features import _intensity_pair, _replay_pair
+        O.build()
+        gp = {k: v for k, v in p.items() if k not in ("intensityMus", "intensityPhis", "surfaceBDRF")}
+        op = dict(surfaceAlbedo=gp.get("surfaceAlbedo", 0.0), useRayTracing=int(gp.get("useRayTracing", True)),
+                  useRussianRoulette=int(gp.get("useRussianRoulette", True)), useRRForIntensity=int(gp.get("useRussianRouletteForIntensity", False)),
+                  zetaMin=gp.get("zetaMin", 0.3), useHybrid=int(gp.get("useHybridPhaseFunsForIntenCalcs", False)),
+                  numOrdersOrig=gp.get("numOrdersOrigPhaseFunIntenCalcs", 0), limitContrib=int(gp.get("limitIntensityContributions", False)))
+        if "maxIntensityContribution" in gp: op["maxContrib"] = gp["maxIntensityContribution"]
+        if "surfaceBDRF" in p:
+            sd = p["surfaceBDRF"]
+            if nxs * nys > 1:
+                gp["surfaceBDRF"] = sd; op["surfaceBDRF"] = (xs, ys, np.ascontiguousarray(alb[0].T)); op.pop("surfaceAlbedo")
+            else:
+                gp["surfaceAlbedo"] = op["surfaceAlbedo"] = float(alb.reshape(-1)[0])
+        mus = p.get("intensityMus", [1.0]); phis = p.get("intensityPhis", [0.0])
+        try:
+            g, o = _intensity_pair(O, d, tab, n_table=2001, gpu_params=gp, oracle_params=op, mus=mus, phis=phis,
+                                   hybrid_width=7.0 if op["useHybrid"] else None)
+        except M.I3RCError as e:
+            note("   rejected:", e); continue
+        m = min(n, 1500)
+        ref, out = _replay_pair(O, g, o, m, [seed, 3], mu0, az)
+        same = (out["fate"] == ref["fate"]) & (out["fateColumn"] == ref["fateColumn"]) & (out["fateOrder"] == ref["fateOrder"]) & \
+               (out["drawsUsed"] == np.diff(ref["drawStart"]))
+        lay = g.layout(); ncol = g.nx * g.ny
+        gi = float(out["raw"][lay.intensityByComponent:lay.intensityByComponent + (g.ncomp + 1) * len(mus) * ncol].sum())
+        ri = float(np.asarray(ref["intensityByComp"], np.float64).sum())
+        problems = []
+        # (photons part ways through 1-ulp differences of log / cos / acos between device and glibc: the more events a
+        # photon lives through -- mirror surfaces, no roulette -- the more of them do; "same" cannot see a photon that
+        # chose another component and still ended alike, hence the weights are compared as a share too)
+        events = max(1.0, float(np.mean(np.diff(ref["drawStart"]))) / 4.0)
+        same &= out["fateWeight"] == ref["fateWeight"]
+        if same.mean() < 1.0 - 0.002 * events - 0.01 and (~same).sum() > 6: problems.append(("replay agreement", float(same.mean()), events))
+        # (a photon that parted ways carries its own contributions: up to 1 / mu of a grazing direction each)
+        if abs(gi - ri) > (0.02 + 40.0 * (1.0 - same.mean())) * max(abs(ri), 1e-3) + 1e-6: problems.append(("radiance sums", gi, ri))
+        note("   ok" if not problems else "   PROBLEM", problems, "identical %.4f of %d, radiance sums %.6g %.6g" % (same.mean(), m, gi, ri))
+        bad += bool(problems)
+        continue
     res = []
     for tune in (dict(evThreshold=0), dict(evThreshold=int(rng.choice([1, 8, 64])), blocksPerCU=1, lightThreshold=int(rng.choice([1, 16, 64])))):
         try:
