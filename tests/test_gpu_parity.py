@@ -408,6 +408,32 @@ def test_step_cloud_at_1e8_photons_size_independent_properties(oracle):
     assert col[:12].max() < col[20:].min()
 
 
+def test_step_cloud_flux_fields_at_1e8_photons_against_the_oracle_at_1e8(tmp_path):
+    # The north star's acceptance line taken literally: flux tallies within 3 sigma of the reference at 1e8 photons.
+    # BASELINE.json configs[1] on the GPU (20 batches of 5e6) against the CPU restatement at the same 1e8 photons
+    # (16 processes x 10 batches x 625000 photons on the box's host cores, started as a child program: ~15 s),
+    # column by column, standard errors from the batch-to-batch scatter on both sides (_assert_3sigma).
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "oracle_1e8.npz")
+    cores = min(16, len(os.sched_getaffinity(0)))
+    per_core = 10
+    photons = 100_000_000 // (cores * per_core)
+    child = subprocess.Popen([sys.executable, os.path.join(root, "tools", "cpu_baseline.py"), "--cores", str(cores), "--batches-per-core", str(per_core),
+                              "--photons", str(photons), "--save", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    g = make_gpu(cases.step_cloud(nlayers=16), hg_table(), minInverseTableSize=10001)   # the GPU works meanwhile
+    gr = _batches_gpu(g, 20, 5_000_000, 1.0)
+    so, se = child.communicate(timeout=600)
+    assert child.returncode == 0, so + se
+    z = np.load(out)
+    orr = [dict(fluxUp=u, fluxDown=d) for u, d in zip(z["fluxUp"], z["fluxDown"])]
+    assert len(orr) == cores * per_core and sum(r["counters"]["photons"] for r in gr) == 100_000_000
+    for key in ("fluxUp", "fluxDown"):
+        _assert_3sigma(gr, orr, key)
+    mg, mo = np.mean([r["fluxUp"].mean() for r in gr]), np.mean([r["fluxUp"].mean() for r in orr])
+    print(f"mean upward flux at 1e8 photons: gpu {mg:.6f} oracle {mo:.6f} (difference {mg - mo:+.2e})")
+
+
 def _random_regular_case(rng, case):
     nx, ny, nz = (int(rng.choice([1, 2, 5, 17, 40])), int(rng.choice([1, 1, 3, 24])), int(rng.choice([1, 4, 9, 33])))
     if case % 5 == 4:

@@ -24,12 +24,14 @@ def _worker(args):
     integ = O.Integrator(d["xe"], d["ye"], d["ze"], d["ext"], d["ssa"], d["pf"], [inv])
     t0 = time.perf_counter()
     fu = 0.0
+    cols = []
     for b in range(first_batch, first_batch + n_batches):
         rng = O.RandomNumberSequence([10, b])
         ph = O.photons_directional(rng, mu0, 0.0, photons)
         r = integ.compute(rng, *ph)
         fu += float(r["fluxUp"].mean())
-    return time.perf_counter() - t0, fu / n_batches
+        cols.append((r["fluxUp"].copy(), r["fluxDown"].copy()))
+    return time.perf_counter() - t0, fu / n_batches, cols
 
 
 def main():
@@ -39,6 +41,7 @@ def main():
     ap.add_argument("--photons", type=int, default=200000)
     ap.add_argument("--nlayers", type=int, default=16)
     ap.add_argument("--mu0", type=float, default=1.0)
+    ap.add_argument("--save", default="", help="write the per-batch flux fields (fluxUp, fluxDown: batch x ny x nx) to this .npz")
     a = ap.parse_args()
     from oracle import pyoracle as O
 
@@ -50,6 +53,10 @@ def main():
         res = list(ex.map(_worker, jobs))
     wall = time.perf_counter() - t0
     busy = max(r[0] for r in res)
+    if a.save:
+        import numpy as np
+
+        np.savez(a.save, fluxUp=np.stack([c[0] for r in res for c in r[2]]), fluxDown=np.stack([c[1] for r in res for c in r[2]]))
     total = cores * a.batches_per_core * a.photons
     print(json.dumps({"value": total / busy, "unit": "photons/s", "cores": cores, "kind": "port",
                       "sample": f"{cores} processes x {a.batches_per_core} batches x {a.photons} photons of the same step cloud "
