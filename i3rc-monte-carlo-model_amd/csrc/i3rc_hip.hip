@@ -549,8 +549,17 @@ int upload_source(i3rc_hip_integrator *h, const i3rc_source *src, int64_t n, Run
   if (src->kind != 1) return h->fail("unknown photon source kind");
   const float *arrs[5] = {src->x, src->y, src->z, src->mu, src->phi};
   const float **dst[5] = {&A.sx, &A.sy, &A.sz, &A.smu, &A.sphi};
+  for (int k = 0; k < 5; ++k) if (!arrs[k]) return h->fail("explicit photon stream: null array");
+  // what the reference's photon-stream constructors check (Code/monteCarloIllumination.f95:78-83, :124, :204, :369-371):
+  // relative positions within [0, 1], |mu| in (tiny, 1] -- a horizontal or NaN direction would never leave the domain
+  for (int64_t i = 0; i < n; ++i) {
+    const float mu = src->mu[i];
+    if (!(std::fabs(mu) <= 1.f) || !(std::fabs(mu) > FLT_MIN)) return h->fail("setIllumination: solarMu out of bounds");
+    if (!(src->x[i] >= 0.f && src->x[i] <= 1.f) || !(src->y[i] >= 0.f && src->y[i] <= 1.f) || !(src->z[i] >= 0.f && src->z[i] <= 1.f))
+      return h->fail("setIllumination: photon position out of bounds (relative positions lie in [0, 1])");
+    if (!std::isfinite(src->phi[i])) return h->fail("setIllumination: solarAzimuth out of bounds");
+  }
   for (int k = 0; k < 5; ++k) {
-    if (!arrs[k]) return h->fail("explicit photon stream: null array");
     HIPCHK(h, h->srcBuf[k].upload(arrs[k], sizeof(float) * (size_t)n));
     *dst[k] = (const float *)h->srcBuf[k].p;
   }

@@ -365,6 +365,15 @@ def test_edge_cases_and_errors():
     assert not s.morePhotonsExist()  # the stream is consumed, as in the reference
     with pytest.raises(M.I3RCError):
         g.computeRadiativeTransfer(M.new_RandomNumberSequence((1, 1)), s)
+    # explicit photons: a horizontal / NaN direction or a start outside the domain is refused, as the reference's
+    # photon-stream constructors do (such a photon would never leave a periodic domain)
+    ok = [np.full(4, 0.5, np.float32), np.full(4, 0.5, np.float32), np.full(4, 0.9, np.float32), np.full(4, -0.7, np.float32), np.zeros(4, np.float32)]
+    assert g.computeRadiativeTransfer(M.new_RandomNumberSequence((1, 1)), M.PhotonStream(arrays=ok))["counters"]["photons"] == 4
+    for k, badv in ((3, 0.0), (3, np.nan), (3, 1.5), (0, 1.2), (2, -0.1), (4, np.inf)):
+        arr = [a.copy() for a in ok]
+        arr[k][2] = badv
+        with pytest.raises(M.I3RCError):
+            g.computeRadiativeTransfer(M.new_RandomNumberSequence((1, 1)), M.PhotonStream(arrays=arr))
     g.finalize_Integrator()
     assert not g.isReady_Integrator()
 
