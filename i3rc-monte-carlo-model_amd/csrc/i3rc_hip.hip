@@ -451,9 +451,15 @@ constexpr size_t kLdsBudget = 64 * 1024;  // per workgroup: leaves room for >= 2
 // photon lands (Code/surfaceProperties.f95:121-162), and the weight is multiplied by the same float.
 bool uniform_surface(const i3rc_hip_integrator *h) { return h->params.useSurfaceBDRF && h->nxs == 1 && h->nys == 1; }
 
+// ray tracing asked for, or max cross-section on an optically empty domain (see make_problem)
+bool traced(const i3rc_hip_integrator *h) {
+  const float width = std::min(h->xE.back() - h->xE.front(), h->yE.back() - h->yE.front());
+  return h->params.useRayTracing || !(h->maxExt * width > 1e-5f);
+}
+
 bool common_class(const i3rc_hip_integrator *h, int srcKind) {
   const bool gridSurface = h->params.useSurfaceBDRF && !uniform_surface(h);
-  return h->xyRegular && h->zRegular && (h->params.useRayTracing || !(h->maxExt > 0.0f)) && !gridSurface && h->ncomp == 1 && srcKind == 0;
+  return h->xyRegular && h->zRegular && traced(h) && !gridSurface && h->ncomp == 1 && srcKind == 0;
 }
 
 size_t ncell_bytes(const i3rc_hip_integrator *h) { return sizeof(float) * (size_t)h->nx * h->ny * h->nz; }
@@ -495,9 +501,11 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool wantPool = false
   P.xsE = (const float *)h->dXs.p; P.ysE = (const float *)h->dYs.p; P.brdf = (const float *)h->dBrdf.p;
   if (P.useBDRF && !P.brdf) return h->fail("computeRadiativeTransfer: surfaceBDRF requested but no surface description set");
   // Max cross-section divides the optical depth by the largest extinction of the domain (:494-496): with no extinction
-  // anywhere that is a step of infinite length and the reference's makePeriodic never returns.  A photon in an empty
-  // domain flies straight to the boundary, which is what ray tracing gives: such a domain is traced.
-  P.useRayTracing = (h->params.useRayTracing || !(h->maxExt > 0.0f)) ? 1 : 0; P.useRR = h->params.useRussianRoulette;
+  // anywhere that is a step of infinite length and the reference's makePeriodic never returns -- nor does it once the
+  // step exceeds 2^24 domain widths, where subtracting a width no longer changes a float32.  A photon in such an
+  // (optically empty: width * maxExtinction <= 1e-5) domain flies straight to the boundary, which is what ray
+  // tracing gives: such a domain is traced.
+  P.useRayTracing = traced(h) ? 1 : 0; P.useRR = h->params.useRussianRoulette;
   P.nDir = h->nDir; P.useHybrid = h->params.useHybridPhaseFunsForIntenCalcs;
   P.numOrdersOrig = h->params.numOrdersOrigPhaseFunIntenCalcs; P.useRRI = h->params.useRussianRouletteForIntensity;
   P.limitContrib = h->params.limitIntensityContributions; P.zetaMin = h->params.zetaMin;

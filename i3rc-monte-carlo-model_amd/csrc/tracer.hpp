@@ -154,9 +154,13 @@ __device__ __forceinline__ int find_index(float value, Tab T, int n, int firstGu
 __device__ __forceinline__ float make_periodic(float a, float aMin, float aMax) {
   for (;;) {
     if (a <= aMax && a > aMin) break;
-    if (a > aMax) a = a - (aMax - aMin);
-    else if (a == aMin) a = aMax;
-    else a = a + (aMax - aMin);
+    float b;
+    if (a > aMax) b = a - (aMax - aMin);
+    else if (a == aMin) b = aMax;
+    else b = a + (aMax - aMin);
+    // no progress (NaN, infinity, or more than 2^24 widths away): the reference's loop never ends; see the oracle
+    if (b == a || b != b) return aMax;
+    a = b;
   }
   return a;
 }

@@ -50,9 +50,15 @@ static void make_dircos(float mu, float phi, float s[3]) {
 static float make_periodic(float a, float aMin, float aMax) {
   for (;;) {
     if (a <= aMax && a > aMin) break;
-    if (a > aMax) a = a - (aMax - aMin);
-    else if (a == aMin) a = aMax;
-    else a = a + (aMax - aMin);
+    float b;
+    if (a > aMax) b = a - (aMax - aMin);
+    else if (a == aMin) b = aMax;
+    else b = a + (aMax - aMin);
+    /* no progress: a is NaN, infinite or more than 2^24 widths away (a width no longer changes a float32), where the
+       reference's loop never ends (a max-cross-section step-back along a direction that is all but horizontal).
+       Such a position carries no information: the boundary value is as good as any (the kernels do the same). */
+    if (b == a || b != b) return aMax;
+    a = b;
   }
   return a;
 }
@@ -303,8 +309,13 @@ int64_t orc_compute_rt(const orc_problem *p, orc_mt *rng, int64_t n,
     for (size_t i = 1; i < ncell; i++) if (p->totalExt[i] > maxExt) maxExt = p->totalExt[i];
   }
   /* no extinction anywhere: tau / maxExt is an infinite step and the reference's makePeriodic never returns (:494-496,
-     :2063-2082).  The photon flies straight to the boundary, which is what ray tracing gives (the kernels do the same). */
-  if (!useRay && !(maxExt > 0.0f)) useRay = 1;
+     :2063-2082) -- nor does it once the step exceeds 2^24 domain widths (subtracting a width no longer changes a
+     float32).  In such an optically empty domain (width * maxExt <= 1e-5) the photon flies straight to the boundary,
+     which is what ray tracing gives (the kernels do the same). */
+  {
+    float wx = XE(p->nx + 1) - XE(1), wy = YE(p->ny + 1) - YE(1);
+    if (!useRay && !(maxExt * (wx < wy ? wx : wy) > 1e-5f)) useRay = 1;
+  }
   float x0 = cx.x0, xMax = XE(p->nx + 1), y0 = cx.y0, yMax = YE(p->ny + 1), z0 = cx.z0, zMax = ZE(p->nz + 1);
   float *contrib = NULL; int *ixF = NULL, *iyF = NULL;
   if (p->nDir > 0) {

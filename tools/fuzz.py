@@ -13,6 +13,8 @@ import i3rc_monte_carlo_model_amd as M
 from tests import cases
 from tests.test_gpu_parity import hg_table, make_gpu
 
+if os.environ.get('I3RC_LIB'):   # another build of the library
+    M.build.LIB = os.path.abspath(os.environ['I3RC_LIB']); M.build.needs_build = lambda: False
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 1), (int(sys.argv[2]) if len(sys.argv) > 2 else 200)
 log = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "fuzz.log"), "a")
 def note(*a):
@@ -102,8 +104,18 @@ for seed in range(first, first + count):
         # photon lives through -- mirror surfaces, no roulette -- the more of them do; "same" cannot see a photon that
         # chose another component and still ended alike, hence the weights are compared as a share too)
         events = max(1.0, float(np.mean(np.diff(ref["drawStart"]))) / 4.0)
+        if os.environ.get("SHOW") == "1":
+            for i in np.nonzero(~same)[0][:16]:
+                note("      photon", int(i), "fate", int(out["fate"][i]), int(ref["fate"][i]), "column", int(out["fateColumn"][i]), int(ref["fateColumn"][i]),
+                     "order", int(out["fateOrder"][i]), int(ref["fateOrder"][i]), "draws", int(out["drawsUsed"][i]), int(np.diff(ref["drawStart"])[i]))
+        if os.environ.get("SHOW") == "1":   # photons that ended alike but with another weight
+            for i in np.nonzero(same & (out["fateWeight"] != ref["fateWeight"]))[0][:12]:
+                note("      photon", int(i), "fate", int(ref["fate"][i]), "order", int(ref["fateOrder"][i]), "draws", int(out["drawsUsed"][i]),
+                     "weight gpu %.9g ref %.9g ratio %.7f" % (out["fateWeight"][i], ref["fateWeight"][i], out["fateWeight"][i] / max(ref["fateWeight"][i], 1e-38)))
         same &= out["fateWeight"] == ref["fateWeight"]
-        if same.mean() < 1.0 - 0.002 * events - 0.01 and (~same).sum() > 6: problems.append(("replay agreement", float(same.mean()), events))
+        # (optically thin media amplify a 1-ulp difference of the sampled optical depth to 1e-4 m of path: after some
+        # tens of events the positions are decimetres apart and a photon in fifty leaves through a neighbouring column)
+        if same.mean() < 1.0 - 0.006 * events - 0.01 and (~same).sum() > 6: problems.append(("replay agreement", float(same.mean()), events))
         # (a photon that parted ways carries its own contributions: up to 1 / mu of a grazing direction each)
         if abs(gi - ri) > (0.02 + 40.0 * (1.0 - same.mean())) * max(abs(ri), 1e-3) + 1e-6: problems.append(("radiance sums", gi, ri))
         note("   ok" if not problems else "   PROBLEM", problems, "identical %.4f of %d, radiance sums %.6g %.6g" % (same.mean(), m, gi, ri))
