@@ -419,3 +419,7 @@ def test_fuzz_random_configurations_in_a_process_of_their_own():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "1", "120"], capture_output=True, text=True, timeout=240,
                        env=dict(os.environ, I3RC_POISON="1", ORACLE="1"))
     assert r.returncode == 0 and "fuzz done 1 120 problems 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    # the same kind of configurations through the replay build against the oracle, photon by photon
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "2000", "100"], capture_output=True, text=True, timeout=240,
+                       env=dict(os.environ, I3RC_POISON="1", REPLAY="1"))
+    assert r.returncode == 0 and "fuzz done 2000 100 problems 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -62,6 +62,7 @@ for seed in range(first, first + count):
         keep = [int(v) for v in os.environ["NDIRS"].split(",")]
         p["intensityMus"] = [p["intensityMus"][i] for i in keep]; p["intensityPhis"] = [p["intensityPhis"][i] for i in keep]; nd = len(keep)
     n = int(rng.choice([1, 63, 1000, 30000]))
+    if "N" in os.environ: n = int(os.environ["N"])   # a closer look at one seed with a larger sample
     mu0, az = float(rng.uniform(0.05, 1.0)), float(rng.uniform(0, 360))
     explicit = rng.random() < 0.3
     if explicit:   # photons anywhere: relative positions in [0, 1], any direction but horizontal
