@@ -139,7 +139,14 @@ int i3rc_hip_zero_tallies(i3rc_hip_integrator *h);
 /* computeRT (:400-707) for one batch of nPhotons, ASYNCHRONOUS on the handle's stream; tallies accumulate.
  * RNG: per-photon Philox4x32-10 stream keyed by (seed0, seed1) -- the driver's seed=(/iseed, batch/)
  * (Example-Drivers/monteCarloDriver.f95:277) -- with the photon's index (firstPhoton + i) as counter, so a
- * photon's trajectory does not depend on how batches are split across launches or GPUs. */
+ * photon's trajectory does not depend on how batches are split across launches or GPUs.
+ * An explicit source (kind 1) is checked as the reference's photon-stream constructors check theirs
+ * (Code/monteCarloIllumination.f95:78-83, :124, :204, :369-371): relative positions in [0, 1], |mu| in (tiny, 1],
+ * finite azimuth; anything else fails with the reference's message.
+ * Where the reference indexes out of bounds or never returns (a photon starting at zIndex nz + 1, max cross-section
+ * on a domain without extinction, makePeriodic on a position 2^24 widths away, a NaN step) the kernels follow the
+ * rules written down in DESIGN.md section 3; they never read outside their arrays and every wave ends.
+ * Environment: I3RC_POISON=1 fills fresh device allocations with 0xFF bytes (debugging aid). */
 int i3rc_hip_launch_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int64_t firstPhoton,
                           int64_t nPhotons, const i3rc_source *src);
 
