@@ -47,9 +47,24 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 __device__ __forceinline__ void add_global(double *p, float v) { unsafeAtomicAdd(p, (double)v); }
 
+// Kernel arguments that are only needed now and then -- the reservoir refill, the counter hand-over, the epilogue --
+// are read from the kernarg segment where they are used (scalar loads) instead of living in scalar registers through
+// the whole photon loop: the flux kernel wanted 106 of the 102 there are, and every spilled one comes back as a
+// v_readlane, i.e. a vector instruction, in the event phase.  (The empty asm keeps the loads from being hoisted.)
+struct KernelArgs { DevProblem P; RunArgs A; };
+typedef const __attribute__((address_space(4))) KernelArgs *ColdArgs;
+__device__ __forceinline__ ColdArgs cold_args() {
+  ColdArgs k = (ColdArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(k));
+  return k;
+}
+
+
 struct Tally {
   const DevProblem &P;
   const Lds &L;
+  // (the tally buffer's base addresses stay in scalar registers: reading them from the kernarg segment at every
+  // tally -- see cold_args -- was measured: -8 % where the tallies go to global memory, nothing gained elsewhere)
   __device__ __forceinline__ void down(int col, float w) const {
     if (P.ldsTallies) lds_add(&L.tDown[col], w); else add_global(P.tally + P.oDown + col, w);
   }
@@ -157,14 +172,18 @@ struct RngInit<ReplayStream> {
 // bounds are wave-uniform and held in scalar registers (readfirstlane tells the compiler so).
 struct Reservoir {
   long long next, end;
-  __device__ __forceinline__ void refill(const RunArgs &A) {   // call in uniform control flow only
+  __device__ __forceinline__ void refill() {   // call in uniform control flow only
+    const ColdArgs k = cold_args();
+    unsigned long long *const counter = k->A.workCounter;
+    const int chunk = k->A.chunk;
+    const long long nPhotons = k->A.nPhotons;
     unsigned long long base = 0;
-    if ((threadIdx.x & 63) == 0) base = atomicAdd(A.workCounter, (unsigned long long)A.chunk);
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(counter, (unsigned long long)chunk);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)__shfl((unsigned)base, 0, 64));
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)__shfl((unsigned)(base >> 32), 0, 64));
     const long long b = (long long)(((unsigned long long)hi << 32) | lo);
-    next = b < A.nPhotons ? b : A.nPhotons;
-    end = b + A.chunk < A.nPhotons ? b + A.chunk : A.nPhotons;
+    next = b < nPhotons ? b : nPhotons;
+    end = b + chunk < nPhotons ? b + chunk : nPhotons;
   }
 };
 
@@ -241,7 +260,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
   int fate = -1, fateCol = -1;        // REPLAY builds
   float fateW = 0.0f;
   Reservoir res;
-  res.refill(A);
+  res.refill();
   // Radiance (local estimate) as part of the lane state machine instead of a loop nested in the event: after an
   // event the photon's own state is parked in LDS and the lane traces one shadow ray per radiance direction in the
   // common voxel-step phase; ray ends are handled in a light phase of their own (DEFER).  The replay build keeps
@@ -280,9 +299,11 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
     }
     if ((threadIdx.x & 63) == 0) {
       const uint32_t c[9] = {wc.photons, wc.dropped, wc.steps, wc.scat, wc.surf, wc.top, wc.roul, wc.shadow, wc.calls};
+      const ColdArgs ka = cold_args();
+      double *const counters = ka->P.tally + ka->P.oCnt;
 #pragma unroll
       for (int k = 0; k < 9; ++k)
-        if (c[k] != 0u) unsafeAtomicAdd(P.tally + P.oCnt + k, (double)c[k]);
+        if (c[k] != 0u) unsafeAtomicAdd(counters + k, (double)c[k]);
     }
     wc = WaveCounters();
   };
@@ -454,7 +475,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
           need -= (int)avail;
           rank -= (int)avail;
           flush_counters();
-          res.refill(A);
+          res.refill();
           avail = res.end - res.next;
         }
         const int taken = (int)(avail < (long long)need ? avail : (long long)need);   // < need only when the batch is exhausted
@@ -680,30 +701,37 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
 
   // ------------------------------------------------------------------ epilogue: flush tallies + counters
   __syncthreads();
-  if (P.ldsTallies) {
-    const int ncol = P.nx * P.ny;
-    for (int i = threadIdx.x; i < ncol; i += blockDim.x) {
-      const float u = L.tUp[i], d = L.tDown[i], a = L.tAbs[i];
-      if (u != 0.0f) add_global(P.tally + P.oUp + i, u);
-      if (d != 0.0f) add_global(P.tally + P.oDown + i, d);
-      if (a != 0.0f) add_global(P.tally + P.oAbs + i, a);
+  {
+    const ColdArgs ka = cold_args();   // (offsets and sizes straight from the kernarg segment: see cold_args)
+    double *const out = ka->P.tally;
+    if (ka->P.ldsTallies) {
+      const int ncol = ka->P.nx * ka->P.ny;
+      const int oUp = ka->P.oUp, oDown = ka->P.oDown, oAbs = ka->P.oAbs;
+      for (int i = threadIdx.x; i < ncol; i += blockDim.x) {
+        const float u = L.tUp[i], d = L.tDown[i], a = L.tAbs[i];
+        if (u != 0.0f) add_global(out + oUp + i, u);
+        if (d != 0.0f) add_global(out + oDown + i, d);
+        if (a != 0.0f) add_global(out + oAbs + i, a);
+      }
     }
-  }
-  if (P.ldsIntensity) {
-    const int nInt = (P.ncomp + 1) * P.nDir * P.nx * P.ny;
-    for (int i = threadIdx.x; i < nInt; i += blockDim.x) {
-      const float v = L.tInt[i];
-      if (v != 0.0f) add_global(P.tally + P.oInt + i, v);
+    if (ka->P.ldsIntensity) {
+      const int nInt = (ka->P.ncomp + 1) * ka->P.nDir * ka->P.nx * ka->P.ny;
+      const int oInt = ka->P.oInt;
+      for (int i = threadIdx.x; i < nInt; i += blockDim.x) {
+        const float v = L.tInt[i];
+        if (v != 0.0f) add_global(out + oInt + i, v);
+      }
     }
-  }
-  // nested local-estimate work and the deviate count are per lane; everything else is already per wave
-  const double nestedShadow = wave_sum((double)nested.shadow), nestedCalls = wave_sum((double)nested.calls);
-  const double draws = wave_sum((double)rng.total());
-  flush_counters();
-  if ((threadIdx.x & 63) == 0) {
-    if (nestedShadow != 0.0) unsafeAtomicAdd(P.tally + P.oCnt + I3RC_CNT_SHADOW_STEPS, nestedShadow);
-    if (nestedCalls != 0.0) unsafeAtomicAdd(P.tally + P.oCnt + I3RC_CNT_TRACER_CALLS, nestedCalls);
-    if (draws != 0.0) unsafeAtomicAdd(P.tally + P.oCnt + I3RC_CNT_RNG_DRAWS, draws);
+    // nested local-estimate work and the deviate count are per lane; everything else is already per wave
+    const double nestedShadow = wave_sum((double)nested.shadow), nestedCalls = wave_sum((double)nested.calls);
+    const double draws = wave_sum((double)rng.total());
+    flush_counters();
+    if ((threadIdx.x & 63) == 0) {
+      double *const counters = out + ka->P.oCnt;
+      if (nestedShadow != 0.0) unsafeAtomicAdd(counters + I3RC_CNT_SHADOW_STEPS, nestedShadow);
+      if (nestedCalls != 0.0) unsafeAtomicAdd(counters + I3RC_CNT_TRACER_CALLS, nestedCalls);
+      if (draws != 0.0) unsafeAtomicAdd(counters + I3RC_CNT_RNG_DRAWS, draws);
+    }
   }
 }
 

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256, 4) photon_pool_kernel(const DevProblem P,
   PhiloxStream rng;
   rng.init(A.seed0, A.seed1);
   Reservoir res;
-  res.refill(A);
+  res.refill();
   auto flush_counters = [&]() {
     if (lane == 0) {
       const uint32_t c[9] = {wc.photons, wc.dropped, wc.steps, wc.scat, wc.surf, wc.top, wc.roul, wc.shadow, wc.calls};
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256, 4) photon_pool_kernel(const DevProblem P,
         need -= (int)avail;
         rank -= (int)avail;
         flush_counters();
-        res.refill(A);
+        res.refill();
         avail = res.end - res.next;
       }
       const int taken = (int)(avail < (long long)need ? avail : (long long)need);   // < need only when the batch is exhausted
