@@ -3,7 +3,7 @@
 // Mapping (MI355X-first, not a port of the scalar Fortran loop nest):
 //   * one photon per LANE, 64 photons in flight per wavefront, persistent waves: a lane that loses its photon
 //     (exit, absorption, roulette, tracer drop) gets the next photon index from the wave's reservoir, which is
-//     refilled from a device-wide counter with one returning atomic per <= 1024 photons;
+//     refilled from a device-wide counter with one returning atomic per <= 256 photons;
 //   * the reference's three nested data-dependent loops (photon / order of scattering / voxel step,
 //     computeRT :452-691 + accumulateExtinctionAlongPath :1690-1806) are flattened into a lane state machine with
 //     ballot-gated phases: a VOXEL-STEP phase executed by the lanes that are tracing, an EVENT phase (exit tallies,
