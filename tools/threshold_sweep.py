@@ -6,7 +6,7 @@ from tests import cases
 
 hg64 = lambda: M.PhaseFunctionTable([M.henyey_greenstein(0.85, 64)])
 hg299 = lambda: M.PhaseFunctionTable([M.henyey_greenstein(0.85, 299)])
-CASES = {"step16": (lambda: cases.step_cloud(nlayers=16), hg64, 2e7), "step32": (lambda: cases.step_cloud(nlayers=32), hg64, 2e7),
+CASES = {"step16": (lambda: cases.step_cloud(nlayers=16), hg64, 1e8), "step32": (lambda: cases.step_cloud(nlayers=32), hg64, 2e7),
          "radar": (cases.radar_cloud, hg299, 1e7), "landsat": (cases.landsat_cloud, hg299, 1e7),
          "landsat36": (lambda: cases.landsat_cloud(nlayers=36), hg299, 1e7), "radar64": (cases.radar_cloud_64, hg299, 1e7)}
 for name in sys.argv[1:]:
@@ -16,7 +16,7 @@ for name in sys.argv[1:]:
     g = M.new_Integrator(dom); g.specifyParameters(minInverseTableSize=10001)
     g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 0)), M.new_PhotonStream(1.0, 0.0, 100000))
     out = []
-    for thr in (0, 8, 16, 24, 32, 40, 48):   # 0 = the per-wave adaptive default
+    for thr in (0, 8, 16, 24, 32, 36, 40, 44, 48, 52):   # 0 = the per-wave adaptive default
         g.set_tuning(thr, 0)
         best = 0
         for rep in range(2):
