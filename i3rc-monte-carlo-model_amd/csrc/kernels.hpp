@@ -281,8 +281,10 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
   int liThr = lightThreshold > 0 ? lightThreshold : -lightThreshold;
   const bool adaptEvent = evThreshold < 0, adaptLight = DEFER_BUILD && lightThreshold < 0;
   uint32_t raysStarted = 0;   // shadow rays since the last refill (wave-uniform)
-  // hands the wave's work counters over to the tally buffer (uniform control flow only)
-  auto flush_counters = [&]() {
+  uint32_t refills = 0;       // visits of the work counter by this wave
+  // re-fit the thresholds to what this wave has seen since its last hand-over (uniform control flow only)
+  uint32_t raysSeen = 0;      // shadow rays since the last hand-over
+  auto adapt_thresholds = [&]() {
     if (adaptEvent) {
       const float events = (float)(wc.scat + wc.photons + wc.surf), steps = (float)wc.steps;
       if (events > 0.0f && steps > 0.0f) {
@@ -291,12 +293,17 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
       }
     }
     if (adaptLight) {
-      if (raysStarted > 0u && wc.shadow > 0u) {
-        const int t = (int)(70.0f * __builtin_amdgcn_rsqf((float)wc.shadow * __builtin_amdgcn_rcpf((float)raysStarted)));
+      raysSeen += raysStarted; raysStarted = 0u;
+      if (raysSeen > 0u && wc.shadow > 0u) {
+        const int t = (int)(70.0f * __builtin_amdgcn_rsqf((float)wc.shadow * __builtin_amdgcn_rcpf((float)raysSeen)));
         liThr = __builtin_amdgcn_readfirstlane(t < 16 ? 16 : (t > 32 ? 32 : t));
       }
-      raysStarted = 0u;
     }
+  };
+  // hands the wave's work counters over to the tally buffer (uniform control flow only)
+  auto flush_counters = [&]() {
+    adapt_thresholds();
+    raysSeen = 0u;
     if ((threadIdx.x & 63) == 0) {
       const uint32_t c[9] = {wc.photons, wc.dropped, wc.steps, wc.scat, wc.surf, wc.top, wc.roul, wc.shadow, wc.calls};
       const ColdArgs ka = cold_args();
@@ -474,7 +481,10 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
           wc.photons += (unsigned)avail;                        // numPhotonsProcessed :459
           need -= (int)avail;
           rank -= (int)avail;
-          flush_counters();
+          // the counters go to the tally buffer (and the thresholds are re-fitted) at every fourth refill: the nine
+          // atomics of a hand-over all go to the same nine addresses, from every wave of the chip
+          if ((++refills & 3u) == 0u || wc.steps > 0x40000000u || wc.shadow > 0x40000000u) flush_counters();
+          else adapt_thresholds();
           res.refill();
           avail = res.end - res.next;
         }
