@@ -17,6 +17,7 @@
 //     geometry, of every scheduling threshold and of the number of GPUs;
 //   * work counters live in scalar registers (advanced by s_bcnt1 of ballots in uniform control flow).
 #pragma once
+#include <cstddef>
 #include "tracer.hpp"
 
 namespace i3rc {
@@ -51,7 +52,9 @@ __device__ __forceinline__ void add_global(double *p, float v) { unsafeAtomicAdd
 // are read from the kernarg segment where they are used (scalar loads) instead of living in scalar registers through
 // the whole photon loop: the flux kernel wanted 106 of the 102 there are, and every spilled one comes back as a
 // v_readlane, i.e. a vector instruction, in the event phase.  (The empty asm keeps the loads from being hoisted.)
-struct KernelArgs { DevProblem P; RunArgs A; };
+struct KernelArgs { DevProblem P; RunArgs A; };   // the kernarg segment of photon_kernel / photon_pool_kernel: (P, A, ...)
+static_assert(offsetof(KernelArgs, A) == sizeof(DevProblem) && sizeof(DevProblem) % 8 == 0 && alignof(RunArgs) == 8,
+              "the second kernel argument must follow the first without padding");
 typedef const __attribute__((address_space(4))) KernelArgs *ColdArgs;
 __device__ __forceinline__ ColdArgs cold_args() {
   ColdArgs k = (ColdArgs)__builtin_amdgcn_kernarg_segment_ptr();
