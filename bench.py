@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- photons/s of the I3RC photon-tracing hot path on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N --steps K --warmup W]        N=1 directly;
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   one rank per GPU (RCCL)
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME] [--scaling weak|strong]
 
-A "step" is one pass of the hot path (computeRadiativeTransfer :262-398 -> computeRT :400-707) over one batch
-of synthetic input: the I3RC step cloud (BASELINE.json configs[1]: 32x1x16, HG g=0.85, omega=1, mu0=1, flux
-up/down) with --photons photons per GPU per step (default 1e8 = the quoted photon count).  Weak scaling: every
-rank traces its own --photons photons (disjoint Philox counter ranges of the same (seed, batch) key), then
-the packed float64 tally buffer is summed across ranks with ONE all-reduce (RCCL over xGMI) -- the exchange
-that replaces Code/multipleProcesses_mpi.f95:57-131.  Inputs are resident in HBM before the timed region.
+`--gpus N` measures N GPUs BY ITSELF: called without a launcher (RANK unset) this process never touches the GPU; it
+starts N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, one per
+GPU), relays rank 0's JSON line and returns the ranks' exit code.  N = 1 goes through the same path.  Under an
+external launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) the process is a rank
+already; WORLD_SIZE must then equal --gpus, else the run aborts (exit 2).
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+A "step" is one pass of the hot path (computeRadiativeTransfer :262-398 -> computeRT :400-707) over one batch of
+synthetic input.  Default workload = BASELINE.json configs[1], the I3RC step cloud (32x1x16, HG g=0.85, omega=1, mu0=1,
+flux up/down) with 1e8 photons per GPU per step; `--config` selects the other BASELINE configurations
+(tools/workloads.py: radar64_nadir, landsat36, landsat119_7dir, ...).  Weak scaling (default): every rank traces its
+own --photons photons (disjoint Philox counter ranges of the same (seed, batch) key).  `--scaling strong`: ONE batch of
+--photons photons is sharded over the ranks by photon range (multigpu.shard_photons).  Either way the packed float64
+tally buffer is then summed across ranks with ONE all-reduce (RCCL over xGMI) -- the exchange that replaces the ten
+MPI_REDUCE calls of Code/multipleProcesses_mpi.f95:57-131 (Example-Drivers/monteCarloDriver.f95:333-352).
+Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 (DESIGN.md section 6 explains every field).
 """
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -23,9 +32,86 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# Vector-instruction issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles per SIMD once >= 2 waves
+# share it (guide: "v_fma_f32 (wave64) 2 cyc (SIMD-32); one wave alone: 4"), at the 2.4 GHz peak clock.  The kernels
+# run 5 waves per SIMD.  tools/microbench/opcost.hip `issue` measures the same figure on the box (profiles/r02_issue_peak.txt).
+N_SIMD = 256 * 4
+ISSUE_PEAK = N_SIMD * 2.4e9 / 2.0
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="step16", help="workload (tools/workloads.py); default = BASELINE.json configs[1]")
+    ap.add_argument("--photons", type=int, default=0, help="photons per GPU per step (weak) / per step (strong); 0 = the workload's")
+    ap.add_argument("--nlayers", type=int, default=16, help="step cloud: 16 = BASELINE.json label, 32 = reference generator (= --config step32)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if a.config == "step16" and a.nlayers == 32:
+        a.config = "step32"
+    return a
+
+
+def run_cpu_baseline(a):
+    """The oracle (kind "port") on the host cores, in a child process that never touches the GPU."""
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--config", a.config],
+                             capture_output=True, text=True, timeout=900, check=True).stdout.strip().splitlines()[-1]
+        cb = json.loads(out)
+        cb.pop("meanFluxUp", None)
+        return cb
+    except Exception as e:  # the baseline is reported, not required
+        return {"value": None, "unit": "photons/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: no GPU call, no torch import in this process
+# ------------------------------------------------------------------------------------------------------------------
+def launcher(a):
+    cpu_baseline = None
+    if a.gpus == 1 and not a.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(a)   # before any rank exists: the host cores are free
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), I3RC_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(codes):
+        sys.stderr.write(f"bench.py: rank exit codes {codes}\n")
+        sys.stdout.write(out0 or "")
+        return max(abs(c) for c in codes) or 1
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{"):
+            line = json.loads(ln)
+        else:
+            print(ln)
+    if line is None:
+        sys.stderr.write("bench.py: rank 0 printed no result line\n")
+        return 1
+    if cpu_baseline is not None:
+        line["cpu_baseline"] = cpu_baseline
+    line["launch"] = f"bench.py spawned {a.gpus} rank process(es) itself (one per GPU, 127.0.0.1:{port})"
+    print(json.dumps(line))
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------------------------
 def algorithmic_bytes_per_photon(c, n_dir=0, absorbing=False):
     """bytes/photon = 16 S + 20 K + 16 K [omega<1] + 8 E + 24 K D, from the kernel's own
     work counters (S cell steps incl. shadow rays, K scatterings, E boundary tallies, D directions)."""
@@ -36,49 +122,56 @@ def algorithmic_bytes_per_photon(c, n_dir=0, absorbing=False):
     return 16 * S + 20 * K + (16 * K if absorbing else 0) + 8 * E + 24 * K * n_dir, dict(S=S, K=K, E=E, D=n_dir)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--photons", type=int, default=100_000_000, help="photons per GPU per step")
-    ap.add_argument("--nlayers", type=int, default=16, help="16 = BASELINE.json label, 32 = reference generator")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
+def load_pmc(config):
+    """Counter figures of this workload's kernel from the committed rocprofv3 PMC passes (profiles/*_pmc.json, written
+    by tools/pmc_to_json.py from the summaries next to it): HBM bytes and vector instructions per photon."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if f.endswith("_pmc.json"):
+            try:
+                j = json.load(open(os.path.join(pdir, f)))
+            except Exception:
+                continue
+            if config in j:
+                best = dict(j[config], source="profiles/" + f)
+    return best
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+def worker(a):
+    rank = int(os.environ["RANK"])
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if world != a.gpus:
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: refusing to report a number for the wrong GPU count\n")
+        return 2
     n_gpus = world
-
-    # CPU baseline first (rank 0, N=1 only), in a child process, before this process touches the GPU.
+    # launched as a rank by somebody else (torchrun) at N = 1: the CPU baseline still runs first, in a child process,
+    # before this process touches the GPU
     cpu_baseline = None
-    if n_gpus == 1 and not a.no_cpu_baseline:
-        try:
-            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--nlayers", str(a.nlayers)],
-                                 capture_output=True, text=True, timeout=600, check=True).stdout.strip().splitlines()[-1]
-            cpu_baseline = json.loads(out)
-            cpu_baseline.pop("meanFluxUp", None)
-        except Exception as e:  # the baseline is reported, not required
-            cpu_baseline = {"value": None, "unit": "photons/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    if n_gpus == 1 and not a.no_cpu_baseline and not os.environ.get("I3RC_BENCH_SPAWNED"):
+        cpu_baseline = run_cpu_baseline(a)
 
     import numpy as np
     import torch
 
-    import i3rc_monte_carlo_model_amd as M
     from i3rc_monte_carlo_model_amd import binding as B
-    from i3rc_monte_carlo_model_amd.multigpu import all_reduce_tallies, max_over_ranks
-    from tests import cases
+    from i3rc_monte_carlo_model_amd.multigpu import all_reduce_tallies, max_over_ranks, shard_photons
+    import i3rc_monte_carlo_model_amd as M
+    from tools import workloads as W
 
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the integrator has no CPU fallback")
+        sys.stderr.write("bench.py needs a GPU: the integrator has no CPU fallback\n")
+        return 3
     # Rehearsal mode for a one-GPU box (never used by the driver): I3RC_BENCH_REHEARSAL=1 lets all ranks share GPU 0
-    # and reduces the tallies through gloo on host copies, so the N>1 control flow can be exercised without RCCL.
+    # and reduces the tallies through gloo on host copies, so the N>1 control flow can be exercised without RCCL
+    # (RCCL refuses two ranks on one device).
     rehearsal = os.environ.get("I3RC_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        sys.stderr.write(f"bench.py: rank {rank} wants GPU {local_rank} but only {torch.cuda.device_count()} visible\n")
+        return 3
     torch.cuda.set_device(local_rank)
     dist = None
     if n_gpus > 1:
@@ -88,28 +181,37 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == a.gpus
 
     # ---- problem: resident on the device before timing -------------------------------------------------
-    d = cases.step_cloud(nlayers=a.nlayers)
-    table = M.PhaseFunctionTable([M.henyey_greenstein(0.85, 64)])
-    dom = M.new_Domain(d["xe"], d["ye"], d["ze"])
-    dom.addOpticalComponent("cloud: non-absorbing", d["ext"], d["ssa"], d["pf"], table)
-    integ = M.new_Integrator(dom, device=local_rank)
-    integ.specifyParameters(surfaceAlbedo=0.0, minInverseTableSize=10001, useRayTracing=True, useRussianRoulette=True)
+    name, w = W.get(a.config)
+    integ, d = W.make_integrator(w, device=local_rank)
+    nd = W.n_dir(w)
+    absorbing = bool(np.any(d["ssa"][d["ext"] > 0] < 1.0))
+    per_step = a.photons or w["photons"]
+    if a.scaling == "strong":
+        first, mine = shard_photons(per_step, n_gpus, rank)
+        total_per_step = per_step
+    else:
+        first, mine = rank * per_step, per_step
+        total_per_step = per_step * n_gpus
     lay = integ.layout()
     tally = torch.zeros(lay.total, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream()
     lib = B.load()
     assert lib.i3rc_hip_bind_tally_buffer(integ._h, tally.data_ptr(), tally.numel() * 8) == 0
     assert lib.i3rc_hip_set_stream(integ._h, stream.cuda_stream) == 0
+    # tables are built (and uploaded) by the first call, as in the reference's 1-photon warm-up (monteCarloDriver.f95:233-253)
+    integ.launch(M.new_RandomNumberSequence((10, 0)), M.new_PhotonStream(w["mu0"], 0.0, 1), zero=True)
+    torch.cuda.synchronize()
 
     iseed = 10
 
     def step(batch):
-        # computeRadiativeTransfer zeroes its tallies per call (:296-309); rank r owns photons [r*n, (r+1)*n)
+        # computeRadiativeTransfer zeroes its tallies per call (:296-309)
         tally.zero_()
-        integ.launch(M.new_RandomNumberSequence((iseed, batch)), M.new_PhotonStream(1.0, 0.0, a.photons),
-                     firstPhoton=rank * a.photons, zero=False)
+        integ.launch(M.new_RandomNumberSequence((iseed, batch)), M.new_PhotonStream(w["mu0"], 0.0, mine),
+                     firstPhoton=first, zero=False)
         if rehearsal and dist is not None:
             host = tally.cpu()
             all_reduce_tallies(host, dist)
@@ -123,9 +225,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for w in range(a.warmup):
-        step(1000 + w)
+    for k in range(a.warmup):
+        step(1000 + k)
     sync()
+    launches_before = int(integ.timed_launches())
     t0 = time.perf_counter()
     for k in range(a.steps):
         step(1 + k)
@@ -133,35 +236,51 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, dist, device="cpu" if rehearsal else "cuda")
 
-    # ---- kernel durations of the K timed launches (HIP events recorded on the launch stream, read now) ------
-    kernel_ms = integ.kernel_ms_history(min(a.steps, 64))
+    # ---- kernel durations of the timed launches (HIP events recorded on the launch stream, read now) ------
+    n_launches = int(integ.timed_launches()) - launches_before   # a step is one launch unless a batch exceeds the launch limit
+    kernel_ms = integ.kernel_ms_history(min(n_launches, 64))
+    launches_per_step = n_launches / a.steps
     # ---- results of the last step (already all-reduced across ranks) ------------------------------------
     raw = tally.cpu().numpy()
     res = integ.finish(raw)
     counters = res["counters"]
-    # the last step's tallies must be those of exactly one step: every photon leaves through the top, reaches the
-    # (black) surface or is dropped by the tracer -- a wrong count or a lost / doubled tally shows here
-    closure = float(res["fluxUp"].mean() + res["fluxDown"].mean()) + counters["dropped"] / counters["photons"]
-    if counters["photons"] != float(a.photons) * n_gpus or abs(closure - 1.0) > 1e-4:
-        raise SystemExit(f"bench: inconsistent results (photons {counters['photons']:.0f}, energy closure {closure:.6f})")
-    local = {k: v / n_gpus for k, v in counters.items()}  # identical work per rank (weak scaling)
-    avg_ms = float(np.mean(kernel_ms))
-    bpp, skd = algorithmic_bytes_per_photon(local)
-    achieved = bpp * a.photons / (avg_ms * 1e-3) / 1e9
-
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            key = f"step_cloud_{a.nlayers}"
-            if key in tj and tj[key].get("photons"):
-                traffic = tj[key]["hbm_bytes_per_launch"] * (a.photons / tj[key]["photons"])
-        except Exception:
-            traffic = None
+    # the last step's tallies must be those of exactly one step: every photon leaves through the top, ends at the
+    # surface / by roulette or is dropped by the tracer -- a wrong count or a lost / doubled tally shows here
+    if counters["photons"] != float(total_per_step):
+        sys.stderr.write(f"bench: inconsistent results (photons {counters['photons']:.0f}, expected {total_per_step})\n")
+        return 4
+    albedo = w.get("surface", 0.0)
+    if albedo == 0.0 and not absorbing:
+        closure = float(res["fluxUp"].mean() + res["fluxDown"].mean()) + counters["dropped"] / counters["photons"]
+        if abs(closure - 1.0) > 1e-4:
+            sys.stderr.write(f"bench: energy closure {closure:.6f}\n")
+            return 4
+    devices = [f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"]
+    if dist is not None:
+        gathered = [None] * n_gpus
+        dist.all_gather_object(gathered, devices[0])
+        devices = gathered
 
     if rank == 0:
-        total_photons = float(a.photons) * n_gpus * a.steps
+        share = mine / float(total_per_step)   # this rank's share of the (all-reduced) work counters
+        local = {k: v * share for k, v in counters.items()}
+        avg_ms = float(np.mean(kernel_ms)) * launches_per_step     # kernel time per step on this rank
+        bpp, skd = algorithmic_bytes_per_photon(local, nd, absorbing)
+        achieved = bpp * mine / (avg_ms * 1e-3) / 1e9
+        pmc = load_pmc(name)
+        traffic = measured = issue = None
+        if pmc:
+            traffic = pmc["hbm_bytes_per_photon"] * mine
+            measured = traffic / (avg_ms * 1e-3) / 1e9
+            ipp = pmc["valu_instr_per_photon"]
+            rate = ipp * mine / (avg_ms * 1e-3)
+            issue = {"valu_instr_per_photon": ipp, "lane_occupancy": pmc["lane_occupancy"],
+                     "achieved_instr_per_s": rate, "peak": ISSUE_PEAK, "frac": rate / ISSUE_PEAK,
+                     "unit": "wave64 VALU instructions/s (whole chip)",
+                     "assumption": "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (>= 2 waves per SIMD; "
+                                   "guide constants table); counters from " + pmc["source"] + f" ({pmc.get('photons', 0):.0f} photons)",
+                     "useful_lane_frac": rate / ISSUE_PEAK * pmc["lane_occupancy"]}
+        total_photons = float(total_per_step) * a.steps
         value = total_photons / elapsed
         line = {
             "metric": "photons/s (whole node) + achieved HBM GB/s, I3RC step-cloud 1e8 photons",
@@ -172,30 +291,50 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": a.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"i3rcStepCloud 32x1x{a.nlayers} (HG g=0.85 64 moments, omega=1, mu0=1, albedo 0), "
-                                   f"{a.photons:.3g} photons per GPU per step, flux up/down",
-                       "photons_per_gpu_per_step": a.photons, "parallelism": f"photon batches sharded over {n_gpus} GPU(s), "
-                       "one RCCL all-reduce of the float64 tally buffer per step" if n_gpus > 1 else "single GPU",
+            "config": {"workload": f"{w['label']}; {mine:.4g} photons per GPU per step" +
+                                   (f" ({per_step:.4g} per step sharded over {n_gpus} GPUs)" if a.scaling == "strong" else ""),
+                       "name": name, "baseline_config_index": w["baseline_config"],
+                       "photons_per_gpu_per_step": mine, "photons_per_step": total_per_step,
+                       "parallelism": (f"photon batches sharded over {n_gpus} GPUs, one RCCL all-reduce of the float64 tally "
+                                       f"buffer ({lay.total * 8} bytes) per step" if n_gpus > 1 else "single GPU"),
                        "rng": "Philox4x32-10 per photon, key (iseed=10, batch)"},
+            "world_size": dist.get_world_size() if dist is not None else 1,
+            "backend": (dist.get_backend() if dist is not None else None),
+            "devices": devices,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "photon_kernel<PhiloxStream, false, false, GRID_LDS>", "kernel_ms_avg": avg_ms,
+                         "achieved_is": "ALGORITHMIC bytes (SURVEY.md 8d formula x the kernel's own S/K/E/D counters) / kernel time: "
+                                        "a model of what the reference loop touches, NOT bytes that crossed the HBM interface",
+                         "measured_hbm_GBps": measured,
+                         "measured_hbm_frac": (measured / HBM_PEAK_GBS if measured is not None else None),
+                         "kernel": integ.kernel_name(), "kernel_ms_avg": avg_ms, "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_photon": bpp, "per_photon": skd,
-                         "note": "working set is LDS/L2 resident: the path is latency/issue bound, not HBM bound (DESIGN.md)"},
+                         "issue": issue,
+                         "note": "working set is LDS/L2 resident: the path is vector-issue bound, not HBM bound -- see `issue` (DESIGN.md section 5)"},
             "cpu_baseline": cpu_baseline,
             "result_check": {"meanFluxUp": float(res["fluxUp"].mean()), "meanFluxDown": float(res["fluxDown"].mean()),
                              "dropped_fraction": counters["dropped"] / counters["photons"]},
         }
-        print(json.dumps(line))
+        if nd:
+            line["result_check"]["meanIntensity"] = [float(x) for x in res["intensity"].mean(axis=(1, 2))]
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     integ.finalize_Integrator()
+    return 0
+
+
+def main():
+    a = parse_args()
+    if "RANK" in os.environ:
+        return worker(a)
+    return launcher(a)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -20,14 +20,14 @@ NUM_COUNTERS = 16
 COUNTER_NAMES = ["photons", "dropped", "cellSteps", "scatterings", "surfaceHits", "exitsTop", "roulette",
                  "shadowSteps", "tracerCalls", "rngDraws"]
 
-# every symbol include/i3rc_hip.h declares (checked by tests/test_cabi_symbols.py)
+# every symbol include/i3rc_hip.h declares (checked by tests/test_host_cpu.py::test_cabi_library_exports_every_declared_symbol)
 SYMBOLS = [
     "i3rc_hip_create", "i3rc_hip_destroy", "i3rc_hip_last_error", "i3rc_hip_set_inverse_table",
     "i3rc_hip_set_forward_tables", "i3rc_hip_set_params", "i3rc_hip_set_surface", "i3rc_hip_set_directions",
     "i3rc_hip_get_tally_layout", "i3rc_hip_bind_tally_buffer", "i3rc_hip_set_stream", "i3rc_hip_use_own_stream", "i3rc_hip_zero_tallies",
     "i3rc_hip_launch_batch", "i3rc_hip_run_replay", "i3rc_hip_trace_rays", "i3rc_hip_synchronize",
     "i3rc_hip_fetch_tallies", "i3rc_hip_normalise", "i3rc_hip_last_kernel_ms", "i3rc_hip_kernel_ms_history", "i3rc_hip_set_tuning", "i3rc_hip_force_general_kernel", "i3rc_hip_select_kernel", "i3rc_hip_set_light_threshold", "i3rc_hip_set_launch_limit",
-    "i3rc_hip_philox_blocks", "i3rc_hip_arith_check", "i3rc_hip_device_count", "i3rc_hip_version",
+    "i3rc_hip_last_kernel_name", "i3rc_hip_timed_launch_count", "i3rc_hip_philox_blocks", "i3rc_hip_arith_check", "i3rc_hip_device_count", "i3rc_hip_version",
 ]
 
 
@@ -95,6 +95,10 @@ def load():
     L.i3rc_hip_normalise.argtypes = [H, dp, fp, fp, fp, fp, fp, fp]
     L.i3rc_hip_last_kernel_ms.argtypes = [H, fp]
     L.i3rc_hip_kernel_ms_history.argtypes = [H, C.c_int, fp]
+    L.i3rc_hip_last_kernel_name.argtypes = [H]
+    L.i3rc_hip_timed_launch_count.argtypes = [H]
+    L.i3rc_hip_timed_launch_count.restype = C.c_int64
+    L.i3rc_hip_last_kernel_name.restype = C.c_char_p
     L.i3rc_hip_set_tuning.argtypes = [H, C.c_int, C.c_int]
     L.i3rc_hip_force_general_kernel.argtypes = [H, C.c_int]
     L.i3rc_hip_select_kernel.argtypes = [H, C.c_int]

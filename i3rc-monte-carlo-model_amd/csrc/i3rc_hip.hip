@@ -85,6 +85,7 @@ struct i3rc_hip_integrator {
   int lightThreshold = 0;     // lanes with an ended shadow ray before a wave runs its light phase; 0 = adapted per wave
   int blocksPerCU = 0;  // 0 = from occupancy query
   int kernelVariant = I3RC_KERNEL_AUTO;  // test / tuning knob (i3rc_hip_select_kernel)
+  std::string lastKernelName;            // kernel the most recent launch ran (i3rc_hip_last_kernel_name)
   int64_t launchLimit = 0;               // photons per kernel launch (i3rc_hip_set_launch_limit); 0 = numCU * 2^22
   std::string err;
 
@@ -352,14 +353,19 @@ int i3rc_hip_set_directions(i3rc_hip_integrator *h, int nDir, const float *dirCo
   if (nDir > 0 && !dirCos) return h->fail("i3rc_hip_set_directions: null directions");
   for (int d = 0; d < nDir; ++d)
     if (std::fabs(dirCos[3 * d + 2]) < FLT_MIN) return h->fail("specifyParameters: intensityMus can't be 0 (directly sideways)");  // :932-933
-  HIPCHK(h, hipSetDevice(h->device));
-  if (nDir > 0) HIPCHK(h, hipMemcpy(h->dDir.p, dirCos, sizeof(float) * 3 * nDir, hipMemcpyHostToDevice));
+  // A change of nDir changes the tally layout.  With a caller-bound tally buffer that is refused BEFORE anything is
+  // touched: nDir, the device copy of the directions and the layout all stay as they are (the caller unbinds --
+  // i3rc_hip_bind_tally_buffer(h, NULL, 0) --, sets the directions, asks for the new layout and binds a buffer of that size).
   const bool changed = nDir != h->nDir;
+  if (changed && h->tally != (double *)h->ownTally.p)
+    return h->fail("i3rc_hip_set_directions: a caller-bound tally buffer is in use; unbind it (bind NULL) before changing nDir, "
+                   "then bind a buffer of the new layout's size");
+  HIPCHK(h, hipSetDevice(h->device));
+  // launches in flight on the (possibly non-blocking) stream read dDir / the tally buffer: drain them first
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (nDir > 0) HIPCHK(h, hipMemcpy(h->dDir.p, dirCos, sizeof(float) * 3 * nDir, hipMemcpyHostToDevice));
   h->nDir = nDir;
-  if (changed) {
-    if (h->tally != (double *)h->ownTally.p) return h->fail("i3rc_hip_set_directions: rebind the tally buffer after changing nDir");
-    return realloc_tally(h);
-  }
+  if (changed) return realloc_tally(h);
   return 0;
 }
 
@@ -595,6 +601,14 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
   using PoolKernel = void (*)(DevProblem, RunArgs);
   static const PoolKernel pools[3] = {photon_pool_kernel<GRID_LDS>, photon_pool_kernel<GRID_GLOBAL>, photon_pool_kernel<GRID_BRICKS>};
   const void *fn = pool ? (const void *)pools[place] : (const void *)kern;
+  {
+    static const char *const placeName[3] = {"GRID_LDS", "GRID_GLOBAL", "GRID_BRICKS"};
+    static thread_local char name[96];
+    if (pool) std::snprintf(name, sizeof(name), "photon_pool_kernel<%s>", placeName[place]);
+    else std::snprintf(name, sizeof(name), "photon_kernel<%s, %s, %s, %s>", Rng::kReplay ? "ReplayStream" : "PhiloxStream",
+                       plan.intensity ? "true" : "false", (simple ? "false" : "true"), placeName[place]);
+    h->lastKernelName = name;
+  }
   int perCU = h->blocksPerCU;
   if (perCU <= 0) {
     int occ = 0;
@@ -808,6 +822,10 @@ int i3rc_hip_kernel_ms_history(i3rc_hip_integrator *h, int n, float *ms) {
 }
 
 int i3rc_hip_last_kernel_ms(i3rc_hip_integrator *h, float *ms) { return i3rc_hip_kernel_ms_history(h, 1, ms); }
+
+int64_t i3rc_hip_timed_launch_count(const i3rc_hip_integrator *h) { return h ? (int64_t)h->timedLaunches : 0; }
+
+const char *i3rc_hip_last_kernel_name(const i3rc_hip_integrator *h) { return h ? h->lastKernelName.c_str() : ""; }
 
 int i3rc_hip_normalise(const i3rc_hip_integrator *h, const double *t, float *fluxUp, float *fluxDown, float *fluxAbsorbed,
                        float *volumeAbsorption, float *intensity, float *intensityByComponent) {

@@ -292,13 +292,14 @@ class Integrator:
                 phr = r32(r32(ph * PI_MCRT) / r32(180.0))
                 st = np.sqrt(r32(1.0) - m * m, dtype=np.float32)
                 d.append([st * np.cos(phr, dtype=np.float32), st * np.sin(phr, dtype=np.float32), m])  # :2041-2059
-            self.intensityDirections = np.array(d, np.float32).reshape(-1, 3)
+            dirs = np.array(d, np.float32).reshape(-1, 3)
+            self._check(self._lib.i3rc_hip_set_directions(self._h, len(d), pf(dirs)), "specifyParameters")
+            self.intensityDirections = dirs      # (only once the device has taken them: a refusal leaves the object as it was)
             self.computeIntensity = True
-            self._check(self._lib.i3rc_hip_set_directions(self._h, len(d), pf(self.intensityDirections)), "specifyParameters")
         if "computeIntensity" in kw and not kw["computeIntensity"] and "intensityMus" not in kw:
+            self._check(self._lib.i3rc_hip_set_directions(self._h, 0, None), "specifyParameters")
             self.intensityDirections = np.zeros((0, 3), np.float32)
             self.computeIntensity = False
-            self._check(self._lib.i3rc_hip_set_directions(self._h, 0, None), "specifyParameters")
         self._check(self._lib.i3rc_hip_set_params(self._h, C.byref(p)), "specifyParameters")
 
     # -- tabulateInversePhaseFunctions :1809-1861, tabulateForwardPhaseFunctions :1863-1923
@@ -393,6 +394,12 @@ class Integrator:
         ms = C.c_float(0)
         self._check(self._lib.i3rc_hip_last_kernel_ms(self._h, C.byref(ms)), "kernel_ms")
         return float(ms.value)
+
+    def timed_launches(self):
+        return int(self._lib.i3rc_hip_timed_launch_count(self._h))
+
+    def kernel_name(self):
+        return self._lib.i3rc_hip_last_kernel_name(self._h).decode()
 
     def kernel_ms_history(self, n):
         ms = np.zeros(n, np.float32)

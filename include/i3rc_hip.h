@@ -186,6 +186,13 @@ int i3rc_hip_last_kernel_ms(i3rc_hip_integrator *h, float *ms);
  * synchronising, so a timed region of many launches can be read back afterwards. */
 int i3rc_hip_kernel_ms_history(i3rc_hip_integrator *h, int n, float *ms);
 
+/* Number of kernel launches timed so far (a batch longer than the launch limit is several launches). */
+int64_t i3rc_hip_timed_launch_count(const i3rc_hip_integrator *h);
+
+/* Name of the kernel instantiation the most recent launch ran, as rocprofv3 lists it without the namespace
+ * (e.g. "photon_kernel<PhiloxStream, false, false, GRID_LDS>"); "" before the first launch. */
+const char *i3rc_hip_last_kernel_name(const i3rc_hip_integrator *h);
+
 /* Experiment knobs (not part of the reference API): lanes that must be waiting before a wavefront runs its
  * event phase (1..64; 0 = default: every wave adapts it to its photons' voxel steps per event, 64 / sqrt(steps per
  * event) within 12..44) and workgroups per CU (0 = occupancy query). */

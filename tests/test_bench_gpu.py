@@ -1,0 +1,56 @@
+"""bench.py end to end on the GPU box: the self-spawning launcher (one rank process per GPU), the N = 2 control flow
+(rehearsal mode: both ranks share GPU 0, tallies reduced through gloo -- RCCL refuses two ranks on one device) and
+the other BASELINE workloads at a small size."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, env=None, timeout=280):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_1_goes_through_the_spawn_path():
+    j = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--photons", "2000000", "--no-cpu-baseline"])
+    assert j["n_gpus"] == 1 and j["world_size"] == 1 and "spawned 1 rank" in j["launch"]
+    assert j["config"]["photons_per_step"] == 2000000 and j["value"] > 1e7
+    assert j["roofline"]["kernel"] == "photon_kernel<PhiloxStream, false, false, GRID_LDS>"
+    assert abs(j["result_check"]["meanFluxUp"] - 0.3253) < 2e-3
+    assert len(j["devices"]) == 1
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_two_ranks_end_to_end_in_rehearsal_mode(scaling):
+    n = 1000001
+    j = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--photons", str(n), "--scaling", scaling],
+               env=dict(I3RC_BENCH_REHEARSAL="1"))
+    assert j["n_gpus"] == 2 and j["world_size"] == 2 and j["backend"] == "gloo" and len(j["devices"]) == 2
+    assert j["scaling"] == scaling
+    # the all-reduced photon count is checked inside bench.py against exactly this figure
+    assert j["config"]["photons_per_step"] == (2 * n if scaling == "weak" else n)
+    assert j["config"]["photons_per_gpu_per_step"] == (n if scaling == "weak" else n // 2 + 1)
+    assert abs(j["result_check"]["meanFluxUp"] - 0.3253) < 3e-3
+
+
+@pytest.mark.parametrize("config,kernel", [("radar64_nadir", "photon_kernel<PhiloxStream, true, false, GRID_GLOBAL>"),
+                                           ("landsat36", "photon_kernel<PhiloxStream, false, false, GRID_GLOBAL>"),
+                                           ("landsat119_7dir", "photon_kernel<PhiloxStream, true, false, GRID_BRICKS>")])
+def test_other_baseline_workloads(config, kernel):
+    n = {"radar64_nadir": 2000000, "landsat36": 4000000, "landsat119_7dir": 300000}[config]
+    j = _bench(["--config", config, "--steps", "1", "--warmup", "0", "--photons", str(n), "--no-cpu-baseline"])
+    assert j["config"]["name"] == config and j["roofline"]["kernel"] == kernel
+    assert j["roofline"]["per_photon"]["S"] > 100
+    if config != "landsat36":
+        assert all(0.01 < x < 1.0 for x in j["result_check"]["meanIntensity"])

@@ -62,3 +62,32 @@ def test_two_rank_gloo_allreduce_equals_single_rank(tmp_path):
     assert np.array_equal(got[:-1], want)      # sums of counts are exact in float64
     assert got[-1] == 2.0                      # max over ranks
     assert got[3 * ncol] == n_total
+
+
+# ---- bench.py's own launcher (no GPU here: the ranks must fail loudly, and the launcher must say so) -------------
+def _bench(args, env=None, timeout=300):
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=e, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    # as a rank of somebody else's launcher with the wrong world size: exit 2, no result line
+    r = _bench(["--gpus", "8", "--no-cpu-baseline"], env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1"))
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and "{" not in r.stdout
+    r = _bench(["--gpus", "1", "--no-cpu-baseline"], env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2"))
+    assert r.returncode == 2
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour of the launcher")
+def test_bench_launcher_starts_n_ranks_and_reports_their_failure_without_a_gpu():
+    # --gpus 2 without a launcher: two rank processes are started (each says it needs a GPU), exit code non-zero
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a GPU") == 2, r.stderr
+    assert "rank exit codes [3, 3]" in r.stderr

@@ -423,3 +423,42 @@ def test_fuzz_random_configurations_in_a_process_of_their_own():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "2000", "100"], capture_output=True, text=True, timeout=240,
                        env=dict(os.environ, I3RC_POISON="1", REPLAY="1"))
     assert r.returncode == 0 and "fuzz done 2000 100 problems 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_changing_the_directions_under_a_bound_tally_buffer_is_refused_without_side_effects():
+    """i3rc_hip_set_directions with a caller-bound tally buffer: a change of nDir is refused BEFORE any state is touched
+    (nDir, the device directions and the layout stay), and the recovery the message prescribes -- unbind, set, ask for
+    the new layout, bind a buffer of that size -- gives a consistent handle (no launch with the new nDir over the old
+    offsets; round-1 advisor finding)."""
+    import ctypes as C
+
+    import torch
+
+    from i3rc_monte_carlo_model_amd import binding as B
+
+    d = cases.step_cloud(nlayers=8)
+    g = make_gpu(d, hg_table(), intensityMus=[1.0], intensityPhis=[0.0], minInverseTableSize=9001)
+    lib = B.load()
+    lay1 = g.layout()
+    buf1 = torch.zeros(lay1.total, dtype=torch.float64, device="cuda")
+    assert lib.i3rc_hip_bind_tally_buffer(g._h, buf1.data_ptr(), buf1.numel() * 8) == 0
+    with pytest.raises(M.I3RCError, match="caller-bound tally buffer"):
+        g.specifyParameters(intensityMus=[1.0, 0.5], intensityPhis=[0.0, 0.0])
+    assert g.layout().total == lay1.total                      # layout unchanged ...
+    r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 1)), M.new_PhotonStream(1.0, 0.0, 20000))
+    assert r["intensity"].shape[0] == 1 and r["counters"]["photons"] == 20000   # ... and still one direction on the device
+    # same nDir, new direction: allowed while bound
+    g.specifyParameters(intensityMus=[0.5], intensityPhis=[90.0])
+    # the prescribed recovery
+    assert lib.i3rc_hip_bind_tally_buffer(g._h, None, 0) == 0
+    g.specifyParameters(intensityMus=[1.0, 0.5], intensityPhis=[0.0, 0.0])
+    lay2 = g.layout()
+    assert lay2.total > lay1.total
+    assert lib.i3rc_hip_bind_tally_buffer(g._h, buf1.data_ptr(), buf1.numel() * 8) != 0        # the old buffer is too small now
+    buf2 = torch.zeros(lay2.total + 64, dtype=torch.float64, device="cuda")
+    assert lib.i3rc_hip_bind_tally_buffer(g._h, buf2.data_ptr(), lay2.total * 8) == 0
+    r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 1)), M.new_PhotonStream(1.0, 0.0, 20000))
+    assert r["intensity"].shape[0] == 2 and np.all(r["intensity"].mean(axis=(1, 2)) > 0)
+    torch.cuda.synchronize()
+    assert float(buf2[lay2.total:].abs().sum()) == 0.0         # nothing written past the layout
+    assert buf2[lay2.counters].item() == 20000.0

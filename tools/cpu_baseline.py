@@ -1,6 +1,10 @@
 """CPU baseline leg of bench.py: times the CPU oracle (oracle/, the C restatement of the reference's
 computeRT) on the host cores of the box, one process per core over disjoint batches -- the reference's own
-decomposition (Example-Drivers/monteCarloDriver.f95:264-274).  Never touches the GPU.  Prints one JSON line."""
+decomposition (Example-Drivers/monteCarloDriver.f95:264-274).  Never touches the GPU.  Prints one JSON line.
+
+kind "port": this is the C restatement, NOT the reference's Fortran (the reference cannot be built in this image:
+netCDF-Fortran is absent).  `reference_note` carries the survey-time figure of the reference
+itself for the nearest shape, so that the two can be set side by side."""
 import argparse
 import json
 import os
@@ -11,17 +15,32 @@ from concurrent.futures import ProcessPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+# the reference's own code, amdflang -O2, one core of an Intel Xeon @ 2.10 GHz (survey container)
+REFERENCE_NOTES = {
+    "step16": "reference Fortran (survey-time, SURVEY.md s6): 1.7-2.0e5 photons/s/core on step cloud 32x1x32 (S=63); this port timed here on 32x1x16 (S=45.8)",
+    "step32": "reference Fortran (survey-time, SURVEY.md s6): 1.7-2.0e5 photons/s/core on this shape (32x1x32, mu0=1)",
+    "radar640": "reference Fortran (survey-time): 7.9e4 photons/s/core on this shape (640x1x54 flux)",
+    "radar640_nadir": "reference Fortran (survey-time): 5.1e4 photons/s/core on this shape (640x1x54 + nadir radiance)",
+    "radar64_nadir": "reference Fortran (survey-time): 5.1e4 photons/s/core on the 640x1x54 field + nadir radiance (same field statistics)",
+    "landsat119": "reference Fortran (survey-time): 5.1e4 photons/s/core on this shape (128x128x119, mu0=1, flux)",
+    "landsat36": "reference Fortran (survey-time): 5.1e4 photons/s/core on 128x128x119 (S=241); this port timed here on 128x128x36 (S=150)",
+    "landsat119_7dir": "reference Fortran (survey-time): 7.2e3 photons/s/core on this shape (128x128x119, mu0=0.5, 7 directions, Lambertian 0.2)",
+    "landsat36_7dir": "reference Fortran (survey-time): 7.2e3 photons/s/core on 128x128x119 with the same 7 directions",
+}
+
 
 def _worker(args):
-    first_batch, n_batches, photons, nlayers, mu0 = args
+    first_batch, n_batches, photons, config, nlayers, mu0 = args
     import numpy as np  # noqa: F401
 
     from oracle import pyoracle as O
-    from tests import cases
+    from tools import workloads as W
 
-    d = cases.step_cloud(nlayers=nlayers)
-    inv = O.inverse_table_legendre(O.hg_coefficients(0.85, 64), 10001)
-    integ = O.Integrator(d["xe"], d["ye"], d["ze"], d["ext"], d["ssa"], d["pf"], [inv])
+    name, w = W.get(config)
+    if nlayers and name.startswith("step"):
+        w = dict(w, domain=("step_cloud", dict(nlayers=nlayers)))
+    integ, _ = W.make_oracle(w)
+    mu0 = w["mu0"] if mu0 is None else mu0
     t0 = time.perf_counter()
     fu = 0.0
     cols = []
@@ -36,18 +55,24 @@ def _worker(args):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="step16")
     ap.add_argument("--cores", type=int, default=0)
     ap.add_argument("--batches-per-core", type=int, default=10)
-    ap.add_argument("--photons", type=int, default=200000)
-    ap.add_argument("--nlayers", type=int, default=16)
-    ap.add_argument("--mu0", type=float, default=1.0)
+    ap.add_argument("--photons", type=int, default=0, help="photons per batch (0 = the workload's bounded sample)")
+    ap.add_argument("--nlayers", type=int, default=0, help="step cloud only: 16 = BASELINE.json label, 32 = reference generator")
+    ap.add_argument("--mu0", type=float, default=None)
     ap.add_argument("--save", default="", help="write the per-batch flux fields (fluxUp, fluxDown: batch x ny x nx) to this .npz")
     a = ap.parse_args()
     from oracle import pyoracle as O
+    from tools import workloads as W
 
     O.build()
+    name, w = W.get(a.config)
+    if a.nlayers == 32 and name == "step16":
+        name, w = W.get("step32")
+    photons = a.photons or w["cpu_photons"]
     cores = a.cores or min(16, len(os.sched_getaffinity(0)))
-    jobs = [(1 + i * a.batches_per_core, a.batches_per_core, a.photons, a.nlayers, a.mu0) for i in range(cores)]
+    jobs = [(1 + i * a.batches_per_core, a.batches_per_core, photons, name, a.nlayers, a.mu0) for i in range(cores)]
     t0 = time.perf_counter()
     with ProcessPoolExecutor(max_workers=cores) as ex:
         res = list(ex.map(_worker, jobs))
@@ -57,10 +82,16 @@ def main():
         import numpy as np
 
         np.savez(a.save, fluxUp=np.stack([c[0] for r in res for c in r[2]]), fluxDown=np.stack([c[1] for r in res for c in r[2]]))
-    total = cores * a.batches_per_core * a.photons
+    total = cores * a.batches_per_core * photons
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown CPU"
     print(json.dumps({"value": total / busy, "unit": "photons/s", "cores": cores, "kind": "port",
-                      "sample": f"{cores} processes x {a.batches_per_core} batches x {a.photons} photons of the same step cloud "
-                                f"(32x1x{a.nlayers}, mu0={a.mu0}), max busy time {busy:.1f} s, wall {wall:.1f} s",
+                      "sample": f"{cores} processes x {a.batches_per_core} batches x {photons} photons of the same workload "
+                                f"({name}), max busy time {busy:.1f} s, wall {wall:.1f} s, host {model}",
+                      "per_core": total / busy / cores,
+                      "reference_note": REFERENCE_NOTES.get(name, "") + "; kind 'port' = oracle/ C restatement, not the reference binary",
                       "meanFluxUp": sum(r[1] for r in res) / len(res)}))
 
 

@@ -1,0 +1,110 @@
+"""The benchmark workloads: BASELINE.json's configurations as synthetic inputs, shared by bench.py,
+tools/cpu_baseline.py, tools/run_case.py and tools/config_bench.py.  Pure description: nothing here touches the GPU
+or the oracle; `make_integrator` builds the product-side problem, `make_oracle` the checker-side one."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+DIRS7 = dict(intensityMus=[1.0, 0.5, 0.5, 0.8, 0.8, 0.3, 0.3], intensityPhis=[0.0, 0.0, 180.0, 90.0, 270.0, 45.0, 225.0])
+NADIR = dict(intensityMus=[1.0], intensityPhis=[0.0])
+RRI = dict(useRussianRouletteForIntensity=True, zetaMin=0.3)   # the driver's defaults (monteCarloDriver.f95:75-76)
+
+# name -> description of one workload.  `photons` = photons per GPU per step at the size BASELINE.json quotes
+# (configs 3 / 4: 1e9 photons over 8 GPUs = 1.25e8 per GPU); `cpu_photons` = photons per CPU-baseline batch so that the
+# bounded CPU sample is about 10-30 s on 16 cores.
+WORKLOADS = {
+    "step16": dict(label="i3rcStepCloud 32x1x16 (HG g=0.85 64 moments, omega=1, mu0=1, albedo 0), flux up/down",
+                   baseline_config=1, domain=("step_cloud", dict(nlayers=16)), moments=64, mu0=1.0, params={},
+                   photons=100_000_000, cpu_photons=200_000),
+    "step32": dict(label="i3rcStepCloud 32x1x32 (the reference generator's shape; HG g=0.85 64 moments, omega=1, mu0=1), flux",
+                   baseline_config=1, domain=("step_cloud", dict(nlayers=32)), moments=64, mu0=1.0, params={},
+                   photons=100_000_000, cpu_photons=200_000),
+    "radar64_nadir": dict(label="i3rcRadarCloud 64x64x54 MMCR domain (labelled synthetic, HG g=0.85 299 moments), flux + "
+                                "local-estimate nadir radiance (roulette, zetaMin 0.3)",
+                          baseline_config=2, domain=("radar_cloud_64", {}), moments=299, mu0=1.0, params=dict(**NADIR, **RRI),
+                          photons=100_000_000, cpu_photons=40_000),
+    "radar640": dict(label="i3rcRadarCloud 640x1x54 (reference-exact field), flux", baseline_config=2,
+                     domain=("radar_cloud", {}), moments=299, mu0=1.0, params={}, photons=100_000_000, cpu_photons=60_000),
+    "radar640_nadir": dict(label="i3rcRadarCloud 640x1x54 (reference-exact field), flux + nadir radiance (roulette, zetaMin 0.3)",
+                           baseline_config=2, domain=("radar_cloud", {}), moments=299, mu0=1.0, params=dict(**NADIR, **RRI),
+                           photons=100_000_000, cpu_photons=40_000),
+    "landsat36": dict(label="i3rcLandsatCloud 128x128x36 (labelled synthetic, HG g=0.85 299 moments, mu0=1), flux",
+                      baseline_config=3, domain=("landsat_cloud", dict(nlayers=36)), moments=299, mu0=1.0, params={},
+                      photons=125_000_000, cpu_photons=60_000),
+    "landsat119": dict(label="i3rcLandsatCloud 128x128x119 (reference-exact field, mu0=1), flux", baseline_config=3,
+                       domain=("landsat_cloud", {}), moments=299, mu0=1.0, params={}, photons=125_000_000, cpu_photons=40_000),
+    "landsat119_7dir": dict(label="i3rcLandsatCloud 128x128x119 + 7 radiance directions + Lambertian surface 0.2 "
+                                  "(surfaceProperties object), mu0=0.5, roulette zetaMin 0.3",
+                            baseline_config=4, domain=("landsat_cloud", {}), moments=299, mu0=0.5,
+                            params=dict(**DIRS7, **RRI), surface=0.2, photons=125_000_000, cpu_photons=6_000),
+    "landsat36_7dir": dict(label="i3rcLandsatCloud 128x128x36 + 7 radiance directions + Lambertian surface 0.2, mu0=0.5",
+                           baseline_config=4, domain=("landsat_cloud", dict(nlayers=36)), moments=299, mu0=0.5,
+                           params=dict(**DIRS7, **RRI), surface=0.2, photons=125_000_000, cpu_photons=8_000),
+}
+ALIASES = {"step_cloud": "step16", "landsat7": "landsat119_7dir", "radar_nadir": "radar640_nadir", "radar": "radar640",
+           "landsat": "landsat119"}
+
+
+def get(name):
+    name = ALIASES.get(name, name)
+    if name not in WORKLOADS:
+        raise SystemExit(f"unknown workload {name!r}; one of {sorted(WORKLOADS)}")
+    return name, WORKLOADS[name]
+
+
+def domain(w):
+    from tests import cases
+
+    fn, kw = w["domain"]
+    return getattr(cases, fn)(**kw)
+
+
+def n_dir(w):
+    return len(w["params"].get("intensityMus", ()))
+
+
+def make_integrator(w, device=0):
+    """The product-side problem (Python mirror of the reference's module API over the C ABI)."""
+    import i3rc_monte_carlo_model_amd as M
+
+    d = domain(w)
+    table = M.PhaseFunctionTable([M.henyey_greenstein(0.85, w["moments"])])
+    dom = M.new_Domain(d["xe"], d["ye"], d["ze"])
+    dom.addOpticalComponent("cloud", d["ext"], d["ssa"], d["pf"], table)
+    g = M.new_Integrator(dom, device=device)
+    kw = dict(w["params"])
+    if "surface" in w:
+        kw["surfaceBDRF"] = M.new_SurfaceDescription([w["surface"]])
+    else:
+        kw["surfaceAlbedo"] = 0.0
+    g.specifyParameters(minInverseTableSize=10001, minForwardTableSize=10001, useRayTracing=True, useRussianRoulette=True, **kw)
+    return g, d
+
+
+def make_oracle(w):
+    """The same problem for the CPU oracle (test infrastructure; bench.py's cpu_baseline leg only)."""
+    import numpy as np
+
+    from oracle import pyoracle as O
+
+    d = domain(w)
+    coef = O.hg_coefficients(0.85, w["moments"])
+    inv = O.inverse_table_legendre(coef, 10001)
+    nd = n_dir(w)
+    fwd = [O.forward_table_legendre(coef, 10001)] if nd else None
+    o = O.Integrator(d["xe"], d["ye"], d["ze"], d["ext"], d["ssa"], d["pf"], [inv], fwd, fwd)
+    kw = {}
+    if nd:
+        kw.update(intensityMus=w["params"]["intensityMus"], intensityPhis=w["params"]["intensityPhis"],
+                  useRRForIntensity=int(bool(w["params"].get("useRussianRouletteForIntensity"))),
+                  zetaMin=w["params"].get("zetaMin", 0.3))
+    if "surface" in w:   # new_SurfaceDescription((/ albedo /)): one cell with edges (0, huge), Code/surfaceProperties.f95:98-117
+        huge = np.finfo(np.float32).max
+        kw.update(surfaceBDRF=(np.array([0.0, huge], np.float32), np.array([0.0, huge], np.float32),
+                               np.array([[w["surface"]]], np.float32)))
+    if kw:
+        o.specify(**kw)
+    return o, d
