@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libi3rc_hip.so")
-SOURCES = ["i3rc_hip.hip", "kernels.hpp", "pool_kernel.hpp", "tracer.hpp", "philox.hpp"]
+SOURCES = ["i3rc_hip.hip", "kernels.hpp", "tracer.hpp", "philox.hpp"]
 HEADER = os.path.join(os.path.dirname(HERE), "include", "i3rc_hip.h")
 
 # -ffp-contract=off: float32 results must follow the reference's operator order (no FMA contraction);

@@ -12,7 +12,6 @@
 #include <vector>
 
 #include "kernels.hpp"
-#include "pool_kernel.hpp"
 
 using namespace i3rc;
 
@@ -427,7 +426,7 @@ int i3rc_hip_set_launch_limit(i3rc_hip_integrator *h, int64_t photons) {
 
 int i3rc_hip_select_kernel(i3rc_hip_integrator *h, int variant) {
   if (!h) return 1;
-  if (variant < I3RC_KERNEL_AUTO || variant > I3RC_KERNEL_POOL) return h->fail("i3rc_hip_select_kernel: unknown variant");
+  if (variant < I3RC_KERNEL_AUTO || variant > I3RC_KERNEL_LANE) return h->fail("i3rc_hip_select_kernel: unknown variant");
   h->kernelVariant = variant;
   return 0;
 }
@@ -445,12 +444,11 @@ struct LaunchPlan {
   DevProblem P;
   size_t ldsBytes;
   bool intensity;
-  bool pool;      // photon_pool_kernel (flux-only problems of the common class)
 };
 
 constexpr size_t kLdsBudget = 64 * 1024;  // per workgroup: leaves room for >= 2 workgroups per CU
 
-// Which kernel runs a launch (see photon_kernel / photon_pool_kernel): the common problem class -- regular grid,
+// Which kernel runs a launch (see photon_kernel): the common problem class -- regular grid,
 // ray tracing, one component, no BRDF grid, Directional source -- has specialised kernels.
 // A surface description with a single cell (new_SurfaceDescription((/ albedo /)), the form BASELINE.json's Landsat
 // radiance case uses) reflects like surfaceAlbedo: computeSurfaceReflectance returns its one parameter wherever the
@@ -465,12 +463,12 @@ bool traced(const i3rc_hip_integrator *h) {
 
 bool common_class(const i3rc_hip_integrator *h, int srcKind) {
   const bool gridSurface = h->params.useSurfaceBDRF && !uniform_surface(h);
-  return h->xyRegular && h->zRegular && traced(h) && !gridSurface && h->ncomp == 1 && srcKind == 0;
+  return h->xyRegular && traced(h) && !gridSurface && h->ncomp == 1 && srcKind == 0;
 }
 
 size_t ncell_bytes(const i3rc_hip_integrator *h) { return sizeof(float) * (size_t)h->nx * h->ny * h->nz; }
 
-int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool wantPool = false) {
+int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan) {
   DevProblem &P = plan.P;
   std::memset(&P, 0, sizeof(P));
   for (int c = 0; c < h->ncomp; ++c)
@@ -527,12 +525,9 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool wantPool = false
   size_t lds = sizeof(float) * ((h->nx + 1) + (h->ny + 1) + (h->nz + 1) + 3 * (size_t)h->nDir);
   if (h->nDir > 0) lds += sizeof(float) * kParkWords * 256;   // parked photon state of the radiance path
   if (lds > kLdsBudget) return h->fail("domain edge vectors do not fit in LDS");
-  // the pool kernel wants 4 workgroups per CU (160 KB of LDS): what the pools leave of 40 KB is the budget for
-  // edges, tallies and grid
-  plan.pool = wantPool && h->nDir == 0 && lds + kPoolBytesPerBlock <= 40 * 1024;
-  const size_t budget = plan.pool ? 40 * 1024 - (size_t)kPoolBytesPerBlock : kLdsBudget;
+  const size_t budget = kLdsBudget;
   P.ldsTallies = 0;
-  if (lds + 3 * ncol * sizeof(float) <= (plan.pool ? budget : kLdsBudget / 2)) { P.ldsTallies = 1; lds += 3 * ncol * sizeof(float); }
+  if (lds + 3 * ncol * sizeof(float) <= kLdsBudget / 2) { P.ldsTallies = 1; lds += 3 * ncol * sizeof(float); }
   P.ldsIntensity = 0;
   {
     const size_t nInt = (size_t)(h->ncomp + 1) * h->nDir * ncol * sizeof(float);
@@ -540,7 +535,6 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool wantPool = false
   }
   P.ldsGrid = 0;
   if (lds + ncell * sizeof(float) <= budget) { P.ldsGrid = 1; lds += ncell * sizeof(float); }
-  if (plan.pool) lds += kPoolBytesPerBlock;
   plan.ldsBytes = (lds + 15) & ~(size_t)15;
   plan.intensity = h->nDir > 0;
   return 0;
@@ -584,7 +578,6 @@ template <class Rng>
 int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, bool timeIt) {
   // fast specialisations when the problem is in the common class (see photon_kernel), else the general kernel
   const bool simple = !Rng::kReplay && common_class(h, A.srcKind) && h->kernelVariant != I3RC_KERNEL_GENERAL;
-  const bool pool = simple && plan.pool;
   // the specialised kernels exist once per place of the extinction grid (LDS / global / global in bricks)
   using Kernel = void (*)(DevProblem, RunArgs, int, int);
   const int place = plan.P.ldsGrid ? GRID_LDS : (plan.P.extBrick ? GRID_BRICKS : GRID_GLOBAL);
@@ -598,14 +591,11 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
         {photon_kernel<Rng, true, false, GRID_LDS>, photon_kernel<Rng, true, false, GRID_GLOBAL>, photon_kernel<Rng, true, false, GRID_BRICKS>}};
     if (simple) kern = special[plan.intensity ? 1 : 0][place];
   }
-  using PoolKernel = void (*)(DevProblem, RunArgs);
-  static const PoolKernel pools[3] = {photon_pool_kernel<GRID_LDS>, photon_pool_kernel<GRID_GLOBAL>, photon_pool_kernel<GRID_BRICKS>};
-  const void *fn = pool ? (const void *)pools[place] : (const void *)kern;
+  const void *fn = (const void *)kern;
   {
     static const char *const placeName[3] = {"GRID_LDS", "GRID_GLOBAL", "GRID_BRICKS"};
     static thread_local char name[96];
-    if (pool) std::snprintf(name, sizeof(name), "photon_pool_kernel<%s>", placeName[place]);
-    else std::snprintf(name, sizeof(name), "photon_kernel<%s, %s, %s, %s>", Rng::kReplay ? "ReplayStream" : "PhiloxStream",
+    std::snprintf(name, sizeof(name), "photon_kernel<%s, %s, %s, %s>", Rng::kReplay ? "ReplayStream" : "PhiloxStream",
                        plan.intensity ? "true" : "false", (simple ? "false" : "true"), placeName[place]);
     h->lastKernelName = name;
   }
@@ -625,12 +615,11 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
   // tuning knob): 128 loses a third (a returning atomic every other generation), 256...448 are equal, 1024 loses
   // 0.5 % on the step cloud and 2-5 % on the radar / Landsat cases to the imbalance at the end of a launch.
   static const long long chunkMax = std::getenv("I3RC_CHUNK_MAX") ? std::max(64ll, std::atoll(std::getenv("I3RC_CHUNK_MAX"))) : 256;
-  B.chunk = (int)std::min<long long>(chunkMax, std::max<long long>(pool ? kPool : 64, A.nPhotons / (blocks * 4 * 8)));
+  B.chunk = (int)std::min<long long>(chunkMax, std::max<long long>(64, A.nPhotons / (blocks * 4 * 8)));
   HIPCHK(h, hipMemsetAsync(A.workCounter, 0, sizeof(unsigned long long), h->stream));
   const int slot = (int)(h->timedLaunches % i3rc_hip_integrator::kEventRing);
   if (timeIt) HIPCHK(h, hipEventRecord(h->evStart[slot], h->stream));
-  if (pool) hipLaunchKernelGGL(pools[place], dim3((unsigned)blocks), dim3(256), plan.ldsBytes, h->stream, plan.P, B);
-  else {
+  {
     // thresholds the caller did not fix are adapted per wave (photon_kernel); negative = adaptive, starting value
     const int evThreshold = h->evThreshold > 0 ? h->evThreshold : -40;
     const int lightThreshold = h->lightThreshold > 0 ? h->lightThreshold : -24;
@@ -652,9 +641,7 @@ int i3rc_hip_launch_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1
   if (nPhotons <= 0) return h->fail("setIllumination: must ask for non-negative number of photons.");  // illumination :78-79
   HIPCHK(h, hipSetDevice(h->device));
   LaunchPlan plan;
-  // the pool kernel is an experiment (slower than the per-lane kernel on every case measured so far): on request only
-  const bool wantPool = common_class(h, src->kind) && nPhotons < ((int64_t)1 << 32) && h->kernelVariant == I3RC_KERNEL_POOL;
-  if (make_problem(h, plan, wantPool)) return 1;
+  if (make_problem(h, plan)) return 1;
   RunArgs A;
   std::memset(&A, 0, sizeof(A));
   A.seed0 = seed0; A.seed1 = seed1; A.firstPhoton = firstPhoton; A.nPhotons = nPhotons;

@@ -52,7 +52,7 @@ __device__ __forceinline__ void add_global(double *p, float v) { unsafeAtomicAdd
 // are read from the kernarg segment where they are used (scalar loads) instead of living in scalar registers through
 // the whole photon loop: the flux kernel wanted 106 of the 102 there are, and every spilled one comes back as a
 // v_readlane, i.e. a vector instruction, in the event phase.  (The empty asm keeps the loads from being hoisted.)
-struct KernelArgs { DevProblem P; RunArgs A; };   // the kernarg segment of photon_kernel / photon_pool_kernel: (P, A, ...)
+struct KernelArgs { DevProblem P; RunArgs A; };   // the kernarg segment of photon_kernel: (P, A, ...)
 static_assert(offsetof(KernelArgs, A) == sizeof(DevProblem) && sizeof(DevProblem) % 8 == 0 && alignof(RunArgs) == 8,
               "the second kernel argument must follow the first without padding");
 typedef const __attribute__((address_space(4))) KernelArgs *ColdArgs;
@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
   // Directional photons all start at z = z0 + (1 - spacing(1)) (zMax - z0): their start layer is wave-uniform
   const float zStart = P.z0 + (1.0f - spacingf(1.0f)) * (P.zMax - P.z0);
   int izStart = 1;
-  find_z<GENERAL>(P, L, zStart, izStart);
+  find_z<true>(P, L, zStart, izStart);   // (once per wave: the specialised kernels take irregular layers too)
   const float rcpDeltaX = refined_rcp(P.deltaX), rcpDeltaY = refined_rcp(P.deltaY);
   const float surfaceZ = P.z0 + spacingf(P.z0);
 

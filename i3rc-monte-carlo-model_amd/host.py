@@ -423,7 +423,7 @@ class Integrator:
         return out
 
     # -- test hooks
-    KERNELS = {"auto": 0, "general": 1, "lane": 2, "pool": 3}
+    KERNELS = {"auto": 0, "general": 1, "lane": 2}
 
     def set_tuning(self, evThreshold=0, blocksPerCU=0, forceGeneral=None, kernel=None, lightThreshold=None):
         """Experiment knobs of the C ABI (i3rc_hip_set_tuning / i3rc_hip_select_kernel); kernel is one of KERNELS."""

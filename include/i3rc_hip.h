@@ -207,13 +207,11 @@ int i3rc_hip_set_light_threshold(i3rc_hip_integrator *h, int lanes);
 int i3rc_hip_set_launch_limit(i3rc_hip_integrator *h, int64_t photons);
 
 /* Test / tuning knob.  A launch normally (AUTO) runs the one-photon-per-lane kernel specialised for the common
- * problem class (regular grid, ray tracing, one component, no BRDF grid, Directional source) when the problem is
+ * problem class (regular x / y grid, ray tracing, one component, no BRDF grid, Directional source) when the problem is
  * in it, else the general kernel.  All kernels trace the same photon paths from the same per-photon random streams,
  * so tests run one against the other.
- *   GENERAL: always the general kernel;  LANE: same choice as AUTO;
- *   POOL: the experimental two-photons-per-lane kernel with photon state in LDS (flux-only problems of the common
- *         class; fuller wavefronts, but measured slower than LANE -- DESIGN.md) where it applies. */
-enum { I3RC_KERNEL_AUTO = 0, I3RC_KERNEL_GENERAL = 1, I3RC_KERNEL_LANE = 2, I3RC_KERNEL_POOL = 3 };
+ *   GENERAL: always the general kernel;  LANE: same choice as AUTO. */
+enum { I3RC_KERNEL_AUTO = 0, I3RC_KERNEL_GENERAL = 1, I3RC_KERNEL_LANE = 2 };
 int i3rc_hip_select_kernel(i3rc_hip_integrator *h, int variant);
 /* = i3rc_hip_select_kernel(h, on ? I3RC_KERNEL_GENERAL : I3RC_KERNEL_AUTO) */
 int i3rc_hip_force_general_kernel(i3rc_hip_integrator *h, int on);

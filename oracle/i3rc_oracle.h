@@ -124,6 +124,18 @@ float orc_trace(const orc_problem *p, const float dir[3], float pos[3], int idx[
 void orc_photons_directional(orc_mt *rng, float solarMu, float solarAzimuthDeg, int64_t n,
                              float *xs, float *ys, float *zs, float *mus, float *phis);
 
+/* the other sources of Code/monteCarloIllumination.f95 (illumination.c): RandomAzimuth :106, Flux :148, Spotlight :187,
+ * Internal_Flux :228, Internal_Intensity :333.  deltaX / deltaY < 0 stand for an absent optional argument. */
+void orc_photons_random_azimuth(orc_mt *rng, float solarMu, int64_t n, float *xs, float *ys, float *zs, float *mus, float *phis);
+void orc_photons_flux(orc_mt *rng, int64_t n, float *xs, float *ys, float *zs, float *mus, float *phis);
+void orc_photons_spotlight(float solarMu, float solarAzimuthDeg, float solarX, float solarY, int64_t n,
+                           float *xs, float *ys, float *zs, float *mus, float *phis);
+void orc_photons_internal_flux(orc_mt *rng, float detX, float detY, float detZ, int pointsUp, float deltaX, float deltaY,
+                               int64_t n, float *xs, float *ys, float *zs, float *mus, float *phis);
+void orc_photons_internal_intensity(orc_mt *rng, float detX, float detY, float detZ, float detMu, float detPhiDeg,
+                                    float deltaX, float deltaY, int64_t n, float *xs, float *ys, float *zs, float *mus,
+                                    float *phis);
+
 /* Helpers shared with tests */
 void orc_regular_flags(const orc_problem *p, int *xyRegular, int *zRegular);     /* :193-211 */
 

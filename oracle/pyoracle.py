@@ -21,7 +21,7 @@ def build(force=False):
     """Compile the C restatement with gcc (seconds)."""
     if force or not os.path.exists(_SO) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_SO)
-        for f in ("numerics.c", "integrator.c", "i3rc_oracle.h", "Makefile")
+        for f in ("numerics.c", "integrator.c", "illumination.c", "i3rc_oracle.h", "Makefile")
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s", "clean", "all"])
     return _SO
@@ -79,6 +79,13 @@ def lib():
         L.orc_trace.restype = C.c_float
         L.orc_trace.argtypes = [C.POINTER(Problem), fp, fp, C.POINTER(C.c_int), C.c_int, C.c_float, lp]
         L.orc_photons_directional.argtypes = [C.POINTER(MT), C.c_float, C.c_float, C.c_int64, fp, fp, fp, fp, fp]
+        L.orc_photons_random_azimuth.argtypes = [C.POINTER(MT), C.c_float, C.c_int64, fp, fp, fp, fp, fp]
+        L.orc_photons_flux.argtypes = [C.POINTER(MT), C.c_int64, fp, fp, fp, fp, fp]
+        L.orc_photons_spotlight.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, fp, fp, fp, fp, fp]
+        L.orc_photons_internal_flux.argtypes = [C.POINTER(MT), C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float,
+                                                C.c_int64, fp, fp, fp, fp, fp]
+        L.orc_photons_internal_intensity.argtypes = [C.POINTER(MT), C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                                     C.c_float, C.c_float, C.c_int64, fp, fp, fp, fp, fp]
         _lib = L
     return _lib
 
@@ -341,3 +348,44 @@ def photons_directional(rng, solar_mu, solar_azimuth_deg, n):
     arrs = [np.zeros(n, np.float32) for _ in range(5)]
     lib().orc_photons_directional(C.byref(rng.t), C.c_float(solar_mu), C.c_float(solar_azimuth_deg), n, *[_pf(a) for a in arrs])
     return arrs
+
+
+def _five(n):
+    return [np.zeros(n, np.float32) for _ in range(5)]
+
+
+def photons_random_azimuth(rng, solar_mu, n):
+    """new_PhotonStream(solarMu, numberOfPhotons, randomNumbers): Code/monteCarloIllumination.f95:106-146."""
+    a = _five(n)
+    lib().orc_photons_random_azimuth(C.byref(rng.t), solar_mu, n, *[_pf(x) for x in a])
+    return a
+
+
+def photons_flux(rng, n):
+    """new_PhotonStream(numberOfPhotons, randomNumbers): :148-185 (flux on the horizontal equally weighted in mu)."""
+    a = _five(n)
+    lib().orc_photons_flux(C.byref(rng.t), n, *[_pf(x) for x in a])
+    return a
+
+
+def photons_spotlight(solar_mu, solar_azimuth_deg, solar_x, solar_y, n):
+    """new_PhotonStream(solarMu, solarAzimuth, solarX, solarY, numberOfPhotons): :187-226."""
+    a = _five(n)
+    lib().orc_photons_spotlight(solar_mu, solar_azimuth_deg, solar_x, solar_y, n, *[_pf(x) for x in a])
+    return a
+
+
+def photons_internal_flux(rng, x, y, z, points_up, n, delta_x=None, delta_y=None):
+    """new_PhotonStream(detectorX, detectorY, detectorZ, detectorPointsUp, [deltaX, deltaY,] ...): :228-331."""
+    a = _five(n)
+    lib().orc_photons_internal_flux(C.byref(rng.t), x, y, z, int(bool(points_up)), -1.0 if delta_x is None else delta_x,
+                                    -1.0 if delta_y is None else delta_y, n, *[_pf(v) for v in a])
+    return a
+
+
+def photons_internal_intensity(rng, x, y, z, mu, phi_deg, n, delta_x=None, delta_y=None):
+    """new_PhotonStream(detectorX, detectorY, detectorZ, detectorMu, detectorPhi, ...): :333-424 (phi stays in degrees)."""
+    a = _five(n)
+    lib().orc_photons_internal_intensity(C.byref(rng.t), x, y, z, mu, phi_deg, -1.0 if delta_x is None else delta_x,
+                                         -1.0 if delta_y is None else delta_y, n, *[_pf(v) for v in a])
+    return a

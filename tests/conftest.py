@@ -34,3 +34,25 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
             item.add_marker(pytest.mark.timeout(300))
+
+
+# ---- statistical retries are not silent --------------------------------------------------------------------------
+# The 3-sigma parity tests re-examine a first miss once on an independent, larger sample (test_gpu_parity._parity,
+# test_gpu_baseline_configs._two_stage).  Every such first miss is recorded here, raised as a warning and listed in a
+# summary line at the end of the session: a slowly growing bias shows first as stage-1 misses.
+STAGE1_MISSES = []
+
+
+def record_stage1_miss(what, detail):
+    import warnings
+
+    STAGE1_MISSES.append((what, str(detail)[:300]))
+    warnings.warn(f"statistical stage-1 miss in {what}: {str(detail)[:300]} (re-examined on an independent larger sample)",
+                  stacklevel=2)
+
+
+def pytest_terminal_summary(terminalreporter):
+    tr = terminalreporter
+    tr.write_sep("-", f"statistical stage-1 misses this session: {len(STAGE1_MISSES)}")
+    for what, detail in STAGE1_MISSES:
+        tr.write_line(f"  stage-1 miss: {what}: {detail}")

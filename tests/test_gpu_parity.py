@@ -233,6 +233,11 @@ def _parity(oracle, g, o, nb, n, mu0, az=0.0, keys=("fluxUp", "fluxDown"), floor
             _assert_3sigma(gr, orr, key, floor=floor)
         return gr, orr
     except AssertionError as first:
+        import inspect
+
+        from tests.conftest import record_stage1_miss
+        caller = next((f.function for f in inspect.stack()[1:] if f.function.startswith("test_")), "?")
+        record_stage1_miss(caller, first.args)
         gr = _batches_gpu(g, 2 * nb, n, mu0, az, iseed=11)
         orr = _batches_oracle(oracle, o, 2 * nb, n, mu0, az, iseed=11)
         try:
@@ -313,33 +318,30 @@ def test_specialised_and_general_kernels_trace_the_same_photons():
         assert np.allclose(a["raw"], b["raw"], rtol=1e-5, atol=1e-5)
 
 
-def test_pool_lane_and_general_kernels_trace_the_same_photons():
-    # flux-only problems of the common class run the photon-pool kernel (128 photons per wave in LDS, full
-    # wavefronts in every phase); the one-photon-per-lane kernel and the general kernel must give every photon the
-    # same fate: identical work counters, tallies equal up to the float32 order of the LDS partial sums
+def test_lane_and_general_kernels_trace_the_same_photons_for_any_batch_size():
+    # the specialised one-photon-per-lane kernel and the general kernel must give every photon the same fate:
+    # identical work counters, tallies equal up to the float32 order of the LDS partial sums -- grids and tallies in
+    # LDS or in HBM, reflecting surfaces, batches smaller than a wave / ending in the middle of a reservoir refill
     cfgs = [(cases.step_cloud(ssa=1.0, nlayers=16), 0.0, 1.0, 0.0, 200000),
             (cases.step_cloud(ssa=0.97, nlayers=32), 0.4, 0.5, 75.0, 60000),
             (cases.plane_parallel(optical_depth=0.3), 1.0, 0.3, 0.0, 20000),      # mirror-white surface, thin layer
             (cases.radar_cloud_64(), 0.1, 0.8, 200.0, 20000)]                      # tallies and grid in HBM, not in LDS
     for d, albedo, mu0, az, n in cfgs:
-        table = hg_table() if "table" not in d else d["table"]
-        g = make_gpu(d, table, surfaceAlbedo=albedo)
+        g = make_gpu(d, hg_table(), surfaceAlbedo=albedo)
         out = {}
-        for kernel in ("pool", "lane", "general"):
+        for kernel in ("lane", "general"):
             g.set_tuning(40, 0, kernel=kernel)
             out[kernel] = g.computeRadiativeTransfer(M.new_RandomNumberSequence((8, 2)), M.new_PhotonStream(mu0, az, n))
-        g.set_tuning(40, 0, kernel="auto")
-        for other in ("lane", "general"):
-            assert out["pool"]["counters"] == out[other]["counters"], other
-            assert np.allclose(out["pool"]["raw"], out[other]["raw"], rtol=2e-5, atol=1e-5), other
-        # a launch that ends in the middle of a pool refill, and one smaller than a pool
+        assert out["lane"]["counters"] == out["general"]["counters"]
+        assert np.allclose(out["lane"]["raw"], out["general"]["raw"], rtol=2e-5, atol=1e-5)
         for m in (1, 63, 129, 5000):
-            g.set_tuning(40, 0, kernel="pool")
+            g.set_tuning(40, 0, kernel="general")
             a = g.computeRadiativeTransfer(M.new_RandomNumberSequence((8, 3)), M.new_PhotonStream(mu0, az, m))
             g.set_tuning(40, 0, kernel="lane")
             b = g.computeRadiativeTransfer(M.new_RandomNumberSequence((8, 3)), M.new_PhotonStream(mu0, az, m))
             assert a["counters"] == b["counters"] and a["counters"]["photons"] == m
             assert np.allclose(a["raw"], b["raw"], rtol=2e-5, atol=1e-5)
+        g.set_tuning(40, 0, kernel="auto")
 
 
 def test_edge_cases_and_errors():
@@ -478,7 +480,7 @@ def test_random_regular_domains_against_the_oracle(oracle):
 
 
 def test_kernels_agree_on_random_regular_domains():
-    # randomised cross-check of the three kernels: regular grids of random shape (1-D, 2-D, 3-D; grid in LDS or in
+    # randomised cross-check of the two kernels: regular grids of random shape (1-D, 2-D, 3-D; grid in LDS or in
     # global memory), random extinction fields with holes, random single-scattering albedo (uniform or per cell),
     # surface albedo, sun position -- identical work counters, tallies equal up to float32 summation order
     rng = np.random.default_rng(2024)
@@ -489,10 +491,10 @@ def test_kernels_agree_on_random_regular_domains():
         g = make_gpu(d, hg_table(), surfaceAlbedo=albedo)
         n = 20000
         out = {}
-        for kernel in ("lane", "general", "pool"):
+        for kernel in ("lane", "general"):
             g.set_tuning(0, 0, kernel=kernel)
             out[kernel] = g.computeRadiativeTransfer(M.new_RandomNumberSequence((77, case)), M.new_PhotonStream(mu0, az, n))
-        for other in ("general", "pool"):
+        for other in ("general",):
             assert out["lane"]["counters"] == out[other]["counters"], (case, other, nx, ny, nz)
             assert np.allclose(out["lane"]["raw"], out[other]["raw"], rtol=3e-5, atol=2e-5), (case, other, nx, ny, nz)
         c = out["lane"]["counters"]

@@ -16,7 +16,7 @@ def summarise(out, workload):
     vals, photons = {}, 0
     for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "photon_kernel" in r["Kernel_Name"] or "photon_pool_kernel" in r["Kernel_Name"]:
+            if "photon_kernel" in r["Kernel_Name"]:
                 # the 1-photon table warm-up launch is a dispatch of the same kernel: its counts are negligible and included
                 vals[r["Counter_Name"]] = vals.get(r["Counter_Name"], 0) + float(r["Counter_Value"])
                 vals["_VGPR"] = r["VGPR_Count"]; vals["_SGPR"] = r["SGPR_Count"]; vals["_LDS"] = r["LDS_Block_Size"]
