@@ -95,10 +95,11 @@ def load():
     L.i3rc_hip_normalise.argtypes = [H, dp, fp, fp, fp, fp, fp, fp]
     L.i3rc_hip_last_kernel_ms.argtypes = [H, fp]
     L.i3rc_hip_kernel_ms_history.argtypes = [H, C.c_int, fp]
-    L.i3rc_hip_last_kernel_name.argtypes = [H]
-    L.i3rc_hip_timed_launch_count.argtypes = [H]
-    L.i3rc_hip_timed_launch_count.restype = C.c_int64
-    L.i3rc_hip_last_kernel_name.restype = C.c_char_p
+    if hasattr(L, "i3rc_hip_last_kernel_name"):   # (absent from older builds of the library loaded for A/B timing: tools/lib_compare.py)
+        L.i3rc_hip_last_kernel_name.argtypes = [H]
+        L.i3rc_hip_timed_launch_count.argtypes = [H]
+        L.i3rc_hip_timed_launch_count.restype = C.c_int64
+        L.i3rc_hip_last_kernel_name.restype = C.c_char_p
     L.i3rc_hip_set_tuning.argtypes = [H, C.c_int, C.c_int]
     L.i3rc_hip_force_general_kernel.argtypes = [H, C.c_int]
     L.i3rc_hip_select_kernel.argtypes = [H, C.c_int]

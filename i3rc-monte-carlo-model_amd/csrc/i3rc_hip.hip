@@ -523,7 +523,13 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan) {
   P.oExc = (int)h->layout.intensityExcess; P.oCnt = (int)h->layout.counters;
   const size_t ncol = (size_t)h->nx * h->ny, ncell = ncol * h->nz;
   size_t lds = sizeof(float) * ((h->nx + 1) + (h->ny + 1) + (h->nz + 1) + 3 * (size_t)h->nDir);
-  if (h->nDir > 0) lds += sizeof(float) * kParkWords * 256;   // parked photon state of the radiance path
+  // radiance runs: every wave's ring of local-estimate events (one record serves the nDir rays of an event) and its
+  // buffer of ready-made rays (photon_kernel, ray mode)
+  P.rayQueueCap = h->nDir > 0 ? 64 : 0;   // (an event phase pushes at most 64 records; the rays go on to the ready buffer)
+  if (h->nDir > 0) lds += sizeof(float) * 4 * (kRecWords * (size_t)P.rayQueueCap + kReadyWords * kReadyRays);
+  if (h->nDir > 0)
+    for (int c = 0; c < h->ncomp; ++c)
+      if (h->maxPfIndex[c] >= 65536) return h->fail("radiance runs take at most 65535 phase-function table entries per component");
   if (lds > kLdsBudget) return h->fail("domain edge vectors do not fit in LDS");
   const size_t budget = kLdsBudget;
   P.ldsTallies = 0;

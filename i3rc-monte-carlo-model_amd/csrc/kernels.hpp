@@ -6,10 +6,13 @@
 //     refilled from a device-wide counter with one returning atomic per <= 256 photons;
 //   * the reference's three nested data-dependent loops (photon / order of scattering / voxel step,
 //     computeRT :452-691 + accumulateExtinctionAlongPath :1690-1806) are flattened into a lane state machine with
-//     ballot-gated phases: a VOXEL-STEP phase executed by the lanes that are tracing, an EVENT phase (exit tallies,
+//     ballot-gated phases: a VOXEL-STEP phase executed by the lanes that are tracing and an EVENT phase (exit tallies,
 //     next photon, one Philox block for the whole wave, scatter / surface / new photon, new optical depth) that runs
-//     when enough lanes wait for it, and for radiances a LIGHT phase: local-estimate (shadow) rays are traced by the
-//     same voxel-step phase while the photon's own state is parked in LDS;
+//     when enough lanes wait for it;
+//   * radiances: an event pushes ONE record into its wave's ray queue (a ring in LDS) and the photon goes on; when the
+//     ring holds a wavefront's worth of local-estimate (shadow) rays the wave changes to RAY MODE, in which every lane
+//     pops an (event, direction) pair and traces it with the same voxel-step phase, popping the next as soon as its
+//     ray ends -- shadow rays run with nearly full wavefronts, independent of the photons that caused them;
 //   * cell edges (and, when they fit, the extinction grid) are staged in LDS with coalesced loads; grids beyond an
 //     XCD's L2 are read from a copy in 32-cell bricks; flux and radiance tallies are privatised per workgroup in LDS
 //     (ds_add_f32) and flushed once with float64 atomics; large domains tally straight to HBM with float64 atomics;
@@ -22,9 +25,7 @@
 
 namespace i3rc {
 
-enum LaneState { ST_TRACE = 0, ST_EVENT = 1, ST_DROPPED = 2, ST_NEW = 3, ST_DONE = 4,
-                 ST_SHADOW = 5,   // tracing a local-estimate (shadow) ray towards a radiance direction
-                 ST_LIGHT = 6 };  // a shadow ray ended, or the first one is due: needs the light phase
+enum LaneState { ST_TRACE = 0, ST_EVENT = 1, ST_DROPPED = 2, ST_NEW = 3, ST_DONE = 4 };
 
 // Work counters (I3RC_CNT_*) are kept per WAVE, in scalar registers: they are only ever advanced in uniform control
 // flow by the population count of a ballot, so they cost no vector registers and no vector instructions.  The
@@ -56,6 +57,7 @@ struct KernelArgs { DevProblem P; RunArgs A; };   // the kernarg segment of phot
 static_assert(offsetof(KernelArgs, A) == sizeof(DevProblem) && sizeof(DevProblem) % 8 == 0 && alignof(RunArgs) == 8,
               "the second kernel argument must follow the first without padding");
 typedef const __attribute__((address_space(4))) KernelArgs *ColdArgs;
+typedef __attribute__((address_space(4))) DevProblem ColdProblem;   // (as a template argument: Tally<ColdProblem>)
 __device__ __forceinline__ ColdArgs cold_args() {
   ColdArgs k = (ColdArgs)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(k));
@@ -63,8 +65,9 @@ __device__ __forceinline__ ColdArgs cold_args() {
 }
 
 
+template <class PR>
 struct Tally {
-  const DevProblem &P;
+  const PR &P;
   const Lds &L;
   // (the tally buffer's base addresses stay in scalar registers: reading them from the kernarg segment at every
   // tally -- see cold_args -- was measured: -8 % where the tallies go to global memory, nothing gained elsewhere)
@@ -88,8 +91,8 @@ struct Tally {
 };
 
 // computeIntensityContribution :1419-1611 for one event; adds straight into intensityByComponent.
-template <int GRID, class Rng>
-__device__ __forceinline__ void intensity_contribution(const DevProblem &P, const Lds &L, Rng &rng, NestedCounters &cnt,
+template <int GRID, class Rng, class PR>
+__device__ __forceinline__ void intensity_contribution(const PR &P, const Lds &L, Rng &rng, NestedCounters &cnt,
                                                        float weight, float x, float y, float z, int ix, int iy, int iz,
                                                        float dx, float dy, float dz, int component, int order) {
   const int zIndexMax = P.nz + 1;
@@ -106,7 +109,7 @@ __device__ __forceinline__ void intensity_contribution(const DevProblem &P, cons
       const float ang = acosf(proj);
       const size_t ncell = ncol * P.nz;
       const int pfi = max(P.pfIndex[(size_t)(component - 1) * ncell + cell_index(P, ix, iy, iz)], 1);
-      const CompTables ct = P.comp[component - 1];
+      const CompTables ct = load_tables(P.comp[component - 1]);
       const int n = ct.nFwd;
       const float *tab = ((P.useHybrid && order <= P.numOrdersOrig) ? ct.fwdOrig : ct.fwd) + (size_t)(pfi - 1) * n;
       normPF = lookup_phase(tab, n, ang) / ((4.0f * kPi) * fabsf(uz));
@@ -150,7 +153,7 @@ __device__ __forceinline__ void intensity_contribution(const DevProblem &P, cons
       add_global(P.tally + P.oExc + component * P.nDir + d, con - P.maxContrib);
       con = P.maxContrib;
     }
-    const Tally tl{P, L};
+    const Tally<PR> tl{P, L};
     tl.radiance(component, d, (r.iy - 1) * P.nx + (r.ix - 1), con);
   }
 }
@@ -160,14 +163,16 @@ struct RngInit;
 template <>
 struct RngInit<PhiloxStream> {
   static __device__ __forceinline__ void init(PhiloxStream &g, const RunArgs &A) { g.init(A.seed0, A.seed1); }
-  static __device__ __forceinline__ void start(PhiloxStream &g, const RunArgs &A, long long i) {
+  template <class AR>
+  static __device__ __forceinline__ void start(PhiloxStream &g, const AR &A, long long i) {
     g.start((uint64_t)(A.firstPhoton + i));
   }
 };
 template <>
 struct RngInit<ReplayStream> {
   static __device__ __forceinline__ void init(ReplayStream &g, const RunArgs &A) { g.init(A.randoms, A.nRandoms); }
-  static __device__ __forceinline__ void start(ReplayStream &g, const RunArgs &A, long long i) { g.start(A.drawStart[i]); }
+  template <class AR>
+  static __device__ __forceinline__ void start(ReplayStream &g, const AR &A, long long i) { g.start(A.drawStart[i]); }
 };
 
 // Wave-private reservoir of photon indices: one returning atomic per `chunk` photons instead of one per respawn
@@ -197,9 +202,9 @@ struct Reservoir {
 // Lambertian albedo (no BRDF grid), Directional source, production RNG: the rare paths (grid searches, periodic
 // re-wrapping loops, max-cross-section moves, BRDF lookups, component selection) are compiled out, which shrinks the
 // loop's code and its scalar-register pressure.  GENERAL = true keeps every path behind run-time switches.
-// (the general radiance kernel keeps the most state live: 4 waves per SIMD give it 128 vector registers and no spills)
+// (radiance kernels keep two rays per lane live -- the photon's and a shadow ray's: 4 waves per SIMD give them 128 vector registers)
 template <class Rng, bool INTENSITY, bool GENERAL, int GRID>
-__global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAVES) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
+__global__ void __launch_bounds__(256, INTENSITY ? 4 : I3RC_MIN_WAVES) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   {
@@ -211,8 +216,8 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
     L.tUp = p; L.tDown = p + ncol; L.tAbs = p + 2 * ncol;
     if (P.ldsTallies) p += 3 * ncol;
     L.dirCos = p; p += 3 * P.nDir;
-    L.park = p;
-    if (INTENSITY && !Rng::kReplay) p += kParkWords * 256;
+    L.queue = p;
+    if (INTENSITY && !Rng::kReplay) p += 4 * (kRecWords * P.rayQueueCap + kReadyWords * kReadyRays);
     L.tInt = p;
     if (P.ldsIntensity) p += (P.ncomp + 1) * P.nDir * ncol;
     L.ext = p;
@@ -233,9 +238,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
   __syncthreads();
 
   constexpr bool REPLAY = Rng::kReplay;        // per-photon fates are recorded by i3rc_hip_run_replay only
-  constexpr bool DEFER_BUILD = INTENSITY && !Rng::kReplay;   // radiances through the lane state machine (see DEFER below)
   constexpr bool NEED_PID = REPLAY || GENERAL; // explicit photon sources are indexed by photon number
-  const Tally tally{P, L};
   const size_t ncell = (size_t)P.nx * P.ny * P.nz;
   const bool rayTracing = GENERAL ? (P.useRayTracing != 0) : true;
   const bool useBDRF = GENERAL ? (P.useBDRF != 0) : false;
@@ -264,26 +267,62 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
   float fateW = 0.0f;
   Reservoir res;
   res.refill();
-  // Radiance (local estimate) as part of the lane state machine instead of a loop nested in the event: after an
-  // event the photon's own state is parked in LDS and the lane traces one shadow ray per radiance direction in the
-  // common voxel-step phase; ray ends are handled in a light phase of their own (DEFER).  The replay build keeps
-  // the reference's nested order (same deviates at the same places).
+
+  // ---- Radiance (local estimate) through a per-wave RAY QUEUE -------------------------------------------------------
+  // A scattering or reflection event does not trace its D local-estimate (shadow) rays itself and the photon does not
+  // wait for them: the event is pushed as ONE record (position, cell, weight, incoming direction, table entry, and the
+  // photon's Philox coordinates) into the wave's ring in LDS, and the photon goes on.  When the wave holds enough rays
+  // to fill the wavefront (or the ring has no room for the next event phase, or the photons are finished) it changes to
+  // RAY MODE, which has three phases:
+  //   EXPAND   all 64 lanes turn one (event, direction) pair each into a ready-made ray -- phase-function factor (acos,
+  //            table look-up), the ray's own Philox block, free path, roulette stage and target -- and put it into the
+  //            wave's buffer of ready rays: the expensive part of a ray's start runs with full wavefronts;
+  //   SERVICE  lanes whose ray has ended tally it and take the next ready ray (a dozen LDS reads), run when `liThr`
+  //            lanes wait;
+  //   STEP     one voxel step of every lane's ray -- nearly all lanes, since a lane whose ray ends is served soon.
+  // Photons and shadow rays have their own registers (r, sr) and their own loops: the wave runs the photon loop until a
+  // change of mode is due, then the ray loop, and back.
+  // When nothing is left to hand out and fewer than kLowWater rays are still under way the wave goes back to its photons;
+  // the unfinished rays go back to the ready buffer as they are and are resumed at the next change.  Every ray draws its two
+  // deviates from a Philox block of its own, counter (photon, block of the event, direction + 1 in the fourth word; the
+  // photon's own stream has 0 there): radiances do not depend on the schedule either.  Ray starts and ends use the
+  // hardware log / exp / reciprocal (2 ulp): these are weights of a Monte Carlo estimate, not trajectories.
+  // The replay build and max cross-section keep the reference's nested order (intensity_contribution).
   constexpr bool DEFER = INTENSITY && !Rng::kReplay;
-  float wI = 0.0f, normPF = 0.0f, tauFree = 0.0f;   // weight of the event, phase-function factor and free path of the current ray
-  int dIdx = 0, stage = -1;                          // direction being traced; -1 none, 0 plain, 1 small-contribution RR, 2/3 two-leg RR
+  const bool defer = DEFER && rayTracing;            // max cross-section moves the photon inside the event: nested order there
+  enum { R_EMPTY = 0, R_TRACE = 1, R_ENDED = 2 };
+#ifndef I3RC_STEP_AHEAD
+#define I3RC_STEP_AHEAD 2
+#endif
+#ifndef I3RC_LOW_WATER
+#define I3RC_LOW_WATER 56
+#endif
+#ifndef I3RC_PHOTON_STEP_AHEAD
+#define I3RC_PHOTON_STEP_AHEAD 64   /* off: measured -1.6 % (step cloud) ... +2.8 % (Landsat-36), -3 % on the radar field */
+#endif
+  // measured (Landsat + 7 directions, 2e7 photons): low water 16 / 32 / 48 / 56 / 64 -> 3.1 / 4.2 / 4.6 / 4.7 / 4.7e7 photons/s;
+  // two steps per pass +8 %; the radar cases (rays of two steps) do not care
+  constexpr int kLowWater = I3RC_LOW_WATER, kStepAhead = I3RC_STEP_AHEAD, kPhotonStepAhead = I3RC_PHOTON_STEP_AHEAD;
+  bool wantSlots = false, photonsLeft = true;         // wave-uniform
+  unsigned qTail = 0u, qHeadEv = 0u, qHeadSub = 0u;   // events pushed / events expanded completely / rays expanded of event qHeadEv
+  unsigned rdHead = 0u, rdTail = 0u;                  // ready rays taken / made
+  lds_float *const qBase = L.queue + (threadIdx.x >> 6) * (kRecWords * P.rayQueueCap + kReadyWords * kReadyRays);
+  lds_float *const rdBase = qBase + kRecWords * P.rayQueueCap;   // ready rays: word w of slot s at rdBase[w * kReadyRays + s]
+  const unsigned qMask = (unsigned)P.rayQueueCap - 1u;
+  const unsigned qMagic = (65536u + (unsigned)P.nDir - 1u) / (unsigned)(P.nDir > 0 ? P.nDir : 1);   // t / nDir = (t * qMagic) >> 16 for t < 200
   bool pendingShadow = false;
-  const bool defer = DEFER && rayTracing;            // max cross-section moves the photon inside the event: keep the nested order there
+  float wI = 0.0f, inDx = 0.0f, inDy = 0.0f, inDz = 0.0f;   // of the event being pushed
+  int evInfo = 0;
 
   // Thresholds: fixed when the caller asks for them (> 0), else adapted by every wave to its own photons at every
   // reservoir refill.  Event phase: the longer the photons' own traces (voxel steps per event), the more a
   // lane loses by waiting for others, so the threshold falls as 64 / sqrt(steps per event) (measured optima: 40 at
-  // 2.5 steps per event, 32 at 3.5, 24 at 9, 16 at 14 ... 16, with or without shadow rays in the mix).  Light phase: likewise with
-  // the length of the shadow rays, 70 / sqrt(steps per ray) within 16..32 (measured: 32 for the radar case's 2-step
-  // nadir rays, 16 for the Landsat case's 19-step rays).  Thresholds only schedule work: no photon path depends on them.
+  // 2.5 steps per event, 32 at 3.5, 24 at 9, 16 at 14 ... 16).  Ray mode's service phase: likewise with the length of
+  // the shadow rays, 70 / sqrt(steps per ray) within 16..32.  Thresholds only schedule work: no photon path depends on them.
   int evThr = evThreshold > 0 ? evThreshold : -evThreshold;
   int liThr = lightThreshold > 0 ? lightThreshold : -lightThreshold;
-  const bool adaptEvent = evThreshold < 0, adaptLight = DEFER_BUILD && lightThreshold < 0;
-  uint32_t raysStarted = 0;   // shadow rays since the last refill (wave-uniform)
+  const bool adaptEvent = evThreshold < 0, adaptLight = DEFER && lightThreshold < 0;
+  uint32_t raysStarted = 0;   // tracer calls for shadow rays since the last refill (wave-uniform)
   uint32_t refills = 0;       // visits of the work counter by this wave
   // re-fit the thresholds to what this wave has seen since its last hand-over (uniform control flow only)
   uint32_t raysSeen = 0;      // shadow rays since the last hand-over
@@ -327,124 +366,220 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
     }
     rng.close();
   };
-
-#ifdef I3RC_PROFILE_PHASES   // diagnostic build only (tools/phase_profile.sh): where do a wave's cycles go?
-  unsigned long long profEv = 0, profSt = 0, profNEv = 0, profNSt = 0, profLanesEv = 0, profLanesSt = 0, profNew = 0;
-  unsigned long long profSeg[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long profMark = 0;
-#define PROF_SEG(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); profSeg[k] += t_ - profMark; profMark = t_; } while (0)
-#else
-#define PROF_SEG(k) do {} while (0)
-#endif
+  // diagnostic build only (-DI3RC_PROFILE_PHASES, tools/phase_profile.py): where do a wave's cycles go?  Per phase kind:
+  // cycles (s_memtime), number of phases, lanes served.  The results leave through the volume-absorption tally.
+  enum { PH_EVENT = 0, PH_STEP = 1, PH_RAYSTEP = 2, PH_EXPAND = 3, PH_SERVICE = 4, PH_KINDS = 5 };
 #ifdef I3RC_PROFILE_PHASES
-#define PROF_T() __builtin_amdgcn_s_memtime()
+  unsigned long long profCycles[PH_KINDS] = {}, profCount[PH_KINDS] = {}, profLanes[PH_KINDS] = {};
+  unsigned long long profMark = 0;
+  const unsigned long long profStart = __builtin_amdgcn_s_memtime();
+#define PROF_BEGIN() (profMark = __builtin_amdgcn_s_memtime())
+#define PROF_END(kind, lanes) do { profCycles[kind] += __builtin_amdgcn_s_memtime() - profMark; profCount[kind]++; profLanes[kind] += (unsigned long long)(lanes); } while (0)
 #else
-#define PROF_T() 0ull
+#define PROF_BEGIN() do {} while (0)
+#define PROF_END(kind, lanes) do {} while (0)
 #endif
   for (;;) {
+    if (DEFER) {
+      // ============================================================================================== RAY MODE?
+      // enough local-estimate rays to fill the wavefront (or no room for the next event phase, or no photons left)?
+      const int work = (int)((qTail - qHeadEv) * (unsigned)P.nDir - qHeadSub) + (int)(rdTail - rdHead);
+      photonsLeft = __ballot(st != ST_DONE) != 0ull;
+      if (work > 0 && (work >= 64 || !photonsLeft || wantSlots)) {
+        wantSlots = false;
+        // this lane's shadow ray: registers of the ray loop only (rays still under way when the wave leaves go back to the
+        // ready buffer), so that the photon loop's register allocation knows nothing of them and the other way round
+        Ray sr;                                             // (every field is set when a lane takes a ray, before any use: no initial
+        int rst = R_EMPTY, sInfo;                           //  values, which would cost a register copy each at every pass of the photon loop)
+        float sW, sNorm, sTauFree;                          // state; component | direction << 8 | stage << 16 (bit 24: see EXPAND); weight, phase-function factor, free path
+        for (;;) {
+          const int ringRays = (int)((qTail - qHeadEv) * (unsigned)P.nDir - qHeadSub);   // rays waiting in the ring, not yet expanded
+          const int ready = (int)(rdTail - rdHead);                                        // ready-made rays
+          if (ready == 0 && ringRays > 0) {
+            // ------------------------------------------------------------ EXPAND phase: (event, direction) -> ready ray
+            const int n = ringRays < kReadyRays ? ringRays : kReadyRays;
+            const int lane = (int)(threadIdx.x & 63);
+            PROF_BEGIN();
+            const ColdArgs kx = cold_args();   // (the problem through the kernarg segment, as in the event phase)
+            const auto &Px = kx->P;
+            const auto &Ax = kx->A;
+            if (lane < n) {                                                  // next radiance direction (:1473-1510)
+              const unsigned t = qHeadSub + (unsigned)lane;
+              const unsigned eOff = (t * qMagic) >> 16;
+              const int dIdx = (int)(t - eOff * (unsigned)Px.nDir);
+              const lds_float *rec = qBase + ((qHeadEv + eOff) & qMask);
+              const int cap = Px.rayQueueCap;
+              const int info = __float_as_int(rec[10 * cap]);
+              const int comp = info & 0xff;
+              const float uz = L.dirCos[3 * dIdx + 2];
+              float norm;
+              if (comp < 1) norm = 1.0f / kPi;
+              else {
+                float proj = 0.0f;
+                proj += rec[7 * cap] * L.dirCos[3 * dIdx]; proj += rec[8 * cap] * L.dirCos[3 * dIdx + 1]; proj += rec[9 * cap] * uz;
+                if (fabsf(proj) > 1.0f) proj = copysignf(1.0f, proj);
+                const float ang = acosf(proj);
+                const int pfi = info >> 16;
+                const CompTables ct = GENERAL ? load_tables(Px.comp[comp - 1]) : load_tables(Px.comp0);
+                const float *tab = ((info & 0x100) ? ct.fwdOrig : ct.fwd) + (size_t)(pfi - 1) * ct.nFwd;
+                norm = fast_div(lookup_phase_fast(tab, ct.nFwd, ang), (4.0f * kPi) * fabsf(uz));
+              }
+              int stg = 0;
+              float tauFree = 0.0f, target = 0.0f;
+              if (Px.useRRI) {
+                // the ray's own Philox block: counter (photon, block of its event, direction + 1)
+                const Philox4 q4 = philox4x32_10(__float_as_uint(rec[11 * cap]), __float_as_uint(rec[12 * cap]),
+                                                 __float_as_uint(rec[13 * cap]), (uint32_t)dIdx + 1u, Ax.seed0, Ax.seed1);
+                rng.count_draws(2u);
+                tauFree = -fast_log(fmaxf(kTiny, u32_to_unit_float(q4.v[0])));
+                // small contribution: it counts -- with the weight of the roulette's bound -- with probability pi normPF / zetaMin
+                // (:1551-1559); the deviate is compared here, the outcome travels as bit 24 of the ray's info word
+                const float r2 = u32_to_unit_float(q4.v[1]);
+                if (kPi * norm <= Px.zetaMin) { stg = 1 | (r2 * Px.zetaMin <= kPi * norm ? 0x100 : 0); target = tauFree; }
+                else { stg = 2; target = -fast_log(fast_div(Px.zetaMin, fmaxf(kTiny, kPi * norm))); }   // tauMax
+              }
+              lds_float *out = rdBase + ((rdTail + (unsigned)lane) & (unsigned)(kReadyRays - 1));
+              out[0] = rec[0]; out[kReadyRays] = rec[cap]; out[2 * kReadyRays] = rec[2 * cap];
+              out[3 * kReadyRays] = rec[3 * cap]; out[4 * kReadyRays] = rec[4 * cap]; out[5 * kReadyRays] = rec[5 * cap];
+              out[6 * kReadyRays] = __int_as_float(comp | (dIdx << 8) | (stg << 16));
+              out[7 * kReadyRays] = rec[6 * cap];
+              out[8 * kReadyRays] = norm; out[9 * kReadyRays] = tauFree; out[10 * kReadyRays] = target; out[11 * kReadyRays] = 0.0f;
+            }
+            {   // ring bookkeeping (wave-uniform)
+              const unsigned t = qHeadSub + (unsigned)n;
+              const unsigned e = (t * qMagic) >> 16;
+              qHeadEv += e; qHeadSub = t - e * (unsigned)Px.nDir;
+              rdTail += (unsigned)n;
+            }
+            PROF_END(PH_EXPAND, n);
+            continue;   // (the loop's only other back edge: see below)
+          }
+          const unsigned long long actMask = __ballot(rst == R_TRACE), endMask = __ballot(rst == R_ENDED);
+          const int nAct = (int)__popcll(actMask), nIdle = 64 - nAct;
+          // with photons still to run, the wave leaves its rays once there is nothing left to hand out and few are under way
+          const bool leaving = ready == 0 && photonsLeft && nAct < kLowWater;   // (ready == 0 here implies an empty ring)
+          const bool canServe = endMask != 0ull || (ready > 0 && nIdle > 0);
+          if (canServe && (nIdle >= liThr || nAct == 0 || leaving)) {
+            // ------------------------------------------------------------ SERVICE phase (shadow-ray ends and starts)
+            PROF_BEGIN();
+            const ColdArgs kx = cold_args();
+            const auto &Px = kx->P;
+            const Tally<ColdProblem> tally{Px, L};
+            bool secondLeg = false;
+            if (rst == R_ENDED) {                                           // the ray that just ended (:1517-1596)
+              const float tauB = sr.acc;
+              const bool outTop = sr.iz >= Px.nz + 1;
+              const int comp = sInfo & 0xff, dIdx = (sInfo >> 8) & 0xff, stage = (sInfo >> 16) & 0xff;
+              const float direct = tauB >= 0.0f ? (sW * sNorm) * fast_exp(-tauB) : 0.0f;   // plain local estimate
+              const float capped = outTop ? sW * Px.zetaMin * (1.0f / kPi) : 0.0f;          // roulette survivor
+              float con = 0.0f;
+              if (stage == 0) con = direct;
+              else if (stage == 1) con = (sInfo & (0x100 << 16)) ? capped : 0.0f;
+              else if (stage == 2) {
+                if (outTop) con = direct;
+                else if (tauB >= 0.0f && sr.iz >= 1) {                      // second leg, up to the free path (:1576-1587)
+                  sr.acc = 0.0f; sr.target = sTauFree; sInfo = (sInfo & 0xffff) | (3 << 16); rst = R_TRACE; secondLeg = true;
+                }
+                // (a first leg that left through the BOTTOM -- a downward radiance direction -- gets no second leg: the
+                // reference starts one from outside the grid, reads zPosition(0) / totalExt(:, :, 0) out of bounds and
+                // discards the outcome, since only an exit through the top counts; the contribution is 0 either way)
+              } else con = capped;
+              if (rst == R_ENDED) {
+                if (Px.limitContrib && con > Px.maxContrib) {                // :1598-1609
+                  add_global(Px.tally + Px.oExc + comp * Px.nDir + dIdx, con - Px.maxContrib);
+                  con = Px.maxContrib;
+                }
+                tally.radiance(comp, dIdx, (sr.iy - 1) * Px.nx + (sr.ix - 1), con);
+                rst = R_EMPTY;
+              }
+            }
+            // hand ready rays to the free lanes, in order
+            const unsigned long long freeMask = __ballot(rst == R_EMPTY);
+            const int nFree = (int)__popcll(freeMask);
+            const int take = nFree < ready ? nFree : ready;
+            const int rank = lanes_below(freeMask);
+            if (rst == R_EMPTY && rank < take) {
+              const lds_float *in = rdBase + ((rdHead + (unsigned)rank) & (unsigned)(kReadyRays - 1));
+              sr.x = in[0]; sr.y = in[kReadyRays]; sr.z = in[2 * kReadyRays];
+              sr.ix = __float_as_int(in[3 * kReadyRays]); sr.iy = __float_as_int(in[4 * kReadyRays]); sr.iz = __float_as_int(in[5 * kReadyRays]);
+              sInfo = __float_as_int(in[6 * kReadyRays]);
+              sW = in[7 * kReadyRays]; sNorm = in[8 * kReadyRays]; sTauFree = in[9 * kReadyRays];
+              sr.target = in[10 * kReadyRays]; sr.acc = in[11 * kReadyRays];
+              const int dIdx = (sInfo >> 8) & 0xff;
+              sr.dx = L.dirCos[3 * dIdx]; sr.dy = L.dirCos[3 * dIdx + 1]; sr.dz = L.dirCos[3 * dIdx + 2];
+              sr.set_direction(L);
+              rst = R_TRACE;
+            }
+            rdHead += (unsigned)take;
+            const unsigned started = (unsigned)take + count_lanes(secondLeg);   // every start is one tracer call
+            wc.calls += started;
+            raysStarted += started;
+            PROF_END(PH_SERVICE, __popcll(endMask) + take);
+            continue;
+          }
+          if (nAct == 0 || leaving) {
+            // rays still under way (fewer than kLowWater, and the ready buffer is empty) go back to the ready buffer as they are
+            if (rst == R_TRACE) {
+              lds_float *out = rdBase + ((rdTail + (unsigned)lanes_below(actMask)) & (unsigned)(kReadyRays - 1));
+              out[0] = sr.x; out[kReadyRays] = sr.y; out[2 * kReadyRays] = sr.z;
+              out[3 * kReadyRays] = __int_as_float(sr.ix); out[4 * kReadyRays] = __int_as_float(sr.iy); out[5 * kReadyRays] = __int_as_float(sr.iz);
+              out[6 * kReadyRays] = __int_as_float(sInfo);
+              out[7 * kReadyRays] = sW; out[8 * kReadyRays] = sNorm; out[9 * kReadyRays] = sTauFree;
+              out[10 * kReadyRays] = sr.target; out[11 * kReadyRays] = sr.acc;
+            }
+            rdTail += (unsigned)nAct;
+            wc.calls -= (unsigned)nAct;      // (they are counted again when they are taken up: one tracer call each, whatever the schedule)
+            raysStarted -= (unsigned)nAct;
+            break;
+          }
+          // -------------------------------------------------------------- VOXEL-STEP phase (shadow rays)
+          // (a second step in the same pass while the next service phase is some lanes away: the phase logic above --
+          // ballots, counts, the decisions -- is paid once for both; written out twice, see the photons' step phase)
+          auto ray_step = [&]() {
+            const bool tracing = rst == R_TRACE;
+            const unsigned nTracing = count_lanes(tracing);
+            wc.shadow += nTracing;
+            PROF_BEGIN();
+            if (tracing) {   // a failed shadow ray contributes nothing (:1531-1535: its optical path is -2)
+              if (trace_step<GRID>(P, L, sr, (sInfo >> 16) != 0) != STEP_CONTINUE) rst = R_ENDED;
+            }
+            PROF_END(PH_RAYSTEP, nTracing);
+          };
+          ray_step();
+          if (liThr - nIdle > kStepAhead) ray_step();
+        }
+      }
+    }
+    // ================================================================================================ PHOTON MODE
     // ---------------------------------------------------------------- EVENT phase
     const bool wantEvent = st == ST_EVENT || st == ST_DROPPED || st == ST_NEW;
     const unsigned long long evMask = __ballot(wantEvent);
-    const unsigned long long trMask = __ballot(st == ST_TRACE || st == ST_SHADOW);
-    unsigned long long liMask = 0ull;
-    if (DEFER) {
-      liMask = __ballot(st == ST_LIGHT);
-      // ------------------------------------------------------------ LIGHT phase (shadow-ray ends and starts)
-      if (liMask != 0ull && (__popcll(liMask) >= liThr || trMask == 0ull)) {
-#ifdef I3RC_PROFILE_PHASES
-        const unsigned long long profL0 = __builtin_amdgcn_s_memtime();
-        profSeg[6] += (unsigned long long)__popcll(liMask);   // lanes served by light phases
-        profNew++;                                            // light phases
-#endif
-        if (st == ST_LIGHT) {
-          lds_float *park = L.park + threadIdx.x;
-          if (stage >= 0) {                                              // the ray that just ended (:1517-1596)
-            const float tauB = r.acc;
-            const bool outTop = r.iz >= P.nz + 1;
-            float con = 0.0f;
-            if (stage == 0) con = tauB >= 0.0f ? (wI * normPF) * expf(-tauB) : 0.0f;
-            else if (stage == 1) {
-              const float r2 = rng.next();
-              con = (r2 <= kPi * normPF / P.zetaMin && outTop) ? wI * P.zetaMin / kPi : 0.0f;
-            } else if (stage == 2) {
-              if (outTop && tauB >= 0.0f) con = (wI * normPF) * expf(-tauB);
-              else if (tauB >= 0.0f && r.iz >= 1) {                      // second leg, up to the free path (:1576-1587)
-                r.acc = 0.0f; r.target = tauFree; stage = 3; st = ST_SHADOW;
-              }
-              // (a first leg that left through the BOTTOM -- a downward radiance direction -- gets no second leg: the
-              // reference starts one from outside the grid, reads zPosition(0) / totalExt(:, :, 0) out of bounds and
-              // discards the outcome, since only an exit through the top counts; the contribution is 0 either way)
-            } else con = outTop ? wI * P.zetaMin / kPi : 0.0f;
-            if (st == ST_LIGHT) {
-              const int comp = __float_as_int(park[13 * 256]) & 0xff;
-              if (P.limitContrib && con > P.maxContrib) {                // :1598-1609
-                add_global(P.tally + P.oExc + comp * P.nDir + dIdx, con - P.maxContrib);
-                con = P.maxContrib;
-              }
-              tally.radiance(comp, dIdx, (r.iy - 1) * P.nx + (r.ix - 1), con);
-              dIdx++; stage = -1;
-            }
-          }
-          if (st == ST_LIGHT) {
-            r.x = park[0]; r.y = park[256]; r.z = park[2 * 256];
-            r.ix = __float_as_int(park[3 * 256]); r.iy = __float_as_int(park[4 * 256]); r.iz = __float_as_int(park[5 * 256]);
-            if (dIdx < P.nDir) {                                         // next radiance direction (:1473-1510)
-              const float ux = L.dirCos[3 * dIdx], uy = L.dirCos[3 * dIdx + 1], uz = L.dirCos[3 * dIdx + 2];
-              const int info = __float_as_int(park[13 * 256]);
-              const int comp = info & 0xff;
-              if (comp < 1) normPF = 1.0f / kPi;
-              else {
-                float proj = 0.0f;
-                proj += park[10 * 256] * ux; proj += park[11 * 256] * uy; proj += park[12 * 256] * uz;
-                if (fabsf(proj) > 1.0f) proj = copysignf(1.0f, proj);
-                const float ang = acosf(proj);
-                const int pfi = __float_as_int(park[14 * 256]);
-                const CompTables ct = GENERAL ? P.comp[comp - 1] : P.comp0;
-                const float *tab = ((info & 0x100) ? ct.fwdOrig : ct.fwd) + (size_t)(pfi - 1) * ct.nFwd;
-                normPF = lookup_phase(tab, ct.nFwd, ang) / ((4.0f * kPi) * fabsf(uz));
-              }
-              r.dx = ux; r.dy = uy; r.dz = uz;
-              r.set_direction(L);
-              r.acc = 0.0f; r.target = 0.0f;
-              if (!P.useRRI) stage = 0;
-              else {
-                tauFree = -logf(fmaxf(kTiny, rng.next()));
-                if (kPi * normPF <= P.zetaMin) { stage = 1; r.target = tauFree; }
-                else { stage = 2; r.target = -logf(P.zetaMin / fmaxf(kTiny, kPi * normPF)); }
-              }
-              st = ST_SHADOW;
-            } else if (w <= kTiny) {
-              st = ST_NEW;                                               // killed by roulette at this event
-            } else {                                                     // back to the photon's own path
-              r.dx = park[6 * 256]; r.dy = park[7 * 256]; r.dz = park[8 * 256];
-              r.target = park[9 * 256]; r.acc = 0.0f;
-              r.set_direction(L);
-              st = ST_TRACE;
-            }
-          }
-        }
-        // every lane that entered as ST_LIGHT and leaves as ST_SHADOW has started exactly one tracer call
-        const unsigned started = (unsigned)__popcll(__ballot(st == ST_SHADOW) & liMask);
-        wc.calls += started;
-        raysStarted += started;
-#ifdef I3RC_PROFILE_PHASES
-        profSeg[7] += __builtin_amdgcn_s_memtime() - profL0;    // cycles in light phases
-#endif
-      }
+    const unsigned long long trMask = __ballot(st == ST_TRACE);
+    if (evMask == 0ull && trMask == 0ull) break;   // (no photons left; any ray work has been done in ray mode above)
+    bool runEvent = evMask != 0ull && (__popcll(evMask) >= evThr || trMask == 0ull);
+    if (DEFER && runEvent && (int)(P.rayQueueCap - (int)(qTail - qHeadEv)) < (int)__popcll(evMask)) {
+      // every lane of the event phase may push one record: without room for all of them the rays are served first
+      wantSlots = true;
+      runEvent = false;
+      if (trMask == 0ull) continue;
     }
-    if (evMask == 0ull && trMask == 0ull && liMask == 0ull) break;
-    const unsigned long long profT0 = PROF_T();
-    if (evMask != 0ull && (__popcll(evMask) >= evThr || (trMask == 0ull && liMask == 0ull))) {
-#ifdef I3RC_PROFILE_PHASES
-      profNEv++; profLanesEv += __popcll(evMask);
-      profMark = __builtin_amdgcn_s_memtime();
-#endif
+    if (runEvent) {
+      // The event phase reads the problem through a pointer into the kernarg segment (scalar loads where they are
+      // needed) instead of keeping some sixty more values in scalar registers through the whole kernel: the kernel
+      // wanted well over twice the scalar registers there are, and every spilled one comes back as a v_readlane,
+      // a vector instruction, inside the voxel-step loops.  The step phases use the kernel argument itself.
+      const ColdArgs ke = cold_args();
+      const auto &Pe = ke->P;
+      const auto &Ae = ke->A;
+      const Tally<ColdProblem> tally{Pe, L};
+      PROF_BEGIN();
       // ---- part A: endings that need no random number -- tracer drop, exit through the top, arrival at a black
       //      surface -- are tallied first so that the lanes can be given their next photon before the wave
       //      generates its random block (part C), which then serves old and new photons in one go.
-      const bool blackSurface = !REPLAY && !useBDRF && !(P.albedo > kTiny) && !INTENSITY;
+      const bool blackSurface = !REPLAY && !useBDRF && !(Pe.albedo > kTiny) && !INTENSITY;
       const bool isEv = wantEvent && st == ST_EVENT;
       const bool dropped = wantEvent && st == ST_DROPPED;                 // :488-489
-      const bool atTop = isEv && r.z >= P.zMax;                           // :499-514
+      const bool atTop = isEv && r.z >= Pe.zMax;                           // :499-514
       const bool atSurface = isEv && !atTop && r.z <= surfaceZ;           // :515-531
       const bool atBlack = atSurface && blackSurface;                     // ... and :560-562
       wc.dropped += count_lanes(dropped);
@@ -454,12 +589,12 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
         // one merged branch for the three endings: a single tally atomic and a single bookkeeping block
         if (!dropped) {
           if (!rayTracing) {   // max cross-section: step back to the boundary (:504-511, :521-528)
-            const float zB = atTop ? P.zMax : P.z0;
-            r.x = make_periodic(r.x - r.dx * fabsf((r.z - zB) / r.dz), P.x0, P.xMax);
-            r.y = make_periodic(r.y - r.dy * fabsf((r.z - zB) / r.dz), P.y0, P.yMax);
-            find_xy<GENERAL>(P, L, r.x, r.y, r.ix, r.iy);
+            const float zB = atTop ? Pe.zMax : Pe.z0;
+            r.x = make_periodic(r.x - r.dx * fabsf((r.z - zB) / r.dz), Pe.x0, Pe.xMax);
+            r.y = make_periodic(r.y - r.dy * fabsf((r.z - zB) / r.dz), Pe.y0, Pe.yMax);
+            find_xy<GENERAL>(Pe, L, r.x, r.y, r.ix, r.iy);
           }
-          const int c2 = (r.iy - 1) * P.nx + (r.ix - 1);
+          const int c2 = (r.iy - 1) * Pe.nx + (r.ix - 1);
           tally.boundary(atTop, c2, w);
           if (REPLAY) { fateCol = c2; fateW = w; }
         }
@@ -470,7 +605,6 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
         close_photon();
         st = ST_NEW;
       }
-      PROF_SEG(0);
       // ---- part B (uniform): hand out photon indices from the wave's reservoir
       const bool isNew = wantEvent && st == ST_NEW;
       const unsigned long long newMask = __ballot(isNew);
@@ -479,7 +613,7 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
         int rank = lanes_below(newMask);
         long long mine = -1;
         long long avail = res.end - res.next;
-        if (avail < (long long)need && res.end < A.nPhotons) {   // drain the reservoir, then refill it (chunk >= 64 covers the rest)
+        if (avail < (long long)need && res.end < Ae.nPhotons) {   // drain the reservoir, then refill it (chunk >= 64 covers the rest)
           if (isNew && rank < (int)avail) mine = res.next + rank;
           wc.photons += (unsigned)avail;                        // numPhotonsProcessed :459
           need -= (int)avail;
@@ -498,75 +632,70 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
         if (isNew) {
           if (mine < 0) st = ST_DONE;
           else {
-            RngInit<Rng>::start(rng, A, mine);
+            RngInit<Rng>::start(rng, Ae, mine);
             if (NEED_PID) pid = mine;
           }
         }
       }
-      PROF_SEG(1);
       // ---- part C: one random block per lane for this event, then the event itself
       bool didScatter = false, didRoulette = false, startedTrace = false;   // per-lane flags -> wave counters below
       if (wantEvent && st != ST_DONE) {
-        rng.begin_event(DEFER_BUILD && P.useRRI != 0);   // the local estimate's roulette draws after the event
-        PROF_SEG(2);
+        rng.begin_event();
         if (st == ST_NEW) {                                               // :453-470
           float px, py, pz;
           if (directional) {   // newPhotonStream_Directional, Code/monteCarloIllumination.f95:91-99
             px = rng.first(); py = rng.second();
             pz = 1.0f - spacingf(1.0f);
-            r.dx = A.solarDx; r.dy = A.solarDy; r.dz = A.solarDz;
+            r.dx = Ae.solarDx; r.dy = Ae.solarDy; r.dz = Ae.solarDz;
           } else {
-            px = A.sx[pid]; py = A.sy[pid]; pz = A.sz[pid];
-            make_dircos(A.smu[pid], A.sphi[pid], r.dx, r.dy, r.dz);
+            px = Ae.sx[pid]; py = Ae.sy[pid]; pz = Ae.sz[pid];
+            make_dircos(Ae.smu[pid], Ae.sphi[pid], r.dx, r.dy, r.dz);
           }
           order = 0;
           if (REPLAY) { fate = -1; fateCol = -1; fateW = 0.0f; }
           w = 1.0f;
-          r.x = P.x0 + px * (P.xMax - P.x0);
-          r.y = P.y0 + py * (P.yMax - P.y0);
-          r.z = P.z0 + pz * (P.zMax - P.z0);
+          r.x = Pe.x0 + px * (Pe.xMax - Pe.x0);
+          r.y = Pe.y0 + py * (Pe.yMax - Pe.y0);
+          r.z = Pe.z0 + pz * (Pe.zMax - Pe.z0);
           r.ix = 1; r.iy = 1; r.iz = 1;
           if (!GENERAL) {   // findXYIndicies :1359-1369 with the divisions by the (uniform) cell sizes done by reciprocal
-            int i = min((int)exact_div(r.x - P.x0, P.deltaX, rcpDeltaX) + 1, P.nx);
-            int j = min((int)exact_div(r.y - P.y0, P.deltaY, rcpDeltaY) + 1, P.ny);
+            int i = min((int)exact_div(r.x - Pe.x0, Pe.deltaX, rcpDeltaX) + 1, Pe.nx);
+            int j = min((int)exact_div(r.y - Pe.y0, Pe.deltaY, rcpDeltaY) + 1, Pe.ny);
             if (fabsf(L.xE[i] - r.x) < spacingf(r.x)) i = i + 1;
             if (fabsf(L.yE[j] - r.y) < spacingf(r.y)) j = j + 1;
-            r.ix = i == P.nx + 1 ? 1 : i;
-            r.iy = j == P.ny + 1 ? 1 : j;
+            r.ix = i == Pe.nx + 1 ? 1 : i;
+            r.iy = j == Pe.ny + 1 ? 1 : j;
             r.iz = izStart;
           } else {
-            find_xy<GENERAL>(P, L, r.x, r.y, r.ix, r.iy);
-            find_z<GENERAL>(P, L, r.z, r.iz);
+            find_xy<GENERAL>(Pe, L, r.x, r.y, r.ix, r.iy);
+            find_z<GENERAL>(Pe, L, r.z, r.iz);
           }
           st = ST_TRACE;
         }
-        PROF_SEG(3);
         if (st == ST_EVENT) {
           if (r.z <= surfaceZ) {                                          // :515-580
             order++;
             if (!rayTracing) {
-              r.x = make_periodic(r.x - r.dx * fabsf((r.z - P.z0) / r.dz), P.x0, P.xMax);
-              r.y = make_periodic(r.y - r.dy * fabsf((r.z - P.z0) / r.dz), P.y0, P.yMax);
-              find_xy<GENERAL>(P, L, r.x, r.y, r.ix, r.iy);
+              r.x = make_periodic(r.x - r.dx * fabsf((r.z - Pe.z0) / r.dz), Pe.x0, Pe.xMax);
+              r.y = make_periodic(r.y - r.dy * fabsf((r.z - Pe.z0) / r.dz), Pe.y0, Pe.yMax);
+              find_xy<GENERAL>(Pe, L, r.x, r.y, r.ix, r.iy);
             }
             r.iz = 1;
             r.z = surfaceZ;
-            const int c2 = (r.iy - 1) * P.nx + (r.ix - 1);
+            const int c2 = (r.iy - 1) * Pe.nx + (r.ix - 1);
             tally.down(c2, w);
             if (REPLAY) { fateCol = c2; fateW = w; }
             float mu = exact_sqrt(rng.first());
-            while (!(fabsf(mu) > 2.0f * kTiny)) mu = exact_sqrt(rng.next());   // :546-549
+            while (!(fabsf(mu) > 2.0f * kTiny)) mu = exact_sqrt(GENERAL ? rng.next() : rng.fresh());   // :546-549
             const float phi = (2.0f * kPi) * rng.second();
-            if (useBDRF) w = w * surface_reflectance(P, r.x, r.y);
-            else w = w * P.albedo;
+            if (useBDRF) w = w * surface_reflectance(Pe, r.x, r.y);
+            else w = w * Pe.albedo;
             if (w <= kTiny) { if (REPLAY) fate = 1; st = ST_NEW; }
             else {
               make_dircos(mu, phi, r.dx, r.dy, r.dz);
-              if (defer) {
-                pendingShadow = true; wI = w;
-                L.park[13 * 256 + threadIdx.x] = __int_as_float(0);     // component 0: the surface
-              } else if (INTENSITY)
-                intensity_contribution<GRID>(P, L, rng, nested, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, 0, order);
+              if (defer) { pendingShadow = true; wI = w; evInfo = 0; }    // component 0: the surface (:567-580)
+              else if (INTENSITY)
+                intensity_contribution<GRID>(Pe, L, rng, nested, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, 0, order);
               st = ST_TRACE;
             }
           } else {                                                        // :581-689
@@ -577,10 +706,10 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
               // those of the photon's start or of its last surface hit.  A start index of nz + 1 (a photon that starts
               // within spacing() of the domain top: thin elevated domains) is outside the grid; the reference reads
               // totalExt out of bounds there.  Here: no extinction outside the grid, hence never a scattering.
-              const bool inGrid = (unsigned)(r.iz - 1) < (unsigned)P.nz;
-              cell = inGrid ? cell_index(P, r.ix, r.iy, r.iz) : 0;
-              const float extHere = inGrid ? P.totalExt[cell] : 0.0f;
-              scatterThis = rng.next() < extHere / P.maxExt;
+              const bool inGrid = (unsigned)(r.iz - 1) < (unsigned)Pe.nz;
+              cell = inGrid ? cell_index(Pe, r.ix, r.iy, r.iz) : 0;
+              const float extHere = inGrid ? Pe.totalExt[cell] : 0.0f;
+              scatterThis = rng.next() < extHere / Pe.maxExt;
             }
             if (scatterThis) {
               order++;
@@ -588,59 +717,56 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
               // :606-632 (quirk Q2 kept): a scattering in a cell without extinction steps back over the cell face.  The
               // tracer only stops inside a cell whose extinction is positive (acc + step * 0 > target cannot hold), so
               // with ray tracing the case cannot arise and the look-up is left to the max-cross-section build.
-              if (!rayTracing && cell_extinction<GRID>(P, L, r.ix, r.iy, r.iz) <= 0.0f) {
+              if (!rayTracing && cell_extinction<GRID>(Pe, L, r.ix, r.iy, r.iz) <= 0.0f) {
                 if (r.x - L.xE[r.ix - 1] <= 0.0f && r.dx > 0.0f) {
                   r.x = r.x - spacingf(r.x);
                   r.ix = r.ix - 1;
-                  if (r.ix <= 0) { r.ix = P.nx; r.x = L.xE[r.ix - 1]; r.x = r.x - 2.0f * spacingf(r.x); }
+                  if (r.ix <= 0) { r.ix = Pe.nx; r.x = L.xE[r.ix - 1]; r.x = r.x - 2.0f * spacingf(r.x); }
                 }
                 if (r.y - L.yE[r.iy - 1] <= 0.0f && r.dy > 0.0f) {
                   r.y = r.y - spacingf(r.y);
                   r.iy = r.iy - 1;
-                  if (r.iy <= 0) { r.iy = P.ny; r.y = L.xE[r.iy - 1]; r.y = r.x - 2.0f * spacingf(r.y); }
+                  if (r.iy <= 0) { r.iy = Pe.ny; r.y = L.xE[r.iy - 1]; r.y = r.x - 2.0f * spacingf(r.y); }
                 }
                 if (r.z - L.zE[r.iz - 1] <= 0.0f && r.dz > 0.0f) { r.z = r.z - spacingf(r.z); r.iz = r.iz - 1; }
               }
               // the cell's properties are read only where the domain does not share one value (see DevProblem)
-              const bool needCell = GENERAL || !(P.uniformSsa >= 0.0f) || P.uniformSsa < 1.0f || P.uniformPf < 1;
-              if (needCell) cell = cell_index(P, r.ix, r.iy, r.iz);
+              const bool needCell = GENERAL || !(Pe.uniformSsa >= 0.0f) || Pe.uniformSsa < 1.0f || Pe.uniformPf < 1;
+              if (needCell) cell = cell_index(Pe, r.ix, r.iy, r.iz);
               int comp = 1;                                               // :637-638
               if (multiComp || REPLAY) {
                 const float rc = rng.next();
                 if (multiComp) {
-                  const float *cum = P.cumExt + cell;
+                  const float *cum = Pe.cumExt + cell;
                   comp = find_index(rc, [cum, ncell](int k) { return k == 1 ? 0.0f : cum[(size_t)(k - 2) * ncell]; },
-                                    P.ncomp + 1, 0);
+                                    Pe.ncomp + 1, 0);
                 }
               }
               // single-scattering albedo and phase-function entry of the cell; a value shared by the whole (one-component)
               // domain comes from the kernel arguments instead of two dependent memory reads
               float ssa;
-              if (!GENERAL && P.uniformSsa >= 0.0f) ssa = P.uniformSsa;
-              else ssa = P.ssa[(size_t)(comp - 1) * ncell + cell];
+              if (!GENERAL && Pe.uniformSsa >= 0.0f) ssa = Pe.uniformSsa;
+              else ssa = Pe.ssa[(size_t)(comp - 1) * ncell + cell];
               if (ssa < 1.0f) {                                           // :642-649
-                tally.absorbed((r.iy - 1) * P.nx + (r.ix - 1), cell, w * (1.0f - ssa));
+                tally.absorbed((r.iy - 1) * Pe.nx + (r.ix - 1), cell, w * (1.0f - ssa));
                 w = w * ssa;
               }
               int pfi;
-              if (!GENERAL && P.uniformPf >= 1) pfi = P.uniformPf;
-              else pfi = max(P.pfIndex[(size_t)(comp - 1) * ncell + cell], 1);   // (index 0 marks clear cells: never a table offset of -1)
-              if (defer) {                                                // :654-668, traced after this event
+              if (!GENERAL && Pe.uniformPf >= 1) pfi = Pe.uniformPf;
+              else pfi = max(Pe.pfIndex[(size_t)(comp - 1) * ncell + cell], 1);   // (index 0 marks clear cells: never a table offset of -1)
+              if (defer) {                                                // :654-668: pushed after this event, traced in ray mode
                 pendingShadow = true; wI = w;
-                lds_float *park = L.park + threadIdx.x;
-                park[10 * 256] = r.dx; park[11 * 256] = r.dy; park[12 * 256] = r.dz;   // incoming direction
-                const int useOrig = (P.useHybrid && order <= P.numOrdersOrig) ? 0x100 : 0;
-                park[13 * 256] = __int_as_float(comp | useOrig);
-                park[14 * 256] = __int_as_float(pfi);
+                inDx = r.dx; inDy = r.dy; inDz = r.dz;                     // incoming direction
+                evInfo = comp | ((Pe.useHybrid && order <= Pe.numOrdersOrig) ? 0x100 : 0) | (pfi << 16);
               } else if (INTENSITY)
-                intensity_contribution<GRID>(P, L, rng, nested, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, comp, order);
-              if (P.useRR && w < 0.5f) {                                  // :673-680
+                intensity_contribution<GRID>(Pe, L, rng, nested, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, comp, order);
+              if (Pe.useRR && w < 0.5f) {                                  // :673-680
                 didRoulette = true;
                 if (rng.spare() >= w / 1.0f) w = 0.0f; else w = 1.0f;
               }
               if (w <= kTiny) { if (REPLAY) fate = 2; st = ST_NEW; }
               else {
-                const CompTables ct = GENERAL ? P.comp[comp - 1] : P.comp0;
+                const CompTables ct = GENERAL ? load_tables(Pe.comp[comp - 1]) : load_tables(Pe.comp0);
                 const float cosS = scattering_cosine(rng.first(), ct.invCos + (size_t)(pfi - 1) * ct.nInv, ct.nInv,
                                                      refined_rcp((float)ct.nInv));
                 next_direct(rng, cosS, r.dx, r.dy, r.dz);                 // :684-687
@@ -651,64 +777,68 @@ __global__ void __launch_bounds__(256, (INTENSITY && GENERAL) ? 4 : I3RC_MIN_WAV
             }
           }
         }
-        PROF_SEG(4);
         if (st == ST_TRACE) {                                             // :480
           const float tau = -sample_log(fmaxf(kTiny, rng.path()));
           r.acc = 0.0f; r.target = tau;
           if (rayTracing) { startedTrace = true; r.set_direction(L); }
           else {                                                          // :494-496 max cross-section move
-            r.x = make_periodic(r.x + r.dx * tau / P.maxExt, P.x0, P.xMax);
-            r.y = make_periodic(r.y + r.dy * tau / P.maxExt, P.y0, P.yMax);
-            r.z = r.z + r.dz * tau / P.maxExt;
+            r.x = make_periodic(r.x + r.dx * tau / Pe.maxExt, Pe.x0, Pe.xMax);
+            r.y = make_periodic(r.y + r.dy * tau / Pe.maxExt, Pe.y0, Pe.yMax);
+            r.z = r.z + r.dz * tau / Pe.maxExt;
             st = ST_EVENT;
           }
-        }
-        PROF_SEG(5);
-        if (defer && pendingShadow) {   // park the photon (alive or killed by roulette) and trace its shadow rays first
-          lds_float *park = L.park + threadIdx.x;
-          park[0] = r.x; park[256] = r.y; park[2 * 256] = r.z;
-          park[3 * 256] = __int_as_float(r.ix); park[4 * 256] = __int_as_float(r.iy); park[5 * 256] = __int_as_float(r.iz);
-          park[6 * 256] = r.dx; park[7 * 256] = r.dy; park[8 * 256] = r.dz;
-          park[9 * 256] = r.target;
-          pendingShadow = false; dIdx = 0; stage = -1;
-          st = ST_LIGHT;
         }
         // a photon that died in part C (roulette, absorbing surface) is closed here and respawns at the next event phase
         if (st == ST_NEW) close_photon();
       }
+      if (defer) {   // push the events of this phase into the wave's ring: one record serves all D rays of an event
+        const unsigned long long pushMask = __ballot(pendingShadow);
+        if (pendingShadow) {
+          lds_float *rec = qBase + ((qTail + (unsigned)lanes_below(pushMask)) & qMask);
+          const int cap = Pe.rayQueueCap;
+          rec[0] = r.x; rec[cap] = r.y; rec[2 * cap] = r.z;
+          rec[3 * cap] = __int_as_float(r.ix); rec[4 * cap] = __int_as_float(r.iy); rec[5 * cap] = __int_as_float(r.iz);
+          rec[6 * cap] = wI;
+          rec[7 * cap] = inDx; rec[8 * cap] = inDy; rec[9 * cap] = inDz;
+          rec[10 * cap] = __int_as_float(evInfo);
+          rec[11 * cap] = __uint_as_float(rng.photon_lo()); rec[12 * cap] = __uint_as_float(rng.photon_hi());
+          rec[13 * cap] = __uint_as_float(rng.event_block());
+          pendingShadow = false;
+        }
+        qTail += (unsigned)__popcll(pushMask);
+      }
       wc.scat += count_lanes(didScatter);
       wc.roul += count_lanes(didRoulette);
       wc.calls += count_lanes(startedTrace);
+      PROF_END(PH_EVENT, __popcll(evMask));
     }
-    const unsigned long long profT1 = PROF_T();
-#ifdef I3RC_PROFILE_PHASES
-    profEv += profT1 - profT0;
-    profNSt++; profLanesSt += __popcll(__ballot(st == ST_TRACE || st == ST_SHADOW));
-#endif
-    // ---------------------------------------------------------------- VOXEL-STEP phase
-    const bool own = st == ST_TRACE, shadowRay = DEFER && st == ST_SHADOW;
-    wc.steps += count_lanes(own);
-    if (DEFER) wc.shadow += count_lanes(shadowRay);
-    if (own || shadowRay) {
-      const StepResult s = trace_step<GRID>(P, L, r, own || stage != 0);
-      if (s == STEP_DONE) st = own ? ST_EVENT : ST_LIGHT;
-      else if (s == STEP_ERROR) st = own ? ST_DROPPED : ST_LIGHT;   // a failed shadow ray contributes nothing (:1531-1535)
-    }
-#ifdef I3RC_PROFILE_PHASES
-    profSt += PROF_T() - profT1;
+    // -------------------------------------------------------------- VOXEL-STEP phase (photons)
+    // (a second step in the same pass while the next event phase is some lanes away: the phase logic is paid once for
+    // both.  Written out twice: a loop around the step made the whole photon loop's code worse, -17 % on the step cloud)
+    auto photon_step = [&]() {
+      const bool tracing = st == ST_TRACE;
+      const unsigned nTracing = count_lanes(tracing);
+      wc.steps += nTracing;
+      PROF_BEGIN();
+      if (tracing) {
+        const StepResult s = trace_step<GRID>(P, L, r, true);
+        if (s != STEP_CONTINUE) st = s == STEP_DONE ? ST_EVENT : ST_DROPPED;
+      }
+      PROF_END(PH_STEP, nTracing);
+    };
+    photon_step();
+#if I3RC_PHOTON_STEP_AHEAD < 64
+    if (!runEvent && evThr - (int)__popcll(evMask) > kPhotonStepAhead) photon_step();
 #endif
   }
 #ifdef I3RC_PROFILE_PHASES
-  if ((threadIdx.x & 63) == 0) {
-    unsafeAtomicAdd(P.tally + P.oCnt + 10, (double)profEv);
-    unsafeAtomicAdd(P.tally + P.oCnt + 11, (double)profSt);
-    unsafeAtomicAdd(P.tally + P.oCnt + 12, (double)profNEv);
-    unsafeAtomicAdd(P.tally + P.oCnt + 13, (double)profNSt);
-    unsafeAtomicAdd(P.tally + P.oCnt + 14, (double)profLanesEv);
-    unsafeAtomicAdd(P.tally + P.oCnt + 15, (double)profLanesSt);
-    // segment shares are packed into the volume-absorption tally of cells 0..5 (diagnostic build only, omega = 1 runs)
-    for (int k = 0; k < 8; ++k) unsafeAtomicAdd(P.tally + P.oVol + k, (double)profSeg[k]);
-    unsafeAtomicAdd(P.tally + P.oVol + 8, (double)profNew);
+  if ((threadIdx.x & 63) == 0) {   // (diagnostic build, omega = 1 runs: the volume-absorption tally is free)
+    unsafeAtomicAdd(P.tally + P.oVol + 3 * PH_KINDS, (double)(__builtin_amdgcn_s_memtime() - profStart));   // the wave's whole loop
+    for (int k = 0; k < PH_KINDS; ++k) {
+      unsafeAtomicAdd(P.tally + P.oVol + 3 * k, (double)profCycles[k]);
+      unsafeAtomicAdd(P.tally + P.oVol + 3 * k + 1, (double)profCount[k]);
+      unsafeAtomicAdd(P.tally + P.oVol + 3 * k + 2, (double)profLanes[k]);
+    }
   }
 #endif
 

@@ -47,8 +47,9 @@ __host__ __device__ inline float u32_to_unit_float(uint32_t u) {
 //   path()    optical depth to the next event
 //   spare()   Russian roulette
 // so that no run-time cursor has to be consulted for them.  Whatever else an event needs (component choice, the
-// max-cross-section test, a retry, the local estimate's roulette) comes from next(), a cursor over further blocks of
-// the same photon.  Which word serves which purpose is this code's own convention: the production streams are not the
+// max-cross-section test, a retry) comes from next(), a cursor over further blocks of the same photon.  The
+// local-estimate rays of an event draw from blocks of their own: same photon and block number, direction + 1 in the
+// fourth counter word (kernels.hpp, ray mode).  Which word serves which purpose is this code's own convention: the production streams are not the
 // reference's Mersenne Twister sequence anyway, and every production kernel follows the same convention (tests
 // compare them photon by photon).  The replay stream hands out the reference's deviates in the reference's order.
 struct PhiloxStream {
@@ -71,6 +72,11 @@ struct PhiloxStream {
     block = 0u; have = 0;
   }
   __device__ inline void close() {}
+  // Philox coordinates of the event in progress (its block was made by begin_event): a local-estimate ray of this
+  // event draws from the block with the same first three counter words and its direction number + 1 in the fourth
+  __device__ inline uint32_t photon_lo() const { return id_lo; }
+  __device__ inline uint32_t photon_hi() const { return id_hi; }
+  __device__ inline uint32_t event_block() const { return block - 1u; }
   __device__ inline uint32_t draws_of_photon() const { return 0u; }   // per-photon records are a replay-stream feature
   // deviates consumed by this lane so far (kernel epilogue)
   __device__ inline uint32_t total() const { return used; }
@@ -84,17 +90,11 @@ struct PhiloxStream {
     block++;
     return o;
   }
-  // withCursor: also fill the block behind next() now, while the whole wave is at it, for the draws that follow the
-  // event at a few lanes a time (the local estimate's roulette in the light phase: refilling there cost 30 %)
-  __device__ inline void begin_event(bool withCursor = false) {
+  __device__ inline void begin_event() {
     const Philox4 o = make_block();
     e0 = o.v[0]; e1 = o.v[1]; e2 = o.v[2]; e3 = o.v[3];
-    if (withCursor) {
-      const Philox4 c = make_block();
-      b0 = c.v[0]; b1 = c.v[1]; b2 = c.v[2]; b3 = c.v[3];
-      have = 4;
-    }
   }
+  __device__ inline void count_draws(uint32_t n) { used += n; }   // deviates drawn elsewhere on this lane's account (shadow rays)
   __device__ inline float first()  { used++; return u32_to_unit_float(e0); }
   __device__ inline float second() { used++; return u32_to_unit_float(e1); }
   __device__ inline float path()   { used++; return u32_to_unit_float(e2); }
@@ -110,6 +110,10 @@ struct PhiloxStream {
     used++;
     return u32_to_unit_float(u);
   }
+  // One deviate from a block of its own, without the cursor.  The specialised kernels draw outside an event's block only in
+  // the all but impossible retry of a surface reflection's cosine (a deviate of exactly 0): using this there keeps the
+  // cursor's five registers out of their photon loop.
+  __device__ inline float fresh() { const Philox4 o = make_block(); used++; return u32_to_unit_float(o.v[0]); }
   // Azimuth for next_direct (:2099-2103).  The reference rejection-samples a point of the unit disc (2 deviates per
   // try, 21 % retries) only to get a uniformly distributed azimuth without trigonometry.  On the GPU one deviate and
   // the hardware sin/cos (arguments in revolutions) give the same distribution with no divergent retry loop; d
@@ -134,7 +138,11 @@ struct ReplayStream {
   __device__ inline uint32_t draws_of_photon() const { return (uint32_t)(pos - photonStart); }
   __device__ inline void close() { closed += draws_of_photon(); photonStart = pos; }
   __device__ inline uint32_t total() const { return closed; }
-  __device__ inline void begin_event(bool = false) {}
+  __device__ inline void begin_event() {}
+  __device__ inline void count_draws(uint32_t) {}
+  __device__ inline uint32_t photon_lo() const { return 0u; }   // (the replay build keeps the nested local estimate)
+  __device__ inline uint32_t photon_hi() const { return 0u; }
+  __device__ inline uint32_t event_block() const { return 0u; }
   __device__ inline float next() {
     // a photon that parts from the reference's path (1-ulp differences of log / cos / ...) may ask for more deviates
     // than were recorded: past the end the recorded ones are used again from the start (a constant would be
@@ -143,6 +151,7 @@ struct ReplayStream {
     pos++;
     return r;
   }
+  __device__ inline float fresh() { return next(); }
   // the reference draws everything from one sequence: the roles of PhiloxStream are plain draws, in call order
   __device__ inline float first() { return next(); }
   __device__ inline float second() { return next(); }

@@ -23,6 +23,14 @@ struct CompTables {
   int nInv, nFwd;
 };
 
+// (member-wise copy: the source may live in the kernarg segment, address space 4, for which no implicit copy exists)
+template <class CT>
+__device__ __forceinline__ CompTables load_tables(const CT &c) {
+  CompTables t;
+  t.inv = c.inv; t.invCos = c.invCos; t.fwd = c.fwd; t.fwdOrig = c.fwdOrig; t.nInv = c.nInv; t.nFwd = c.nFwd;
+  return t;
+}
+
 // Everything the kernel reads, by value in the kernarg segment (wave-uniform -> SGPRs).
 struct DevProblem {
   int nx, ny, nz, ncomp;
@@ -56,6 +64,7 @@ struct DevProblem {
   int ldsTallies;                     // 1: fluxUp/Down/Absorbed privatised in LDS (ncol small)
   int ldsGrid;                        // 1: totalExt staged in LDS
   int ldsIntensity;                   // 1: intensityByComponent privatised in LDS ((ncomp+1)*nDir*ncol small)
+  int rayQueueCap;                    // radiance runs: events a wave's ray queue holds (power of two; kRecWords floats each)
 };
 
 struct RunArgs {
@@ -81,10 +90,14 @@ struct Lds {
   lds_float *ext;             // totalExt copy (valid when ldsGrid)
   lds_float *dirCos;          // intensity directions
   lds_float *tInt;            // privatised intensityByComponent (valid when ldsIntensity)
-  lds_float *park;            // [kParkWords][256]: a photon's own state while its shadow rays are traced
+  lds_float *queue;           // [waves][kRecWords][rayQueueCap]: every wave's ring of local-estimate events (see kernels.hpp)
 };
 __device__ __forceinline__ void lds_add(lds_float *p, float v) { atomicAdd((float *)p, v); }
-constexpr int kParkWords = 15;
+// One record of a wave's ray queue: what the D local-estimate (shadow) rays of one scattering / reflection event need.
+constexpr int kRecWords = 14;   // x y z | ix iy iz | weight | incoming direction (3) | info | photon id (2) | Philox block
+// ... and one ready-made shadow ray of the wave's ready buffer (kReadyRays of them, one expand phase's worth)
+constexpr int kReadyWords = 12;  // x y z | ix iy iz | component, direction, stage | weight | phase-function factor | free path | target | optical path so far
+constexpr int kReadyRays = 64;
 
 // Fortran SPACING() for real(4)
 __device__ __forceinline__ float spacingf(float x) {
@@ -200,13 +213,17 @@ struct Ray {
 
 enum StepResult { STEP_CONTINUE = 0, STEP_DONE = 1, STEP_ERROR = 2 };
 
-__device__ __forceinline__ int cell_index(const DevProblem &P, int ix, int iy, int iz) {
+// (PR: DevProblem -- the kernel argument, held in scalar registers -- or the same struct read through a pointer into the
+// kernarg segment, address space 4: see cold_args in kernels.hpp)
+template <class PR>
+__device__ __forceinline__ int cell_index(const PR &P, int ix, int iy, int iz) {
   // 24-bit multiplies (full rate): i3rc_hip_create guarantees nx*ny < 2^24 and nx*ny*nz < 2^30
   return (int)(__umul24((unsigned)(iz - 1), (unsigned)(P.nx * P.ny)) + __umul24((unsigned)(iy - 1), (unsigned)P.nx)) + (ix - 1);
 }
 
 // position of cell (ix, iy, iz) (1-based) in the bricked copy of the extinction field
-__device__ __forceinline__ int brick_index(const DevProblem &P, int ix, int iy, int iz) {
+template <class PR>
+__device__ __forceinline__ int brick_index(const PR &P, int ix, int iy, int iz) {
   const unsigned x = (unsigned)(ix - 1), y = (unsigned)(iy - 1), z = (unsigned)(iz - 1);
   const unsigned brick = __umul24(z >> P.bsz, (unsigned)P.nbxy) + __umul24(y >> P.bsy, (unsigned)P.nbx) + (x >> P.bsx);
   const unsigned mx = (1u << P.bsx) - 1u, my = (1u << P.bsy) - 1u, mz = (1u << P.bsz) - 1u;
@@ -224,8 +241,8 @@ __device__ __forceinline__ int brick_index(const DevProblem &P, int ix, int iy, 
 // grid that lives in global memory and read zeros (found by the replay tests on the I3RC radar / Landsat fields;
 // tests/test_build_isa.py keeps the pattern out of the kernels).
 enum GridPlace { GRID_LDS = 0, GRID_GLOBAL = 1, GRID_BRICKS = 2 };
-template <int GRID>
-__device__ __forceinline__ float cell_extinction(const DevProblem &P, const Lds &L, int ix, int iy, int iz) {
+template <int GRID, class PR>
+__device__ __forceinline__ float cell_extinction(const PR &P, const Lds &L, int ix, int iy, int iz) {
   if (GRID == GRID_LDS) return L.ext[cell_index(P, ix, iy, iz)];   // ds_read
   if (GRID == GRID_BRICKS) return P.extBrick[brick_index(P, ix, iy, iz)];
   return P.totalExt[cell_index(P, ix, iy, iz)];
@@ -237,8 +254,8 @@ __device__ __forceinline__ float cell_extinction(const DevProblem &P, const Lds 
 // escapes): on a 64-lane wavefront the lanes take the reference's if/else arms in every combination at every step,
 // so branches would execute both arms anyway and add exec-mask bookkeeping on top.  The arithmetic of each arm is
 // exactly the reference's (checked bit for bit against the oracle by the tracer tests).
-template <int GRID>
-__device__ __forceinline__ StepResult trace_step(const DevProblem &P, const Lds &L, Ray &r, bool hasTarget) {
+template <int GRID, class PR>
+__device__ __forceinline__ StepResult trace_step(const PR &P, const Lds &L, Ray &r, bool hasTarget) {
   // the extinction of the current cell is requested first: its latency (LDS, or L2 / HBM for grids that do not fit
   // in LDS) is covered by the three face-distance divisions below
   const float ext = cell_extinction<GRID>(P, L, r.ix, r.iy, r.iz);
@@ -297,8 +314,8 @@ __device__ __forceinline__ StepResult trace_step(const DevProblem &P, const Lds 
 }
 
 // findXYIndicies :1353-1374, findZIndex :1376-1388
-template <bool GENERAL = true>
-__device__ __forceinline__ void find_xy(const DevProblem &P, const Lds &L, float x, float y, int &ix, int &iy) {
+template <bool GENERAL = true, class PR>
+__device__ __forceinline__ void find_xy(const PR &P, const Lds &L, float x, float y, int &ix, int &iy) {
   if (!GENERAL || P.xyRegular) {
     int i = min((int)((x - P.x0) / P.deltaX) + 1, P.nx);
     int j = min((int)((y - P.y0) / P.deltaY) + 1, P.ny);
@@ -317,8 +334,8 @@ __device__ __forceinline__ void find_xy(const DevProblem &P, const Lds &L, float
     if (iy == P.ny + 1) iy = 1;
   }
 }
-template <bool GENERAL = true>
-__device__ __forceinline__ void find_z(const DevProblem &P, const Lds &L, float z, int &iz) {
+template <bool GENERAL = true, class PR>
+__device__ __forceinline__ void find_z(const PR &P, const Lds &L, float z, int &iz) {
   if (!GENERAL || P.zRegular) {
     int k = min((int)((z - P.z0) / P.deltaZ) + 1, P.nz);
     if (fabsf(L.zE[k] - z) < spacingf(z)) k = k + 1;
@@ -369,8 +386,26 @@ __device__ __forceinline__ float lookup_phase(const float *tab, int n, float ang
   return tab[n - 1];
 }
 
+// Hardware log / exp / reciprocal (v_log_f32, v_exp_f32, v_rcp_f32: 1-2 ulp) for the WEIGHTS of local-estimate rays
+// (phase-function factor, transmission, roulette bounds): a Monte Carlo estimate's weights, not photon trajectories.
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+// lookUpPhaseFuncValsFromTable :1613-1652 with the two divisions by the (uniform) table spacing as one reciprocal
+__device__ __forceinline__ float lookup_phase_fast(const float *tab, int n, float angle) {
+  const float rcpDTheta = (float)(n - 1) * (1.0f / kPi);
+  const float pos = angle * rcpDTheta;
+  const int k = (int)pos + 1;
+  if (k < n) {
+    const float f = pos - (float)(k - 1);
+    return (1.0f - f) * tab[k - 1] + f * tab[k];
+  }
+  return tab[n - 1];
+}
+
 // computeSurfaceReflectance, Code/surfaceProperties.f95:121-148, with the Lambertian R (:154-162)
-__device__ __forceinline__ float surface_reflectance(const DevProblem &P, float x, float y) {
+template <class PR>
+__device__ __forceinline__ float surface_reflectance(const PR &P, float x, float y) {
   const float *xs = P.xsE, *ys = P.ysE;
   const int ix = find_index(make_periodic(x, xs[0], xs[P.nxs]), [xs](int k) { return xs[k - 1]; }, P.nxs + 1, 0);
   const int iy = find_index(make_periodic(y, ys[0], ys[P.nys]), [ys](int k) { return ys[k - 1]; }, P.nys + 1, 0);

@@ -399,6 +399,8 @@ class Integrator:
         return int(self._lib.i3rc_hip_timed_launch_count(self._h))
 
     def kernel_name(self):
+        if not hasattr(self._lib, "i3rc_hip_last_kernel_name"):
+            return "?"
         return self._lib.i3rc_hip_last_kernel_name(self._h).decode()
 
     def kernel_ms_history(self, n):
