@@ -204,7 +204,7 @@ struct Reservoir {
 // loop's code and its scalar-register pressure.  GENERAL = true keeps every path behind run-time switches.
 // (radiance kernels keep two rays per lane live -- the photon's and a shadow ray's: 4 waves per SIMD give them 128 vector registers)
 template <class Rng, bool INTENSITY, bool GENERAL, int GRID>
-__global__ void __launch_bounds__(256, INTENSITY ? 4 : I3RC_MIN_WAVES) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
+__global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : 4) : I3RC_MIN_WAVES) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   {

@@ -51,3 +51,28 @@ def test_no_exec_dependent_flag_masks_in_inner_loops(tmp_path):
                     found.append((kernel[:70], i + 1, depth))
     assert kernels >= 20, kernels          # the scan saw the kernels at all
     assert not found, found
+
+
+def test_production_kernels_keep_their_state_in_registers():
+    """No production instantiation of photon_kernel may spill vector registers or use scratch memory (the code object's
+    own resource figures, hipcc -Rpass-analysis=kernel-resource-usage): round 1's general radiance kernel carried
+    26-29 spilled vector registers and 116 bytes of scratch per lane.  Scalar-register spills (held in vector-register
+    lanes, no memory traffic) are bounded: the specialised kernels -- every BASELINE configuration runs one of them --
+    may have a handful, the flux kernels none."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    from tools.kernel_resources import resources
+
+    everything = resources()
+    rows = [r for r in everything if r["name"].startswith("photon_kernel<PhiloxStream")]
+    assert len(rows) == 12, [r["name"] for r in rows]
+    for r in rows:
+        assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, (r["name"], r["VGPRs Spill"], r["ScratchSize [bytes/lane]"])
+        if ", false, GRID" in r["name"]:                       # specialised (GENERAL = false)
+            limit = 0 if r["name"].startswith("photon_kernel<PhiloxStream, false") else 16
+            assert r["SGPRs Spill"] <= limit, (r["name"], r["SGPRs Spill"])
+    # the replay build (test infrastructure on the device) must not use scratch either
+    for r in everything:
+        if r["name"].startswith("photon_kernel<ReplayStream"):
+            assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, r["name"]

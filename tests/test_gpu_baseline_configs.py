@@ -107,3 +107,81 @@ def test_config4_landsat_seven_radiances_lambertian_surface_object(oracle):
     gr, orr = _two_stage(oracle, g, o, 8, 10000, 0.5, ("fluxUp", "fluxDown", "intensity"), per_direction=True)
     sh = sum(r["counters"]["shadowSteps"] for r in gr) / (10000 * len(gr))
     assert sh > 1500   # ~3200 cell steps per photon, almost all of them shadow rays
+
+
+# ---- configs 2 and 4 at 1e6+ photons: the oracle's sample is produced by a child program on the host cores while the
+#      GPU traces its own (as the 1e8 step-cloud test does) -------------------------------------------------------------
+def _oracle_child(tmp_path, config, cores, per_core, photons):
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / f"oracle_{config}.npz")
+    child = subprocess.Popen([sys.executable, os.path.join(root, "tools", "cpu_baseline.py"), "--config", config, "--cores", str(cores),
+                              "--batches-per-core", str(per_core), "--photons", str(photons), "--save", out],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    return child, out
+
+
+def _gpu_batches(config, nb, n):
+    from tools import workloads as W
+
+    name, w = W.get(config)
+    g, d = W.make_integrator(w)
+    rs = [g.computeRadiativeTransfer(M.new_RandomNumberSequence((77, b)), M.new_PhotonStream(w["mu0"], 0.0, n)) for b in range(1, nb + 1)]
+    g.finalize_Integrator()
+    return rs
+
+
+def _assert_means_3sigma(gpu_vals, ref_vals, what):
+    gpu_vals, ref_vals = np.asarray(gpu_vals, np.float64), np.asarray(ref_vals, np.float64)
+    tol = 3.0 * np.sqrt(gpu_vals.var(ddof=1) / len(gpu_vals) + ref_vals.var(ddof=1) / len(ref_vals)) + 1e-7
+    assert abs(gpu_vals.mean() - ref_vals.mean()) <= tol, (what, gpu_vals.mean(), ref_vals.mean(), tol)
+    return abs(gpu_vals.mean() - ref_vals.mean()) / tol
+
+
+def test_config2_radar_64_nadir_radiance_at_2e6_photons(tmp_path):
+    import os
+
+    cores = min(16, len(os.sched_getaffinity(0)))
+    per_core, n_ref = 4, 2_000_000 // (cores * 4)
+    child, out = _oracle_child(tmp_path, "radar64_nadir", cores, per_core, n_ref)
+    gr = _gpu_batches("radar64_nadir", 40, 50_000)                        # 2e6 photons on the GPU meanwhile
+    so, se = child.communicate(timeout=900)
+    assert child.returncode == 0, so + se
+    z = np.load(out)
+    assert len(z["means"]) == cores * per_core
+    for k, key in enumerate(("fluxUp", "fluxDown")):
+        _assert_means_3sigma([r[key].mean(dtype=np.float64) for r in gr], z["means"][:, k], key)
+    _assert_means_3sigma([r["intensity"][0].mean(dtype=np.float64) for r in gr], z["intensityMeans"][:, 0], "nadir radiance")
+    # per column: the same 3-sigma statistic over the 4096 columns (Student-t allowance as in _assert_3sigma)
+    from tests.test_gpu_parity import _assert_3sigma
+    orr = [dict(fluxUp=u, fluxDown=dn, intensity=i) for u, dn, i in zip(z["fluxUp"], z["fluxDown"], z["intensity"])]
+    for key in ("fluxUp", "fluxDown", "intensity"):
+        _assert_3sigma(gr, orr, key, floor=1e-7)
+    # dropped-photon deficit (quirk Q4) and work per photon: same on both sides
+    n_g, n_o = 50_000 * len(gr), n_ref * len(z["nBad"])
+    dg, do = sum(r["counters"]["dropped"] for r in gr) / n_g, z["nBad"].sum() / n_o
+    assert abs(dg - do) < 3 * np.sqrt(do / n_g + do / n_o) + 1e-5, (dg, do)
+    sg = sum(r["counters"]["cellSteps"] + r["counters"]["shadowSteps"] for r in gr) / n_g   # (the oracle counts both in one figure)
+    assert abs(sg - z["cellSteps"].sum() / n_o) < 0.01 * sg
+
+
+def test_config4_landsat_seven_radiances_at_1e6_photons(tmp_path):
+    import os
+
+    cores = min(16, len(os.sched_getaffinity(0)))
+    per_core, n_ref = 4, 1_000_000 // (cores * 4)
+    child, out = _oracle_child(tmp_path, "landsat119_7dir", cores, per_core, n_ref)
+    gr = _gpu_batches("landsat119_7dir", 40, 25_000)                      # 1e6 photons on the GPU meanwhile
+    so, se = child.communicate(timeout=900)
+    assert child.returncode == 0, so + se
+    z = np.load(out)
+    for k, key in enumerate(("fluxUp", "fluxDown")):
+        _assert_means_3sigma([r[key].mean(dtype=np.float64) for r in gr], z["means"][:, k], key)
+    for d in range(7):                                                      # every direction on its own
+        _assert_means_3sigma([r["intensity"][d].mean(dtype=np.float64) for r in gr], z["intensityMeans"][:, d], f"radiance {d}")
+    n_g, n_o = 25_000 * len(gr), n_ref * len(z["nBad"])
+    dg, do = sum(r["counters"]["dropped"] for r in gr) / n_g, z["nBad"].sum() / n_o
+    assert abs(dg - do) < 3 * np.sqrt(do / n_g + do / n_o) + 1e-5, (dg, do)

@@ -187,3 +187,33 @@ def test_landsat_scene_recorded_results(oracle):
     # (cell steps per photon scatter with a standard deviation of ~2000: +-16 at this sample size, +-10 in the recorded run;
     # the GPU's 2e7-photon mean is 3205)
     assert abs(per["tracerCalls"] - 214) < 4 and abs(per["cellSteps"] - 3194) < 60 and abs(per["scatterings"] - 23.1) < 0.5
+
+
+def test_photon_sources_have_the_distributions_the_reference_documents(oracle):
+    """Code/monteCarloIllumination.f95:106-424 restated in oracle/illumination.c: what each source promises.
+    Flux: mu = -sqrt(r) makes the flux on the horizontal equally weighted in mu (density 2 |mu|: mean |mu| = 2/3,
+    mean mu^2 = 1/2); azimuths uniform in [0, 2 pi]; RandomAzimuth keeps mu; the internal flux detector draws the same
+    cosine law upward or downward; the finite detector moves x by delta (1 - r / 2), i.e. into [x + delta / 2, x + delta]
+    (the reference's formula, not a centred detector); Internal_Intensity stores its azimuth in degrees."""
+    O = oracle
+    n = 200000
+    x, y, z, mu, phi = O.photons_flux(O.RandomNumberSequence([3, 4]), n)
+    assert np.all(z == np.float32(1.0) - np.spacing(np.float32(1.0)))
+    assert abs(np.abs(mu).mean() - 2 / 3) < 4 * np.sqrt(1 / 18 / n) and abs((mu.astype(np.float64) ** 2).mean() - 0.5) < 4 * np.sqrt(1 / 12 / n)
+    assert mu.max() <= 0.0 and 0.0 <= phi.min() and phi.max() <= np.float32(2 * np.pi) * (1 + 1e-6)
+    assert abs(phi.mean() - np.pi) < 4 * 2 * np.pi / np.sqrt(12 * n) and abs(x.mean() - 0.5) < 4 / np.sqrt(12 * n)
+    x, y, z, mu, phi = O.photons_random_azimuth(O.RandomNumberSequence([3, 4]), 0.3, n)
+    assert np.all(mu == np.float32(-0.3)) and abs(phi.mean() - np.pi) < 4 * 2 * np.pi / np.sqrt(12 * n)
+    x, y, z, mu, phi = O.photons_spotlight(-0.3, 90.0, 0.2, 0.9, 10)
+    assert np.all(x == np.float32(0.2)) and np.all(y == np.float32(0.9)) and np.all(mu == np.float32(-0.3))
+    assert np.all(phi == np.float32(90.0) * np.arccos(np.float32(-1.0)) / np.float32(180.0))
+    for up in (True, False):
+        x, y, z, mu, phi = O.photons_internal_flux(O.RandomNumberSequence([3, 4]), 0.5, 0.5, 0.25, up, n, delta_x=0.2)
+        assert np.all(mu > 0) if up else np.all(mu < 0)
+        assert abs(np.abs(mu).mean() - 2 / 3) < 4 * np.sqrt(1 / 18 / n)
+        assert np.all(z == np.float32(0.25)) and np.all(y == np.float32(0.5))
+        assert x.min() >= np.float32(0.5) + np.float32(0.1) * (1 - 1e-6) and x.max() <= np.float32(0.7) * (1 + 1e-6)
+        assert abs(x.mean() - 0.65) < 4 * 0.1 / np.sqrt(12 * n)
+    x, y, z, mu, phi = O.photons_internal_intensity(O.RandomNumberSequence([3, 4]), 0.5, 0.5, 1.0, -0.2, 270.0, 5)
+    assert np.all(phi == np.float32(270.0)) and np.all(mu == np.float32(-0.2))          # degrees, as the reference stores it
+    assert np.all(z == np.float32(1.0) - np.spacing(np.float32(1.0)))                   # a downward detector at the top is nudged inside

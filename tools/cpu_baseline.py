@@ -31,7 +31,7 @@ REFERENCE_NOTES = {
 
 def _worker(args):
     first_batch, n_batches, photons, config, nlayers, mu0 = args
-    import numpy as np  # noqa: F401
+    import numpy as np
 
     from oracle import pyoracle as O
     from tools import workloads as W
@@ -49,7 +49,13 @@ def _worker(args):
         ph = O.photons_directional(rng, mu0, 0.0, photons)
         r = integ.compute(rng, *ph)
         fu += float(r["fluxUp"].mean())
-        cols.append((r["fluxUp"].copy(), r["fluxDown"].copy()))
+        small = r["fluxUp"].size <= 5000     # per-column fields of small domains; domain means (float64) of all
+        inten = r.get("intensity")
+        cols.append(dict(fluxUp=r["fluxUp"].copy() if small else None, fluxDown=r["fluxDown"].copy() if small else None,
+                         intensity=inten.copy() if (small and inten is not None) else None,
+                         means=[float(r[k].mean(dtype=np.float64)) for k in ("fluxUp", "fluxDown", "fluxAbsorbed")],
+                         intensityMeans=[] if inten is None else [float(v) for v in inten.mean(axis=(1, 2), dtype=np.float64)],
+                         nBad=int(r["nBad"]), cellSteps=int(r["cellSteps"]), scatterings=int(r["scatterings"])))
     return time.perf_counter() - t0, fu / n_batches, cols
 
 
@@ -61,7 +67,7 @@ def main():
     ap.add_argument("--photons", type=int, default=0, help="photons per batch (0 = the workload's bounded sample)")
     ap.add_argument("--nlayers", type=int, default=0, help="step cloud only: 16 = BASELINE.json label, 32 = reference generator")
     ap.add_argument("--mu0", type=float, default=None)
-    ap.add_argument("--save", default="", help="write the per-batch flux fields (fluxUp, fluxDown: batch x ny x nx) to this .npz")
+    ap.add_argument("--save", default="", help="write per-batch results to this .npz: domain means of every batch, per-column fields of small domains")
     a = ap.parse_args()
     from oracle import pyoracle as O
     from tools import workloads as W
@@ -81,7 +87,14 @@ def main():
     if a.save:
         import numpy as np
 
-        np.savez(a.save, fluxUp=np.stack([c[0] for r in res for c in r[2]]), fluxDown=np.stack([c[1] for r in res for c in r[2]]))
+        allb = [c for r in res for c in r[2]]
+        out = dict(means=np.array([c["means"] for c in allb]), intensityMeans=np.array([c["intensityMeans"] for c in allb]),
+                   nBad=np.array([c["nBad"] for c in allb]), cellSteps=np.array([c["cellSteps"] for c in allb]),
+                   scatterings=np.array([c["scatterings"] for c in allb]), photonsPerBatch=np.array(photons))
+        for k in ("fluxUp", "fluxDown", "intensity"):
+            if allb[0][k] is not None:
+                out[k] = np.stack([c[k] for c in allb])
+        np.savez(a.save, **out)
     total = cores * a.batches_per_core * photons
     try:
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
