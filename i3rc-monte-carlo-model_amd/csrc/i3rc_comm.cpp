@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>
 
 #include <arpa/inet.h>
+#include <netdb.h>
 #include <fcntl.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
@@ -46,7 +47,14 @@ std::string env_str(const char *a, const char *dflt) {
 }
 
 // ---- rendezvous: rank 0 -> everyone, n bytes -----------------------------------------------------------------------
-int rendezvous_port() { return env_int("I3RC_COMM_PORT", "MASTER_PORT", 29500); }
+// Its own port: I3RC_COMM_PORT, else MASTER_PORT + 1 -- under torchrun / SLURM launchers MASTER_PORT itself is held by
+// the launcher's store, which would answer a connecting rank with bytes that are not ours (hence also the header below).
+int rendezvous_port() {
+  if (std::getenv("I3RC_COMM_PORT")) return std::atoi(std::getenv("I3RC_COMM_PORT"));
+  return env_int("MASTER_PORT", nullptr, 29499) + 1;
+}
+struct RendezvousHeader { uint32_t magic, bytes; };
+constexpr uint32_t kMagic = 0x69337263u;   // "i3rc"
 
 bool send_all(int fd, const void *buf, size_t n) {
   const char *p = (const char *)buf;
@@ -85,25 +93,34 @@ int rendezvous_broadcast(void *blob, size_t n) {
     for (int peer = 1; peer < g_size; ++peer) {
       const int fd = ::accept(srv, nullptr, nullptr);
       if (fd < 0) { ::close(srv); return fail("i3rc_comm_init: timed out waiting for the other processes"); }
-      const bool ok = send_all(fd, blob, n);
+      const RendezvousHeader hdr{kMagic, (uint32_t)n};
+      const bool ok = send_all(fd, &hdr, sizeof(hdr)) && send_all(fd, blob, n);
       ::close(fd);
       if (!ok) { ::close(srv); return fail("i3rc_comm_init: sending the rendezvous blob failed"); }
     }
     ::close(srv);
     return 0;
   }
-  sockaddr_in addr{};
-  addr.sin_family = AF_INET; addr.sin_port = htons((uint16_t)port);
+  // MASTER_ADDR may be a host name (torchrun, SLURM): resolve it; IPv4 (rank 0 listens on INADDR_ANY)
   const std::string host = env_str("MASTER_ADDR", "127.0.0.1");
-  if (inet_pton(AF_INET, host.c_str(), &addr.sin_addr) != 1) return fail("i3rc_comm_init: MASTER_ADDR must be an IPv4 address");
+  addrinfo hints{}, *res = nullptr;
+  hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM;
+  if (getaddrinfo(host.c_str(), std::to_string(port).c_str(), &hints, &res) != 0 || !res)
+    return fail("i3rc_comm_init: cannot resolve MASTER_ADDR " + host);
+  sockaddr_in addr = *(sockaddr_in *)res->ai_addr;
+  freeaddrinfo(res);
   for (int tries = 0; tries < 1200; ++tries) {             // up to 2 minutes for rank 0 to come up
     const int fd = ::socket(AF_INET, SOCK_STREAM, 0);
     if (fd < 0) return fail("i3rc_comm_init: socket() failed");
     if (::connect(fd, (sockaddr *)&addr, sizeof(addr)) == 0) {
-      const bool ok = recv_all(fd, blob, n);
+      timeval tv{30, 0};                                    // a listener that is not ours may never send anything
+      (void)setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+      RendezvousHeader hdr{0u, 0u};
+      const bool ok = recv_all(fd, &hdr, sizeof(hdr)) && hdr.magic == kMagic && hdr.bytes == (uint32_t)n && recv_all(fd, blob, n);
       ::close(fd);
       if (ok) return 0;
-      return fail("i3rc_comm_init: receiving the rendezvous blob failed");
+      return fail("i3rc_comm_init: " + host + ":" + std::to_string(port) + " did not answer with the rendezvous blob "
+                  "(another service on that port?  set I3RC_COMM_PORT)");
     }
     ::close(fd);
     std::this_thread::sleep_for(std::chrono::milliseconds(100));

@@ -14,7 +14,7 @@ module monteCarloRadiativeTransfer
   use CharacterUtils,           only: IntToChar
   use ErrorMessages,            only: ErrorMessage, stateIsFailure, setStateToFailure, setStateToWarning, &
                                       setStateToSuccess, setStateToCompleteSuccess
-  use RandomNumbers,            only: randomNumberSequence, getRandomReal, getSeedWords
+  use RandomNumbers,            only: randomNumberSequence, getRandomReal, getSeedWords, reservePhotonStreams
   use numericUtilities,         only: findIndex
   use scatteringPhaseFunctions, only: phaseFunctionTable, getInfo_PhaseFunctionTable, copy_PhaseFunctionTable, &
                                       getPhaseFunctionValues, finalize_PhaseFunctionTable
@@ -438,6 +438,7 @@ contains
     type(photonStream),         intent(inout) :: incomingPhotons
     type(ErrorMessage),         intent(inout) :: status
     integer :: remaining, seed0, seed1
+    integer(selected_int_kind(18)) :: firstPhoton
     logical :: lazy
     real    :: mu0, azimuth, advance
     type(i3rc_source)       :: source
@@ -469,11 +470,12 @@ contains
       source%x = c_loc(sx); source%y = c_loc(sy); source%z = c_loc(sz); source%mu = c_loc(smu); source%phi = c_loc(sphi)
     end if
     call getSeedWords(randomNumbers, seed0, seed1)
+    call reservePhotonStreams(randomNumbers, remaining, firstPhoton)   ! (a sequence used again goes on with fresh photon streams)
 
     ! tallies are overwritten, not accumulated, on every call (reference :296-309)
     if(.not. deviceCall(thisIntegrator, i3rc_hip_zero_tallies(thisIntegrator%device), "computeRadiativeTransfer", status)) return
     if(.not. deviceCall(thisIntegrator, i3rc_hip_launch_batch(thisIntegrator%device, int(seed0, c_int32_t), int(seed1, c_int32_t), &
-                        0_c_int64_t, int(remaining, c_int64_t), source), "computeRadiativeTransfer", status)) return
+                        int(firstPhoton, c_int64_t), int(remaining, c_int64_t), source), "computeRadiativeTransfer", status)) return
     if(.not. deviceCall(thisIntegrator, i3rc_hip_get_tally_layout(thisIntegrator%device, layout), &
                         "computeRadiativeTransfer", status)) return
     allocate(raw(layout%total))

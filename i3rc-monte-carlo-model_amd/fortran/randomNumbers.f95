@@ -20,6 +20,7 @@ module RandomNumbers
     integer(i8), dimension(0:nWords - 1) :: mt = 0_i8     ! 32-bit words held in 64-bit integers
     integer                              :: next = nWords
     integer                              :: seedWord0 = 0, seedWord1 = 0
+    integer(i8)                          :: photonsDrawn = 0_i8   ! photons whose Philox streams this sequence has handed out
   end type randomNumberSequence
 
   interface new_RandomNumberSequence
@@ -29,7 +30,7 @@ module RandomNumbers
   public :: randomNumberSequence
   public :: new_RandomNumberSequence, finalize_RandomNumberSequence, &
             getRandomInt, getRandomPositiveInt, getRandomReal, getRandomDouble
-  public :: getSeedWords   ! extension used by the GPU integrator
+  public :: getSeedWords, reservePhotonStreams   ! extensions used by the GPU integrator
 contains
   function seedFromScalar(seed) result(twister)
     integer, intent(in)        :: seed
@@ -37,6 +38,7 @@ contains
     call initGenrand(twister, toUnsigned(seed))
     twister%seedWord0 = seed
     twister%seedWord1 = 0
+    twister%photonsDrawn = 0_i8
   end function seedFromScalar
 
   function seedFromVector(seed) result(twister)
@@ -81,6 +83,7 @@ contains
     type(randomNumberSequence), intent(out) :: twister
     twister%next = nWords
     twister%mt(:) = 0_i8
+    twister%photonsDrawn = 0_i8
   end subroutine finalize_RandomNumberSequence
 
   subroutine getSeedWords(twister, word0, word1)
@@ -89,6 +92,17 @@ contains
     word0 = twister%seedWord0
     word1 = twister%seedWord1
   end subroutine getSeedWords
+
+  ! The GPU integrator gives photon i of a sequence the Philox stream (key = seed words, counter = i).  A sequence that
+  ! is used for a second computeRadiativeTransfer without being re-seeded must not hand out the same streams again
+  ! (the reference's Mersenne Twister simply goes on): every call reserves the next n photon numbers.
+  subroutine reservePhotonStreams(twister, n, first)
+    type(randomNumberSequence), intent(inout) :: twister
+    integer,                    intent(in   ) :: n
+    integer(i8),                intent(  out) :: first
+    first = twister%photonsDrawn
+    twister%photonsDrawn = twister%photonsDrawn + int(n, i8)
+  end subroutine reservePhotonStreams
 
   ! -- generator ------------------------------------------------------------------------------------
   pure function toUnsigned(k) result(u)

@@ -38,6 +38,7 @@ class RandomNumberSequence:
         if len(seed) != 2:
             raise I3RCError("new_RandomNumberSequence: the GPU integrator takes seed=(/i, j/)")
         self.seed = seed
+        self.photonsDrawn = 0   # photons whose Philox streams this sequence has handed out (see Integrator.launch)
 
 
 class PhotonStream:
@@ -333,8 +334,11 @@ class Integrator:
             self._fwd_size[component - 1] = max(t.shape[1], 10 ** 9)
 
     # -- computeRadiativeTransfer :262-398
-    def launch(self, randomNumbers, incomingPhotons, firstPhoton=0, zero=True):
-        """Asynchronous part: zero the tallies (as the reference does per call) and launch the batch."""
+    def launch(self, randomNumbers, incomingPhotons, firstPhoton=None, zero=True):
+        """Asynchronous part: zero the tallies (as the reference does per call) and launch the batch.
+        Photon i of a sequence has the Philox stream (key = seed, counter = i).  A sequence that is used again without
+        being re-seeded goes on with the next photon numbers -- the reference's Mersenne Twister simply goes on too --
+        unless the caller names the first photon itself (sharding a batch over ranks)."""
         if not self.isReady_Integrator():
             raise I3RCError("computeRadiativeTransfer: problem not completely specified.")
         if not incomingPhotons.morePhotonsExist():
@@ -348,6 +352,9 @@ class Integrator:
             s.solarMu, s.solarAzimuth = incomingPhotons.solarMu, incomingPhotons.solarAzimuth
         else:
             s.x, s.y, s.z, s.mu, s.phi = [pf(a) for a in incomingPhotons.arrays]
+        if firstPhoton is None:
+            firstPhoton = randomNumbers.photonsDrawn
+            randomNumbers.photonsDrawn += incomingPhotons.n
         self._check(self._lib.i3rc_hip_launch_batch(self._h, randomNumbers.seed[0], randomNumbers.seed[1], int(firstPhoton),
                                                     incomingPhotons.n, C.byref(s)), "computeRadiativeTransfer")
         incomingPhotons.currentPhoton = incomingPhotons.n + 1  # the stream is consumed

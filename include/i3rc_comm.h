@@ -9,8 +9,10 @@
  * MASTER_PORT (torchrun style), else OMPI_COMM_WORLD_RANK / _SIZE / _LOCAL_RANK, else a single process.
  * Backends: "rccl" (default: ncclAllReduce over xGMI) and "shm" (I3RC_COMM_BACKEND=shm: POSIX shared memory on one
  * node, no GPU needed -- used by the CPU tests of the N > 1 path).  Bootstrap of both: rank 0 listens on
- * MASTER_ADDR:MASTER_PORT (IPv4; I3RC_COMM_PORT overrides the port, e.g. under a launcher that keeps MASTER_PORT for
- * itself) and hands the ncclUniqueId / the segment name to the other ranks; nothing is left behind for a later run.
+ * port MASTER_PORT + 1 (I3RC_COMM_PORT overrides it; MASTER_PORT itself belongs to the launcher's store under torchrun)
+ * of MASTER_ADDR (an IPv4 address or a host name) and hands the ncclUniqueId / the segment name to the other ranks
+ * behind a magic / size header, so that a connection to some other service fails instead of hanging; nothing is left
+ * behind for a later run.
  * All functions return 0 on success; i3rc_comm_last_error() describes the last failure.
  */
 #ifndef I3RC_COMM_H

@@ -300,6 +300,23 @@ def test_results_do_not_depend_on_launch_geometry():
     assert np.allclose(e["raw"], a["raw"], rtol=1e-5, atol=1e-6)
 
 
+def test_a_sequence_used_twice_goes_on_with_fresh_photons():
+    # the reference's Mersenne Twister simply goes on when a sequence is used for a second computeRadiativeTransfer; here a
+    # sequence hands out per-photon Philox streams by number, and a second call must get the NEXT numbers, not the same
+    # photons again (round-1 advisor finding): two calls of n photons = one call of 2 n photons
+    d = cases.step_cloud(ssa=0.99)
+    g = make_gpu(d, hg_table(), surfaceAlbedo=0.1)
+    n = 20000
+    seq = M.new_RandomNumberSequence((3, 4))
+    a = g.computeRadiativeTransfer(seq, M.new_PhotonStream(0.7, 30.0, n))
+    b = g.computeRadiativeTransfer(seq, M.new_PhotonStream(0.7, 30.0, n))
+    assert a["counters"] != b["counters"] and not np.array_equal(a["raw"], b["raw"])
+    c = g.computeRadiativeTransfer(M.new_RandomNumberSequence((3, 4)), M.new_PhotonStream(0.7, 30.0, 2 * n))
+    for k in ("photons", "cellSteps", "scatterings", "surfaceHits", "exitsTop", "roulette", "dropped"):
+        assert a["counters"][k] + b["counters"][k] == c["counters"][k], k
+    assert np.allclose(a["raw"] + b["raw"], c["raw"], rtol=1e-5, atol=1e-5)
+
+
 def test_specialised_and_general_kernels_trace_the_same_photons():
     # the launch picks a kernel specialised for regular grid / ray tracing / one component / Directional source;
     # the general kernel must give the same photons the same fate
