@@ -778,7 +778,9 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : 4) : I3RC_MIN_
           }
         }
         if (st == ST_TRACE) {                                             // :480
-          const float tau = -sample_log(fmaxf(kTiny, rng.path()));
+          // (production streams: hardware log2, within 2 ulp -- an optical depth, not a trajectory's bit pattern; the replay
+          // build follows the reference's deviates with libm's logf)
+          const float tau = REPLAY ? -sample_log(fmaxf(kTiny, rng.path())) : -fast_log(fmaxf(kTiny, rng.path()));
           r.acc = 0.0f; r.target = tau;
           if (rayTracing) { startedTrace = true; r.set_direction(L); }
           else {                                                          // :494-496 max cross-section move

@@ -105,6 +105,13 @@ __device__ __forceinline__ float spacingf(float x) {
   return e > (23u << 23) ? __uint_as_float(e - (23u << 23)) : kTiny;
 }
 
+// 2 * spacing(x), exactly: spacing() is a power of two (exponent field E - 23, never below tiny = field 1), so twice it is
+// the field max(E, 24) - 22 -- three integer instructions instead of the five of 2.0f * spacingf(x)
+__device__ __forceinline__ float two_spacingf(float x) {
+  const uint32_t e = __float_as_uint(x) & 0x7f800000u;
+  return __uint_as_float(max(e, 24u << 23) - (22u << 23));
+}
+
 // ---- correctly rounded float32 divide / sqrt from the hardware approximations --------------------------------
 // The reference divides by the same direction cosine at every voxel step of a trace.  v_rcp_f32 (1 ulp) refined
 // once gives r1 ~ 1/d; n/d is then q0 = n*r1 followed by two fused residual corrections -- the tail of the IEEE
@@ -293,23 +300,26 @@ __device__ __forceinline__ StepResult trace_step(const PR &P, const Lds &L, Ray 
   const bool hx = !reach && stx <= step, hy = !reach && sty <= step, hz = !reach && stz <= step;   // face reached
   // :1744-1769 the face position itself when the face is reached, else the advanced position; the index moves on
   // when the face is reached or the position ends within 2 spacing() of it
-  const bool bx = hx || (!reach && fabsf(ex - ax) <= 2.0f * spacingf(ax));
-  const bool by = hy || (!reach && fabsf(ey - ay) <= 2.0f * spacingf(ay));
-  const bool bz = hz || (!reach && fabsf(ez - az) <= 2.0f * spacingf(az));
+  const bool bx = hx || (!reach && fabsf(ex - ax) <= two_spacingf(ax));
+  const bool by = hy || (!reach && fabsf(ey - ay) <= two_spacingf(ay));
+  const bool bz = hz || (!reach && fabsf(ez - az) <= two_spacingf(az));
   r.x = hx ? ex : ax; r.y = hy ? ey : ay; r.z = hz ? ez : az;
   r.ix += bx ? cx : 0; r.iy += by ? cy : 0; r.iz += bz ? cz : 0;
 
-  // periodic wrap :1774-1788 (y uses x's sign, as the reference does)
-  const float nudge = r.nudge;
+  // periodic wrap :1774-1788 (y uses x's sign, as the reference does).  Few steps cross the domain's side walls: the
+  // wrap is skipped by the whole wave when no lane needs it (a uniform branch on a ballot: two scalar instructions)
   const bool xLo = r.ix <= 0, xHi = r.ix >= P.nx + 1, yLo = r.iy <= 0, yHi = r.iy >= P.ny + 1;
-  const float sxp = nudge * spacingf(r.x), syp = nudge * spacingf(r.y);
-  r.x = xLo ? P.xMax + sxp : (xHi ? P.x0 + sxp : r.x);
-  r.y = yLo ? P.yMax + syp : (yHi ? P.y0 + syp : r.y);
-  r.ix = xLo ? P.nx : (xHi ? 1 : r.ix);
-  r.iy = yLo ? P.ny : (yHi ? 1 : r.iy);
+  if (__ballot(xLo || xHi || yLo || yHi) != 0ull) {
+    const float nudge = r.nudge;   // 2 cellIncrement(1) as a float: the nudges are +- 2 spacing()
+    const float sxp = copysignf(two_spacingf(r.x), nudge), syp = copysignf(two_spacingf(r.y), nudge);
+    r.x = xLo ? P.xMax + sxp : (xHi ? P.x0 + sxp : r.x);
+    r.y = yLo ? P.yMax + syp : (yHi ? P.y0 + syp : r.y);
+    r.ix = xLo ? P.nx : (xHi ? 1 : r.ix);
+    r.iy = yLo ? P.ny : (yHi ? 1 : r.iy);
+  }
 
   const bool top = r.iz > P.nz, bottom = r.iz < 1;                     // :1793-1804
-  r.z = top ? P.zMax + 2.0f * spacingf(P.zMax) : (bottom ? P.z0 : r.z);
+  r.z = top ? P.zMax + two_spacingf(P.zMax) : (bottom ? P.z0 : r.z);
   return (reach || top || bottom) ? STEP_DONE : STEP_CONTINUE;
 }
 
