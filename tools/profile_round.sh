@@ -1,0 +1,30 @@
+#!/bin/bash
+# Everything the judged evidence under profiles/ comes from, for one tag (e.g. r02): per workload
+#   * rocprofv3 --kernel-trace --stats of `bench.py --config <w>` (kernel durations -> profiles/<tag>_<w>_kernel_stats.csv)
+#   * the bench line itself                                         (-> profiles/<tag>_<w>_bench.json)
+#   * the --pmc passes of tools/pmc_profile.sh                      (-> profiles/<tag>_<w>_pmc_summary.txt)
+# and the issue-rate microbenchmark.  Runs on the GPU box; results land in gpurun_out/<tag>/ and are copied into profiles/
+# by `tools/profile_round.sh collect <tag>` in the build container afterwards.
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+if [ "$1" = collect ]; then
+  TAG=$2; O=$R/gpurun_out/$TAG
+  for w in step16 radar64_nadir landsat36 landsat119_7dir; do
+    [ -f $O/bench_$w.json ] && cp $O/bench_$w.json $R/profiles/${TAG}_${w}_bench.json
+    f=$(ls $O/stats_$w/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $R/profiles/${TAG}_${w}_kernel_stats.csv
+    [ -f $O/pmc_$w/summary.txt ] && cp $O/pmc_$w/summary.txt $R/profiles/${TAG}_${w}_pmc_summary.txt
+  done
+  [ -f $O/issue_rate.txt ] && cp $O/issue_rate.txt $R/profiles/${TAG}_issue_rate_microbench.txt
+  python3 $R/tools/pmc_to_json.py --collect $R/profiles/${TAG}_pmc.json $R/profiles/${TAG}_*_pmc_summary.txt > /dev/null
+  ls $R/profiles | grep "^${TAG}_"
+  exit 0
+fi
+TAG=$1; O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+declare -A N=( [step16]=50000000 [radar64_nadir]=50000000 [landsat36]=100000000 [landsat119_7dir]=20000000 )
+for w in step16 radar64_nadir landsat36 landsat119_7dir; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$w -- python3 $R/bench.py --config $w --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_prof_$w.json 2> $O/bench_prof_$w.err || echo "stats $w failed"
+  python3 $R/bench.py --config $w > $O/bench_$w.json 2> $O/bench_$w.err || echo "bench $w failed"
+  $R/tools/pmc_profile.sh $TAG/pmc_$w $w ${N[$w]} > $O/pmc_$w.log 2>&1 || echo "pmc $w failed"
+  echo "$w done: $(python3 -c "import json;j=json.load(open('$O/bench_$w.json'));print('%.3e photons/s'%j['value'], j['roofline']['kernel'])")"
+done
+[ -x $R/tools/microbench/issue_rate ] && $R/tools/microbench/issue_rate 5 > $O/issue_rate.txt 2>&1
+echo "profile round $TAG done"
