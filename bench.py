@@ -201,8 +201,10 @@ def worker(a):
     lib = B.load()
     assert lib.i3rc_hip_bind_tally_buffer(integ._h, tally.data_ptr(), tally.numel() * 8) == 0
     assert lib.i3rc_hip_set_stream(integ._h, stream.cuda_stream) == 0
-    # tables are built (and uploaded) by the first call, as in the reference's 1-photon warm-up (monteCarloDriver.f95:233-253)
-    integ.launch(M.new_RandomNumberSequence((10, 0)), M.new_PhotonStream(w["mu0"], 0.0, 1), zero=True)
+    # the phase-function tables are built and uploaded before the timed region (the reference builds them in its 1-photon
+    # warm-up, monteCarloDriver.f95:233-253); no kernel launch here, so that every photon_kernel dispatch a profiler sees
+    # is a full step
+    integ._ensure_tables()
     torch.cuda.synchronize()
 
     iseed = 10
@@ -277,8 +279,14 @@ def worker(a):
             issue = {"valu_instr_per_photon": ipp, "lane_occupancy": pmc["lane_occupancy"],
                      "achieved_instr_per_s": rate, "peak": ISSUE_PEAK, "frac": rate / ISSUE_PEAK,
                      "unit": "wave64 VALU instructions/s (whole chip)",
+                     "cycles_per_valu_instr_per_simd": N_SIMD * 2.4e9 / rate,
                      "assumption": "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (>= 2 waves per SIMD; "
                                    "guide constants table); counters from " + pmc["source"] + f" ({pmc.get('photons', 0):.0f} photons)",
+                     "measured_issue_costs": "tools/microbench/issue_rate.hip at 5 waves per SIMD (profiles/*_issue_rate_microbench.txt): "
+                                             "v_add_f32 / v_mul_f32 / v_add_u32 / v_and_b32 2.5-2.7 cycles, v_fma_f32 3.6, v_cmp / v_min / "
+                                             "v_max3 / v_bfe / v_lshl_add / integer multiplies / f64 / packed f32 4.2-4.9, "
+                                             "v_rcp / v_sqrt / v_log 8.2: the 2-cycle figure holds for the simplest class only, "
+                                             "this kernel's mix is issued at its own pace",
                      "useful_lane_frac": rate / ISSUE_PEAK * pmc["lane_occupancy"]}
         total_photons = float(total_per_step) * a.steps
         value = total_photons / elapsed
