@@ -25,7 +25,8 @@
 
 namespace i3rc {
 
-enum LaneState { ST_TRACE = 0, ST_EVENT = 1, ST_DROPPED = 2, ST_NEW = 3, ST_DONE = 4 };
+enum LaneState { ST_TRACE = 0, ST_EVENT = 1, ST_DROPPED = 2, ST_NEW = 3, ST_DONE = 4,
+                 ST_EXIT = 5 };   // an event known to end the photon (left through the top / onto a black surface): see the turnover quorum
 
 // Work counters (I3RC_CNT_*) are kept per WAVE, in scalar registers: they are only ever advanced in uniform control
 // flow by the population count of a ballot, so they cost no vector registers and no vector instructions.  The
@@ -195,6 +196,9 @@ struct Reservoir {
   }
 };
 
+#ifndef I3RC_RADIANCE_WAVES
+#define I3RC_RADIANCE_WAVES 5   /* (the Landsat + 7 directions case gains 9 % over 4; 6 would spill) */
+#endif
 #ifndef I3RC_MIN_WAVES
 #define I3RC_MIN_WAVES 5
 #endif
@@ -204,7 +208,7 @@ struct Reservoir {
 // loop's code and its scalar-register pressure.  GENERAL = true keeps every path behind run-time switches.
 // (radiance kernels keep two rays per lane live -- the photon's and a shadow ray's: 4 waves per SIMD give them 128 vector registers)
 template <class Rng, bool INTENSITY, bool GENERAL, int GRID>
-__global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : 4) : I3RC_MIN_WAVES) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
+__global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_WAVES) : I3RC_MIN_WAVES) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   {
@@ -250,6 +254,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : 4) : I3RC_MIN_
   find_z<true>(P, L, zStart, izStart);   // (once per wave: the specialised kernels take irregular layers too)
   const float rcpDeltaX = refined_rcp(P.deltaX), rcpDeltaY = refined_rcp(P.deltaY);
   const float surfaceZ = P.z0 + spacingf(P.z0);
+  const bool blackSurface = !Rng::kReplay && !useBDRF && !(P.albedo > kTiny) && !INTENSITY;   // arrival at the surface ends the photon
 
   WaveCounters wc;
   NestedCounters nested;
@@ -297,11 +302,18 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : 4) : I3RC_MIN_
 #ifndef I3RC_LOW_WATER
 #define I3RC_LOW_WATER 56
 #endif
+#ifndef I3RC_TURN_MIN
+#define I3RC_TURN_MIN 4
+#endif
+#ifndef I3RC_TURN_FORCE
+#define I3RC_TURN_FORCE 12
+#endif
 #ifndef I3RC_PHOTON_STEP_AHEAD
 #define I3RC_PHOTON_STEP_AHEAD 64   /* off: measured -1.6 % (step cloud) ... +2.8 % (Landsat-36), -3 % on the radar field */
 #endif
   // measured (Landsat + 7 directions, 2e7 photons): low water 16 / 32 / 48 / 56 / 64 -> 3.1 / 4.2 / 4.6 / 4.7 / 4.7e7 photons/s;
   // two steps per pass +8 %; the radar cases (rays of two steps) do not care
+  constexpr int kTurnMin = Rng::kReplay ? 1 : I3RC_TURN_MIN, kTurnForce = Rng::kReplay ? 1 : I3RC_TURN_FORCE;
   constexpr int kLowWater = I3RC_LOW_WATER, kStepAhead = I3RC_STEP_AHEAD, kPhotonStepAhead = I3RC_PHOTON_STEP_AHEAD;
   bool wantSlots = false, photonsLeft = true;         // wave-uniform
   unsigned qTail = 0u, qHeadEv = 0u, qHeadSub = 0u;   // events pushed / events expanded completely / rays expanded of event qHeadEv
@@ -489,7 +501,9 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : 4) : I3RC_MIN_
                   add_global(Px.tally + Px.oExc + comp * Px.nDir + dIdx, con - Px.maxContrib);
                   con = Px.maxContrib;
                 }
-                tally.radiance(comp, dIdx, (sr.iy - 1) * Px.nx + (sr.ix - 1), con);
+                // (most rays of the roulette end without a contribution: no atomic for adding nothing -- on the radar
+              // field the radiance atomics were 1.4 KB of HBM writes per photon and half of the waves' cycles were waits)
+              if (con != 0.0f) tally.radiance(comp, dIdx, (sr.iy - 1) * Px.nx + (sr.ix - 1), con);
                 rst = R_EMPTY;
               }
             }
@@ -548,16 +562,29 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : 4) : I3RC_MIN_
           ray_step();
           if (liThr - nIdle > kStepAhead) ray_step();
         }
+        // what the photons' rays derive from their directions is worked out again here, so that those eleven registers per
+        // lane are free during the ray loop (the radiance kernels then fit five waves per SIMD)
+        r.set_direction(L);
       }
     }
     // ================================================================================================ PHOTON MODE
     // ---------------------------------------------------------------- EVENT phase
-    const bool wantEvent = st == ST_EVENT || st == ST_DROPPED || st == ST_NEW;
-    const unsigned long long evMask = __ballot(wantEvent);
+    // Two kinds of lanes wait for it: photons with an interaction due (scattering, reflection) and TURNOVER lanes, whose
+    // photon has ended (left through the top, reached a black surface, dropped by the tracer) or that have none yet.
+    // Closing a photon and starting the next one is a third of the event phase's instructions and in most event phases
+    // two or three lanes need it: turnover lanes therefore sit out until kTurnMin of them have gathered (or kTurnForce
+    // of them call for an event phase of their own, or nothing else is left to do).
+    const bool wantScat = st == ST_EVENT;
+    const bool wantTurn = st == ST_EXIT || st == ST_DROPPED || st == ST_NEW;
+    const unsigned long long scMask = __ballot(wantScat), tuMask = __ballot(wantTurn);
     const unsigned long long trMask = __ballot(st == ST_TRACE);
-    if (evMask == 0ull && trMask == 0ull) break;   // (no photons left; any ray work has been done in ray mode above)
-    bool runEvent = evMask != 0ull && (__popcll(evMask) >= evThr || trMask == 0ull);
-    if (DEFER && runEvent && (int)(P.rayQueueCap - (int)(qTail - qHeadEv)) < (int)__popcll(evMask)) {
+    if (scMask == 0ull && tuMask == 0ull && trMask == 0ull) break;   // (no photons left; any ray work has been done in ray mode above)
+    const int nSc = (int)__popcll(scMask), nTu = (int)__popcll(tuMask);
+    bool runEvent = nSc + nTu > 0 && (nSc >= evThr || nTu >= kTurnForce || trMask == 0ull);
+    const bool doTurn = nTu >= kTurnMin || trMask == 0ull || nSc == 0;
+    const bool wantEvent = wantScat || (doTurn && wantTurn);
+    const unsigned long long evMask = __ballot(wantEvent);            // the lanes this event phase serves
+    if (DEFER && runEvent && (int)(P.rayQueueCap - (int)(qTail - qHeadEv)) < nSc) {
       // every lane of the event phase may push one record: without room for all of them the rays are served first
       wantSlots = true;
       runEvent = false;
@@ -576,8 +603,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : 4) : I3RC_MIN_
       // ---- part A: endings that need no random number -- tracer drop, exit through the top, arrival at a black
       //      surface -- are tallied first so that the lanes can be given their next photon before the wave
       //      generates its random block (part C), which then serves old and new photons in one go.
-      const bool blackSurface = !REPLAY && !useBDRF && !(Pe.albedo > kTiny) && !INTENSITY;
-      const bool isEv = wantEvent && st == ST_EVENT;
+      const bool isEv = wantEvent && (st == ST_EVENT || st == ST_EXIT);
       const bool dropped = wantEvent && st == ST_DROPPED;                 // :488-489
       const bool atTop = isEv && r.z >= Pe.zMax;                           // :499-514
       const bool atSurface = isEv && !atTop && r.z <= surfaceZ;           // :515-531
@@ -767,8 +793,8 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : 4) : I3RC_MIN_
               if (w <= kTiny) { if (REPLAY) fate = 2; st = ST_NEW; }
               else {
                 const CompTables ct = GENERAL ? load_tables(Pe.comp[comp - 1]) : load_tables(Pe.comp0);
-                const float cosS = scattering_cosine(rng.first(), ct.invCos + (size_t)(pfi - 1) * ct.nInv, ct.nInv,
-                                                     refined_rcp((float)ct.nInv));
+                const float cosS = scattering_cosine<REPLAY>(rng.first(), ct.invCos + (size_t)(pfi - 1) * ct.nInv, ct.nInv,
+                                                             refined_rcp((float)ct.nInv));
                 next_direct(rng, cosS, r.dx, r.dy, r.dz);                 // :684-687
                 st = ST_TRACE;
               }
@@ -824,13 +850,15 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : 4) : I3RC_MIN_
       PROF_BEGIN();
       if (tracing) {
         const StepResult s = trace_step<GRID>(P, L, r, true);
-        if (s != STEP_CONTINUE) st = s == STEP_DONE ? ST_EVENT : ST_DROPPED;
+        // (an exit through the top, or onto a black surface, ends the photon: such lanes wait for the turnover quorum)
+        if (s != STEP_CONTINUE)
+          st = s == STEP_DONE ? ST_EVENT : (s == STEP_ERROR ? ST_DROPPED : ((r.iz >= 1 || blackSurface) ? ST_EXIT : ST_EVENT));
       }
       PROF_END(PH_STEP, nTracing);
     };
     photon_step();
 #if I3RC_PHOTON_STEP_AHEAD < 64
-    if (!runEvent && evThr - (int)__popcll(evMask) > kPhotonStepAhead) photon_step();
+    if (!runEvent && evThr - nSc > kPhotonStepAhead) photon_step();
 #endif
   }
 #ifdef I3RC_PROFILE_PHASES

@@ -218,7 +218,7 @@ struct Ray {
   }
 };
 
-enum StepResult { STEP_CONTINUE = 0, STEP_DONE = 1, STEP_ERROR = 2 };
+enum StepResult { STEP_CONTINUE = 0, STEP_DONE = 1, STEP_ERROR = 2, STEP_EXIT = 3 };   // DONE: target reached; EXIT: left through the top or the bottom
 
 // (PR: DevProblem -- the kernel argument, held in scalar registers -- or the same struct read through a pointer into the
 // kernarg segment, address space 4: see cold_args in kernels.hpp)
@@ -320,7 +320,7 @@ __device__ __forceinline__ StepResult trace_step(const PR &P, const Lds &L, Ray 
 
   const bool top = r.iz > P.nz, bottom = r.iz < 1;                     // :1793-1804
   r.z = top ? P.zMax + two_spacingf(P.zMax) : (bottom ? P.z0 : r.z);
-  return (reach || top || bottom) ? STEP_DONE : STEP_CONTINUE;
+  return reach ? STEP_DONE : ((top || bottom) ? STEP_EXIT : STEP_CONTINUE);
 }
 
 // findXYIndicies :1353-1374, findZIndex :1376-1388
@@ -360,26 +360,32 @@ __device__ __forceinline__ void find_z(const PR &P, const Lds &L, float z, int &
 // The table holds cos(T(k)) (float64 cosine of the reference's float32 angle table, rounded once).  Because the
 // interpolation weight `left` is < 1/n, cos((1-left) T(k) + left T(k+1)) and (1-left) cos T(k) + left cos T(k+1)
 // differ by < left * dT^2 / 2 ~ 1e-11, far below one float32 ulp: the same cosine without a 57-op cosf per event.
+// EXACT = false (production streams): (k - 1) / n by reciprocal -- `left` only weights the two neighbouring entries.
+template <bool EXACT = true>
 __device__ __forceinline__ float scattering_cosine(float r, const float *cosTab, int n, float rcpN) {
   const int k = (int)(r * (float)n) + 1;
   if (k < n) {
-    const float left = r - exact_div((float)(k - 1), (float)n, rcpN);
+    const float left = r - (EXACT ? exact_div((float)(k - 1), (float)n, rcpN) : (float)(k - 1) * rcpN);
     return (1.0f - left) * cosTab[k - 1] + left * cosTab[k];
   }
   return cosTab[n - 1];
 }
 
 // next_direct :2086-2113
+// The production streams take the azimuth from the hardware sine / cosine (1e-7): there the square root and the two
+// divisions use the hardware approximations as well (same order of error; the direction's norm is renewed by d at every
+// scattering either way).  The replay stream keeps the correctly rounded operations of the reference's arithmetic.
 template <class Rng>
 __device__ __forceinline__ void next_direct(Rng &rng, float cosS, float &s0, float &s1, float &s2) {
   float d, ax, ay;
   rng.disc_point(ax, ay, d);   // a point of the unit disc (any radius): only its azimuth matters
-  float b = exact_sqrt(exact_div(1.0f - cosS * cosS, d, refined_rcp(d)));
+  float b = Rng::kReplay ? exact_sqrt(exact_div(1.0f - cosS * cosS, d, refined_rcp(d)))
+                         : __builtin_amdgcn_sqrtf((1.0f - cosS * cosS) * __builtin_amdgcn_rcpf(d));
   ax = ax * b;
   ay = ay * b;
   b = s0 * ax - s1 * ay;
   const float den = 1.0f + fabsf(s2);
-  d = cosS - exact_div(b, den, refined_rcp(den));
+  d = cosS - (Rng::kReplay ? exact_div(b, den, refined_rcp(den)) : b * __builtin_amdgcn_rcpf(den));
   s0 = s0 * d + ax;
   s1 = s1 * d - ay;
   s2 = s2 * cosS - copysignf(fabsf(b), s2 * b);
