@@ -302,6 +302,9 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
 #ifndef I3RC_LOW_WATER
 #define I3RC_LOW_WATER 56
 #endif
+#ifndef I3RC_THIRD_STEP
+#define I3RC_THIRD_STEP 4   /* a third ray step per pass when the service phase is this much further away: Landsat + 7 directions +2.4 % */
+#endif
 #ifndef I3RC_TURN_MIN
 #define I3RC_TURN_MIN 4
 #endif
@@ -342,7 +345,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
     if (adaptEvent) {
       const float events = (float)(wc.scat + wc.photons + wc.surf), steps = (float)wc.steps;
       if (events > 0.0f && steps > 0.0f) {
-        const int t = (int)(64.0f * __builtin_amdgcn_rsqf(steps * __builtin_amdgcn_rcpf(events)));
+        const int t = (int)(58.0f * __builtin_amdgcn_rsqf(steps * __builtin_amdgcn_rcpf(events)));
         evThr = __builtin_amdgcn_readfirstlane(t < 12 ? 12 : (t > 44 ? 44 : t));
       }
     }
@@ -561,6 +564,9 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
           };
           ray_step();
           if (liThr - nIdle > kStepAhead) ray_step();
+#if I3RC_THIRD_STEP < 64
+          if (liThr - nIdle > kStepAhead + I3RC_THIRD_STEP) ray_step();
+#endif
         }
         // what the photons' rays derive from their directions is worked out again here, so that those eleven registers per
         // lane are free during the ray loop (the radiance kernels then fit five waves per SIMD)
@@ -713,12 +719,18 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
             if (REPLAY) { fateCol = c2; fateW = w; }
             float mu = exact_sqrt(rng.first());
             while (!(fabsf(mu) > 2.0f * kTiny)) mu = exact_sqrt(GENERAL ? rng.next() : rng.fresh());   // :546-549
-            const float phi = (2.0f * kPi) * rng.second();
+            const float turn = rng.second();                               // phi = 2 pi turn (:550)
             if (useBDRF) w = w * surface_reflectance(Pe, r.x, r.y);
             else w = w * Pe.albedo;
             if (w <= kTiny) { if (REPLAY) fate = 1; st = ST_NEW; }
             else {
-              make_dircos(mu, phi, r.dx, r.dy, r.dz);
+              if (REPLAY) make_dircos(mu, (2.0f * kPi) * turn, r.dx, r.dy, r.dz);
+              else {
+                // production streams: the hardware sine / cosine take their argument in revolutions -- two instructions
+                // instead of the ~180 of libm's sinf + cosf (argument reduction for any float), as for the scattering azimuth
+                const float sinTheta = exact_sqrt(1.0f - mu * mu);
+                r.dx = sinTheta * __builtin_amdgcn_cosf(turn); r.dy = sinTheta * __builtin_amdgcn_sinf(turn); r.dz = mu;
+              }
               if (defer) { pendingShadow = true; wI = w; evInfo = 0; }    // component 0: the surface (:567-580)
               else if (INTENSITY)
                 intensity_contribution<GRID>(Pe, L, rng, nested, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, 0, order);
