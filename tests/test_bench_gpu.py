@@ -54,3 +54,22 @@ def test_other_baseline_workloads(config, kernel):
     assert j["roofline"]["per_photon"]["S"] > 100
     if config != "landsat36":
         assert all(0.01 < x < 1.0 for x in j["result_check"]["meanIntensity"])
+
+
+def _gpu_count():
+    import torch
+
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: the real RCCL all-reduce between two ranks (one-GPU boxes run the gloo rehearsal above)")
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_two_ranks_over_rccl(scaling):
+    # the exchange step on the real thing: two rank processes, one GPU each, ONE ncclAllReduce of the packed float64 tally
+    # buffer per step (what replaces Code/multipleProcesses_mpi.f95:57-131); bench.py checks the all-reduced photon count
+    n = 4000001
+    j = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--photons", str(n), "--scaling", scaling])
+    assert j["n_gpus"] == 2 and j["world_size"] == 2 and j["backend"] == "nccl" and len(j["devices"]) == 2
+    assert "cuda:0" in j["devices"][0] and "cuda:1" in j["devices"][1]
+    assert j["config"]["photons_per_step"] == (2 * n if scaling == "weak" else n)
+    assert abs(j["result_check"]["meanFluxUp"] - 0.3253) < 2e-3

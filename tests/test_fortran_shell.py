@@ -417,3 +417,22 @@ def test_photon_stream_constructors_equal_the_oracles_bit_for_bit(shell_built, o
         mine = np.array(got[name], dtype=np.uint32)
         assert mine.shape == (n, 5), (name, mine.shape)
         assert np.array_equal(mine, bits), (name, np.argwhere(mine != bits)[:5])
+
+
+def _gpu_count():
+    try:
+        import torch
+
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: two ranks of module MultipleProcesses over RCCL (one-GPU boxes run the one-rank case)")
+def test_multiple_processes_module_over_rccl_two_ranks():
+    # sumAcrossProcesses (scalar, 1-D ... 4-D) = ncclAllReduce between two rank processes, one GPU each
+    exe = _need(os.path.join(BUILD, "commSelfTest"))
+    rcs, outs = _spawn_ranks([exe], 2, 29651, extra_env=dict(I3RC_COMM_BACKEND="rccl"))
+    assert rcs == [0, 0], outs
+    assert "rank 0 of 2 sums ok master=T" in outs[0] and "rank 1 of 2 sums ok master=F" in outs[1], outs
