@@ -5,12 +5,16 @@
  * I3RC community Monte Carlo model.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
  * leg may load this library; the product (HIP) path never calls it.
  *
- * Parity status: PINNED BY RECORDED REFERENCE OUTPUTS ONLY.  The reference needs netCDF-Fortran, which
- * this image lacks, and the build rules forbid stand-in libraries, so no oracle/_ref binary exists.  The
- * restatement is pinned against (i) the canonical MT19937 known answers, (ii) the reference-run numbers
- * recorded at survey time in SURVEY.md 6 / 8c and BASELINE.md 2 (RNG KATs for seed=(/10,1/), inverse and
- * forward table spot values, planeParallel.nml result 0.16420 / 0.83580 / 0.00363, step-cloud fluxes and
- * per-photon work counters).  See tests/test_oracle_pins.py.
+ * Parity status: PARITY UNPINNED by a reference binary or by reference-held vectors.  The reference needs
+ * netCDF-Fortran, which this image lacks, and the build rules forbid stand-in libraries, so no oracle/_ref binary
+ * exists; the reference ships no tests, golden vectors or expected outputs.  What the restatement is pinned against:
+ * (i) closed forms of the very loop -- Beer-Lambert transmission per column and layer at omega = 0, an empty domain
+ * over a Lambertian surface, first-order scattering of a slab (tests/test_closed_form.py, independent of this code);
+ * (ii) the product's independent Fortran implementation of the six photon-stream constructors, bit for bit
+ * (tests/test_fortran_shell.py); (iii) the canonical MT19937 known answers and the reference-run numbers recorded at
+ * survey time in SURVEY.md 6 / 8c and BASELINE.md 2 (RNG KATs for seed=(/10,1/), inverse and forward table spot values,
+ * planeParallel.nml result 0.16420 / 0.83580 / 0.00363, step-cloud fluxes and per-photon work counters:
+ * tests/test_oracle_pins.py).
  *
  * Every function cites the reference file:line it follows (paths relative to /root/reference).
  * Arithmetic is float32 with no FMA contraction (compile with -ffp-contract=off), matching the
