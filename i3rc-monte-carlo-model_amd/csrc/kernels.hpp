@@ -677,6 +677,9 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
           float px, py, pz;
           if (directional) {   // newPhotonStream_Directional, Code/monteCarloIllumination.f95:91-99
             px = rng.first(); py = rng.second();
+#ifdef I3RC_EXPERIMENT_SLAB   // measurement only (tools/locality_experiment.py): all photons start in one eighth of the domain
+            py *= 0.125f;
+#endif
             pz = 1.0f - spacingf(1.0f);
             r.dx = Ae.solarDx; r.dy = Ae.solarDy; r.dz = Ae.solarDz;
           } else {
