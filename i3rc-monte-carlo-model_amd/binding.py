@@ -18,7 +18,7 @@ MAX_COMPONENTS = 8
 MAX_DIRECTIONS = 20
 NUM_COUNTERS = 16
 COUNTER_NAMES = ["photons", "dropped", "cellSteps", "scatterings", "surfaceHits", "exitsTop", "roulette",
-                 "shadowSteps", "tracerCalls", "rngDraws"]
+                 "shadowSteps", "tracerCalls", "rngDraws", "raysSkipped"]
 
 # every symbol include/i3rc_hip.h declares (checked by tests/test_host_cpu.py::test_cabi_library_exports_every_declared_symbol)
 SYMBOLS = [

@@ -317,6 +317,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
   // measured (Landsat + 7 directions, 2e7 photons): low water 16 / 32 / 48 / 56 / 64 -> 3.1 / 4.2 / 4.6 / 4.7 / 4.7e7 photons/s;
   // two steps per pass +8 %; the radar cases (rays of two steps) do not care
   constexpr int kTurnMin = Rng::kReplay ? 1 : I3RC_TURN_MIN, kTurnForce = Rng::kReplay ? 1 : I3RC_TURN_FORCE;
+  constexpr int kExpandBatch = 32;   // an expand phase runs when the ready buffer has room for this many rays
   constexpr int kLowWater = I3RC_LOW_WATER, kStepAhead = I3RC_STEP_AHEAD, kPhotonStepAhead = I3RC_PHOTON_STEP_AHEAD;
   bool wantSlots = false, photonsLeft = true;         // wave-uniform
   unsigned qTail = 0u, qHeadEv = 0u, qHeadSub = 0u;   // events pushed / events expanded completely / rays expanded of event qHeadEv
@@ -338,6 +339,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
   int liThr = lightThreshold > 0 ? lightThreshold : -lightThreshold;
   const bool adaptEvent = evThreshold < 0, adaptLight = DEFER && lightThreshold < 0;
   uint32_t raysStarted = 0;   // tracer calls for shadow rays since the last refill (wave-uniform)
+  uint32_t raysSkipped = 0;   // local-estimate rays known to contribute nothing before any tracing (lost roulette): whole kernel, per wave
   uint32_t refills = 0;       // visits of the work counter by this wave
   // re-fit the thresholds to what this wave has seen since its last hand-over (uniform control flow only)
   uint32_t raysSeen = 0;      // shadow rays since the last hand-over
@@ -410,14 +412,18 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
         for (;;) {
           const int ringRays = (int)((qTail - qHeadEv) * (unsigned)P.nDir - qHeadSub);   // rays waiting in the ring, not yet expanded
           const int ready = (int)(rdTail - rdHead);                                        // ready-made rays
-          if (ready == 0 && ringRays > 0) {
+          if (ringRays > 0 && ready <= kReadyRays - kExpandBatch) {
             // ------------------------------------------------------------ EXPAND phase: (event, direction) -> ready ray
-            const int n = ringRays < kReadyRays ? ringRays : kReadyRays;
+            const int room = kReadyRays - ready;
+            const int n = ringRays < room ? ringRays : room;
             const int lane = (int)(threadIdx.x & 63);
             PROF_BEGIN();
             const ColdArgs kx = cold_args();   // (the problem through the kernarg segment, as in the event phase)
             const auto &Px = kx->P;
             const auto &Ax = kx->A;
+            bool keep = false;
+            float evWord6 = 0.0f, evNorm = 0.0f, evTauFree = 0.0f, evTarget = 0.0f;
+            const lds_float *evRec = qBase;
             if (lane < n) {                                                  // next radiance direction (:1473-1510)
               const unsigned t = qHeadSub + (unsigned)lane;
               const unsigned eOff = (t * qMagic) >> 16;
@@ -453,18 +459,31 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
                 if (kPi * norm <= Px.zetaMin) { stg = 1 | (r2 * Px.zetaMin <= kPi * norm ? 0x100 : 0); target = tauFree; }
                 else { stg = 2; target = -fast_log(fast_div(Px.zetaMin, fmaxf(kTiny, kPi * norm))); }   // tauMax
               }
-              lds_float *out = rdBase + ((rdTail + (unsigned)lane) & (unsigned)(kReadyRays - 1));
-              out[0] = rec[0]; out[kReadyRays] = rec[cap]; out[2 * kReadyRays] = rec[2 * cap];
-              out[3 * kReadyRays] = rec[3 * cap]; out[4 * kReadyRays] = rec[4 * cap]; out[5 * kReadyRays] = rec[5 * cap];
-              out[6 * kReadyRays] = __int_as_float(comp | (dIdx << 8) | (stg << 16));
-              out[7 * kReadyRays] = rec[6 * cap];
-              out[8 * kReadyRays] = norm; out[9 * kReadyRays] = tauFree; out[10 * kReadyRays] = target; out[11 * kReadyRays] = 0.0f;
+              // A small contribution that has lost its roulette (:1554: the deviate is independent of the path) is 0 whatever
+              // the trace would find: such a ray is not traced at all -- the same estimator, evaluated lazily.  (The
+              // reference traces first and draws afterwards; the replay build keeps that order.)
+              keep = stg != 1;   // (stg == 1: small contribution, roulette lost; 1 | 0x100: won; 0 and 2: always traced)
+              evWord6 = __int_as_float(comp | (dIdx << 8) | (stg << 16));
+              evNorm = norm; evTauFree = tauFree; evTarget = target;
+              evRec = rec;
+            }
+            const unsigned long long keepMask = __ballot(keep);
+            if (keep) {
+              const int cap = Px.rayQueueCap;
+              lds_float *out = rdBase + ((rdTail + (unsigned)lanes_below(keepMask)) & (unsigned)(kReadyRays - 1));
+              out[0] = evRec[0]; out[kReadyRays] = evRec[cap]; out[2 * kReadyRays] = evRec[2 * cap];
+              out[3 * kReadyRays] = evRec[3 * cap]; out[4 * kReadyRays] = evRec[4 * cap]; out[5 * kReadyRays] = evRec[5 * cap];
+              out[6 * kReadyRays] = evWord6;
+              out[7 * kReadyRays] = evRec[6 * cap];
+              out[8 * kReadyRays] = evNorm; out[9 * kReadyRays] = evTauFree; out[10 * kReadyRays] = evTarget; out[11 * kReadyRays] = 0.0f;
             }
             {   // ring bookkeeping (wave-uniform)
               const unsigned t = qHeadSub + (unsigned)n;
               const unsigned e = (t * qMagic) >> 16;
               qHeadEv += e; qHeadSub = t - e * (unsigned)Px.nDir;
-              rdTail += (unsigned)n;
+              const unsigned kept = (unsigned)__popcll(keepMask);
+              rdTail += kept;
+              raysSkipped += (unsigned)n - kept;
             }
             PROF_END(PH_EXPAND, n);
             continue;   // (the loop's only other back edge: see below)
@@ -472,8 +491,9 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
           const unsigned long long actMask = __ballot(rst == R_TRACE), endMask = __ballot(rst == R_ENDED);
           const int nAct = (int)__popcll(actMask), nIdle = 64 - nAct;
           // with photons still to run, the wave leaves its rays once there is nothing left to hand out and few are under way
-          const bool leaving = ready == 0 && photonsLeft && nAct < kLowWater;   // (ready == 0 here implies an empty ring)
-          const bool canServe = endMask != 0ull || (ready > 0 && nIdle > 0);
+          // (no more rays can be made ready at this point: the ring is empty, or the ready buffer is full)
+          const bool leaving = ringRays == 0 && photonsLeft && ready + nAct < kLowWater;   // too few for a wavefront: gather more first
+          const bool canServe = endMask != 0ull || (!leaving && ready > 0 && nIdle > 0);
           if (canServe && (nIdle >= liThr || nAct == 0 || leaving)) {
             // ------------------------------------------------------------ SERVICE phase (shadow-ray ends and starts)
             PROF_BEGIN();
@@ -513,7 +533,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
             // hand ready rays to the free lanes, in order
             const unsigned long long freeMask = __ballot(rst == R_EMPTY);
             const int nFree = (int)__popcll(freeMask);
-            const int take = nFree < ready ? nFree : ready;
+            const int take = leaving ? 0 : (nFree < ready ? nFree : ready);   // (a wave about to leave ends its rays but takes no new ones)
             const int rank = lanes_below(freeMask);
             if (rst == R_EMPTY && rank < take) {
               const lds_float *in = rdBase + ((rdHead + (unsigned)rank) & (unsigned)(kReadyRays - 1));
@@ -535,7 +555,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
             continue;
           }
           if (nAct == 0 || leaving) {
-            // rays still under way (fewer than kLowWater, and the ready buffer is empty) go back to the ready buffer as they are
+            // rays still under way go back to the ready buffer as they are (ready + nAct < kLowWater <= kReadyRays: they fit)
             if (rst == R_TRACE) {
               lds_float *out = rdBase + ((rdTail + (unsigned)lanes_below(actMask)) & (unsigned)(kReadyRays - 1));
               out[0] = sr.x; out[kReadyRays] = sr.y; out[2 * kReadyRays] = sr.z;
@@ -919,6 +939,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
       if (nestedShadow != 0.0) unsafeAtomicAdd(counters + I3RC_CNT_SHADOW_STEPS, nestedShadow);
       if (nestedCalls != 0.0) unsafeAtomicAdd(counters + I3RC_CNT_TRACER_CALLS, nestedCalls);
       if (draws != 0.0) unsafeAtomicAdd(counters + I3RC_CNT_RNG_DRAWS, draws);
+      if (raysSkipped != 0u) unsafeAtomicAdd(counters + I3RC_CNT_RAYS_SKIPPED, (double)raysSkipped);
     }
   }
 }

@@ -67,6 +67,8 @@ enum {
   I3RC_CNT_SHADOW_STEPS,  /* tracer iterations spent in local-estimate rays (:1517-1595) */
   I3RC_CNT_TRACER_CALLS,  /* calls of the tracer, all kinds */
   I3RC_CNT_RNG_DRAWS,     /* uniform deviates consumed */
+  I3RC_CNT_RAYS_SKIPPED,  /* local-estimate rays not traced at all: small contributions that lost their roulette (:1554) -- the
+                             deviate is independent of the path, so the contribution is 0 whatever a trace would find */
   I3RC_NUM_COUNTERS = 16
 };
 
