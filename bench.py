@@ -84,6 +84,8 @@ def launcher(a):
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), I3RC_BENCH_SPAWNED="1")
+        if cpu_baseline is not None and r == 0:   # rank 0 writes the line: it quotes the oracle's work counters in its roofline
+            env["I3RC_BENCH_CPU_BASELINE"] = json.dumps(cpu_baseline)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
@@ -102,8 +104,6 @@ def launcher(a):
     if line is None:
         sys.stderr.write("bench.py: rank 0 printed no result line\n")
         return 1
-    if cpu_baseline is not None:
-        line["cpu_baseline"] = cpu_baseline
     line["launch"] = f"bench.py spawned {a.gpus} rank process(es) itself (one per GPU, 127.0.0.1:{port})"
     print(json.dumps(line))
     return 0
@@ -149,7 +149,9 @@ def worker(a):
     # launched as a rank by somebody else (torchrun) at N = 1: the CPU baseline still runs first, in a child process,
     # before this process touches the GPU
     cpu_baseline = None
-    if n_gpus == 1 and not a.no_cpu_baseline and not os.environ.get("I3RC_BENCH_SPAWNED"):
+    if os.environ.get("I3RC_BENCH_CPU_BASELINE"):
+        cpu_baseline = json.loads(os.environ["I3RC_BENCH_CPU_BASELINE"])   # measured by the launcher before any rank existed
+    elif n_gpus == 1 and not a.no_cpu_baseline and not os.environ.get("I3RC_BENCH_SPAWNED"):
         cpu_baseline = run_cpu_baseline(a)
 
     import numpy as np
@@ -267,8 +269,24 @@ def worker(a):
         share = mine / float(total_per_step)   # this rank's share of the (all-reduced) work counters
         local = {k: v * share for k, v in counters.items()}
         avg_ms = float(np.mean(kernel_ms)) * launches_per_step     # kernel time per step on this rank
-        bpp, skd = algorithmic_bytes_per_photon(local, nd, absorbing)
+        kbpp, kskd = algorithmic_bytes_per_photon(local, nd, absorbing)        # what this kernel actually did
+        # Algorithmic bytes follow SURVEY.md 8(d): the formula evaluated with the work per photon of the REFERENCE'S
+        # ALGORITHM on this input, counted by the CPU restatement.  For flux-only workloads the kernel does exactly that
+        # work; with the local estimate's roulette it leaves out rays that are known to contribute nothing (kernel_work).
+        ref, ref_src = None, None
+        if cpu_baseline and cpu_baseline.get("oracle_per_photon"):
+            ref, ref_src = cpu_baseline["oracle_per_photon"], "CPU restatement (oracle) on this workload, counted in this run's cpu_baseline leg"
+        elif name in W.REFERENCE_WORK:
+            ref, ref_src = W.REFERENCE_WORK[name], "CPU-restatement-equivalent counters recorded in tools/workloads.py (REFERENCE_WORK)"
+        if ref is None or nd == 0:
+            ref, ref_src = kskd, "the kernel's own counters (flux only: identical to the reference's algorithm)"
+        bpp = 16 * ref["S"] + 20 * ref["K"] + (16 * ref["K"] if absorbing else 0) + 8 * ref["E"] + 24 * ref["K"] * nd
+        skd = dict(S=ref["S"], K=ref["K"], E=ref["E"], D=nd)
         achieved = bpp * mine / (avg_ms * 1e-3) / 1e9
+        kernel_work = {"per_photon": kskd, "bytes_per_photon": kbpp, "GBps": kbpp * mine / (avg_ms * 1e-3) / 1e9,
+                       "frac": kbpp * mine / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "rays_skipped_per_photon": local.get("raysSkipped", 0.0) / mine,
+                       "note": "the kernel's own counters: local-estimate rays whose roulette is lost before the trace are not traced"}
         pmc = load_pmc(name)
         traffic = measured = issue = None
         if pmc:
@@ -320,7 +338,8 @@ def worker(a):
                          "measured_hbm_GBps": measured,
                          "measured_hbm_frac": (measured / HBM_PEAK_GBS if measured is not None else None),
                          "kernel": integ.kernel_name(), "kernel_ms_avg": avg_ms, "launches_per_step": launches_per_step,
-                         "algorithmic_bytes_per_photon": bpp, "per_photon": skd,
+                         "algorithmic_bytes_per_photon": bpp, "per_photon": skd, "per_photon_source": ref_src,
+                         "kernel_work": kernel_work,
                          "issue": issue,
                          "note": "working set is LDS/L2 resident: the path is vector-issue bound, not HBM bound -- see `issue` (DESIGN.md section 5)"},
             "cpu_baseline": cpu_baseline,

@@ -55,7 +55,8 @@ def _worker(args):
                          intensity=inten.copy() if (small and inten is not None) else None,
                          means=[float(r[k].mean(dtype=np.float64)) for k in ("fluxUp", "fluxDown", "fluxAbsorbed")],
                          intensityMeans=[] if inten is None else [float(v) for v in inten.mean(axis=(1, 2), dtype=np.float64)],
-                         nBad=int(r["nBad"]), cellSteps=int(r["cellSteps"]), scatterings=int(r["scatterings"])))
+                         nBad=int(r["nBad"]), cellSteps=int(r["cellSteps"]), scatterings=int(r["scatterings"]),
+                         exits=int(r["exitsTop"]) + int(r["surfaceHits"])))
     return time.perf_counter() - t0, fu / n_batches, cols
 
 
@@ -87,7 +88,6 @@ def main():
     if a.save:
         import numpy as np
 
-        allb = [c for r in res for c in r[2]]
         out = dict(means=np.array([c["means"] for c in allb]), intensityMeans=np.array([c["intensityMeans"] for c in allb]),
                    nBad=np.array([c["nBad"] for c in allb]), cellSteps=np.array([c["cellSteps"] for c in allb]),
                    scatterings=np.array([c["scatterings"] for c in allb]), photonsPerBatch=np.array(photons))
@@ -96,6 +96,11 @@ def main():
                 out[k] = np.stack([c[k] for c in allb])
         np.savez(a.save, **out)
     total = cores * a.batches_per_core * photons
+    allb = [c for r in res for c in r[2]]
+    # work per photon of the reference's algorithm on this workload (the oracle's own counters: tracer iterations incl.
+    # local-estimate rays, scatterings, boundary tallies) -- what SURVEY.md 8(d)'s byte formula is evaluated with
+    per_photon = {"S": sum(c["cellSteps"] for c in allb) / total, "K": sum(c["scatterings"] for c in allb) / total,
+                  "E": sum(c["exits"] for c in allb) / total}
     try:
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
@@ -103,7 +108,7 @@ def main():
     print(json.dumps({"value": total / busy, "unit": "photons/s", "cores": cores, "kind": "port",
                       "sample": f"{cores} processes x {a.batches_per_core} batches x {photons} photons of the same workload "
                                 f"({name}), max busy time {busy:.1f} s, wall {wall:.1f} s, host {model}",
-                      "per_core": total / busy / cores,
+                      "per_core": total / busy / cores, "oracle_per_photon": per_photon,
                       "reference_note": REFERENCE_NOTES.get(name, "") + "; kind 'port' = oracle/ C restatement, not the reference binary",
                       "meanFluxUp": sum(r[1] for r in res) / len(res)}))
 

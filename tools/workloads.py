@@ -44,6 +44,17 @@ WORKLOADS = {
                            baseline_config=4, domain=("landsat_cloud", dict(nlayers=36)), moments=299, mu0=0.5,
                            params=dict(**DIRS7, **RRI), surface=0.2, photons=125_000_000, cpu_photons=8_000),
 }
+# Work per photon of the REFERENCE'S ALGORITHM on the four bench workloads (S tracer iterations incl. local-estimate rays,
+# K scatterings, E boundary tallies): the figures SURVEY.md 8(d)'s byte formula is evaluated with.  Recorded from runs in
+# which the kernel still traced every ray (profiles/r02m_*_bench.json; equal to the oracle's counters within Monte Carlo
+# noise, tests/test_gpu_baseline_configs.py); bench.py prefers the oracle's live counters when its CPU-baseline leg ran.
+REFERENCE_WORK = {
+    "step16": dict(S=45.791, K=17.002, E=1.0000),
+    "radar64_nadir": dict(S=198.07, K=44.342, E=0.9998),
+    "landsat36": dict(S=150.02, K=15.787, E=0.9999),
+    "landsat119_7dir": dict(S=3206.2, K=23.228, E=1.1236),
+}
+
 ALIASES = {"step_cloud": "step16", "landsat7": "landsat119_7dir", "radar_nadir": "radar640_nadir", "radar": "radar640",
            "landsat": "landsat119"}
 
