@@ -333,8 +333,9 @@ def worker(a):
             "devices": devices,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "achieved_is": "ALGORITHMIC bytes (SURVEY.md 8d formula x the kernel's own S/K/E/D counters) / kernel time: "
-                                        "a model of what the reference loop touches, NOT bytes that crossed the HBM interface",
+                         "achieved_is": "ALGORITHMIC bytes (SURVEY.md 8d formula x the S/K/E/D per photon of the reference's algorithm "
+                                        "on this input, see per_photon_source) / kernel time: a model of what the reference loop touches, "
+                                        "NOT bytes that crossed the HBM interface (measured_hbm_GBps) and not the kernel's own work (kernel_work)",
                          "measured_hbm_GBps": measured,
                          "measured_hbm_frac": (measured / HBM_PEAK_GBS if measured is not None else None),
                          "kernel": integ.kernel_name(), "kernel_ms_avg": avg_ms, "launches_per_step": launches_per_step,

@@ -64,7 +64,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="step16")
     ap.add_argument("--cores", type=int, default=0)
-    ap.add_argument("--batches-per-core", type=int, default=10)
+    ap.add_argument("--batches-per-core", type=int, default=40)   # 10-16 s on the GPU box's 16 cores (bench.py: "a bounded sample")
     ap.add_argument("--photons", type=int, default=0, help="photons per batch (0 = the workload's bounded sample)")
     ap.add_argument("--nlayers", type=int, default=0, help="step cloud only: 16 = BASELINE.json label, 32 = reference generator")
     ap.add_argument("--mu0", type=float, default=None)

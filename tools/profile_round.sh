@@ -20,10 +20,15 @@ if [ "$1" = collect ]; then
 fi
 TAG=$1; O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 declare -A N=( [step16]=50000000 [radar64_nadir]=50000000 [landsat36]=100000000 [landsat119_7dir]=20000000 )
+# counters first, so that the bench lines below quote THIS build's instruction mix and traffic (bench.py reads the newest profiles/*_pmc.json)
+for w in step16 radar64_nadir landsat36 landsat119_7dir; do
+  $R/tools/pmc_profile.sh $TAG/pmc_$w $w ${N[$w]} > $O/pmc_$w.log 2>&1 || echo "pmc $w failed"
+  echo "$w counters done"
+done
+python3 $R/tools/pmc_to_json.py --collect $R/profiles/${TAG}_pmc.json $O/pmc_*/summary.txt > /dev/null && cp $R/profiles/${TAG}_pmc.json $O/pmc.json
 for w in step16 radar64_nadir landsat36 landsat119_7dir; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$w -- python3 $R/bench.py --config $w --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_prof_$w.json 2> $O/bench_prof_$w.err || echo "stats $w failed"
   python3 $R/bench.py --config $w > $O/bench_$w.json 2> $O/bench_$w.err || echo "bench $w failed"
-  $R/tools/pmc_profile.sh $TAG/pmc_$w $w ${N[$w]} > $O/pmc_$w.log 2>&1 || echo "pmc $w failed"
   echo "$w done: $(python3 -c "import json;j=json.load(open('$O/bench_$w.json'));print('%.3e photons/s'%j['value'], j['roofline']['kernel'])")"
 done
 [ -x $R/tools/microbench/issue_rate ] && $R/tools/microbench/issue_rate 5 > $O/issue_rate.txt 2>&1
