@@ -48,6 +48,8 @@ struct Clocks { unsigned long long shader, wall; };
 #define I_CMPS_CNDMASK(k) asm volatile("v_cmp_lt_u32 s[20:21], %0, %1\n s_nop 1\n v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a##k) : "v"(b) : "s20", "s21");
 #define I_CMP_CNDMASK3(k) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a##k) : "v"(b) : "vcc");
 #define I_CNDMASK_ADD(k) asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_add_u32 %0, %1, %0" : "+v"(a##k) : "v"(b));
+#define I_SWAP(k) asm volatile("v_swap_b32 %0, %1" : "+v"(a##k), "+v"(b));
+#define I_MOV(k) asm volatile("v_mov_b32 %0, %1" : "=v"(a##k) : "v"(b));
 #define I_CMP(k) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a##k), "v"(b) : "vcc");
 #define I_CMPS(k) asm volatile("v_cmp_lt_f32 s[20:21], %0, %1" : : "v"(a##k), "v"(b) : "s20", "s21");
 #define I_MULLO(k) asm volatile("v_mul_lo_u32 %0, %1, %0" : "+v"(a##k) : "v"(b));
@@ -78,6 +80,8 @@ KERNEL(k_cmp_cndmask, UDECL, R64(I_CMP_CNDMASK), USINK)
 KERNEL(k_cmps_cndmask, UDECL, R64(I_CMPS_CNDMASK), USINK)
 KERNEL(k_cmp_cndmask3, UDECL, R64(I_CMP_CNDMASK3), USINK)
 KERNEL(k_cndmask_add, UDECL asm volatile("s_mov_b64 vcc, 0x5555" ::: "vcc");, R64(I_CNDMASK_ADD), USINK)
+KERNEL(k_swap, UDECL, R64(I_SWAP), USINK out[0] = (float)b;)
+KERNEL(k_mov, UDECL, R64(I_MOV), USINK)
 KERNEL(k_cmp, FDECL, R64(I_CMP), FSINK)
 KERNEL(k_cmps, FDECL, R64(I_CMPS), FSINK)
 KERNEL(k_mullo, UDECL, R64(I_MULLO), USINK)
@@ -159,7 +163,7 @@ int main(int argc, char **argv) {
   struct { const char *n; Kern k; } tests[] = {
       {"v_fma_f32", k_fma}, {"v_mul_f32", k_mul}, {"v_add_f32", k_add}, {"v_add_u32", k_addu}, {"v_and_b32", k_and},
       {"v_lshl_add_u32", k_lshladd}, {"v_cndmask_b32", k_cndmask}, {"v_cndmask (sgpr)", k_cndmask_s}, {"v_cndmask (new dst)", k_cndmask_d},
-      {"v_cmp+v_cndmask", k_cmp_cndmask}, {"v_cmp+3 v_cndmask", k_cmp_cndmask3}, {"v_cndmask+v_add", k_cndmask_add}, {"v_cmp_s+nop+cndmsk", k_cmps_cndmask}, {"v_cmp (vcc)", k_cmp}, {"v_cmp (sgpr)", k_cmps},
+      {"v_swap_b32", k_swap}, {"v_mov_b32", k_mov}, {"v_cmp+v_cndmask", k_cmp_cndmask}, {"v_cmp+3 v_cndmask", k_cmp_cndmask3}, {"v_cndmask+v_add", k_cndmask_add}, {"v_cmp_s+nop+cndmsk", k_cmps_cndmask}, {"v_cmp (vcc)", k_cmp}, {"v_cmp (sgpr)", k_cmps},
       {"v_min_f32", k_min}, {"v_max3_f32", k_max3}, {"v_bfe_u32", k_bfe}, {"v_mul_u32_u24", k_mul24},
       {"v_mul_lo_u32", k_mullo}, {"v_mul_hi_u32", k_mulhi}, {"v_mad_u64_u32", k_mad64}, {"v_rcp_f32", k_rcp}, {"v_sqrt_f32", k_sqrt},
       {"v_log_f32", k_log}, {"v_cvt_f32_u32", k_cvtfu}, {"v_cvt_f64_u32", k_cvtf64u}, {"v_mul_f64", k_mulf64}, {"v_fma_f64", k_fmaf64},
