@@ -2,6 +2,7 @@
 (the reference itself cannot be built in this image: it needs netCDF-Fortran) and against the canonical
 MT19937 known answers.  CPU only."""
 import numpy as np
+import pytest
 
 from tests import cases
 
@@ -217,3 +218,22 @@ def test_photon_sources_have_the_distributions_the_reference_documents(oracle):
     x, y, z, mu, phi = O.photons_internal_intensity(O.RandomNumberSequence([3, 4]), 0.5, 0.5, 1.0, -0.2, 270.0, 5)
     assert np.all(phi == np.float32(270.0)) and np.all(mu == np.float32(-0.2))          # degrees, as the reference stores it
     assert np.all(z == np.float32(1.0) - np.spacing(np.float32(1.0)))                   # a downward detector at the top is nudged inside
+
+
+def test_cpu_baseline_tool_reports_work_counters_and_saves_batches(tmp_path):
+    """tools/cpu_baseline.py is bench.py's cpu_baseline leg and the oracle child of the big GPU parity tests: its JSON
+    line carries the reference algorithm's work per photon (what SURVEY.md 8(d)'s byte formula is evaluated with) and
+    --save writes the per-batch results those tests read."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "batches.npz")
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "cpu_baseline.py"), "--config", "radar64_nadir", "--cores", "2",
+                        "--batches-per-core", "2", "--photons", "500", "--save", out], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    j = json.loads(p.stdout.strip().splitlines()[-1])
+    assert j["kind"] == "port" and j["cores"] == 2 and j["value"] > 0
+    w = j["oracle_per_photon"]
+    assert 100 < w["S"] < 400 and 20 < w["K"] < 80 and 0.9 < w["E"] <= 1.0 + 1e-6    # radar field + nadir shadow rays
+    z = np.load(out)
+    assert z["means"].shape[0] == 4 and z["intensityMeans"].shape[0] == 4 and int(z["photonsPerBatch"]) == 500
+    assert float(z["cellSteps"].sum()) / 2000 == pytest.approx(w["S"])

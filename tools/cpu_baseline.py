@@ -85,6 +85,7 @@ def main():
         res = list(ex.map(_worker, jobs))
     wall = time.perf_counter() - t0
     busy = max(r[0] for r in res)
+    allb = [c for r in res for c in r[2]]
     if a.save:
         import numpy as np
 
@@ -96,7 +97,6 @@ def main():
                 out[k] = np.stack([c[k] for c in allb])
         np.savez(a.save, **out)
     total = cores * a.batches_per_core * photons
-    allb = [c for r in res for c in r[2]]
     # work per photon of the reference's algorithm on this workload (the oracle's own counters: tracer iterations incl.
     # local-estimate rays, scatterings, boundary tallies) -- what SURVEY.md 8(d)'s byte formula is evaluated with
     per_photon = {"S": sum(c["cellSteps"] for c in allb) / total, "K": sum(c["scatterings"] for c in allb) / total,
