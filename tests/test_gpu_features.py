@@ -63,6 +63,25 @@ def test_intensity_hybrid_phase_function_and_contribution_limit(oracle):
     assert any(r["raw"][g.layout().intensityExcess:g.layout().intensityExcess + 4].sum() > 0 for r in gr)
 
 
+def test_each_side_makes_its_own_tables(oracle):
+    """Row a13 on the GPU: the product tabulates the inverse / forward / hybrid phase functions itself (nothing is set from
+    outside), the oracle uses its own restatement of tabulateInversePhaseFunctions / tabulateForwardPhaseFunctions /
+    computeHydridPhaseFunctions (monteCarloRadiativeTransfer.f95:1809-1998); fluxes and radiances must still agree."""
+    d = cases.step_cloud(ssa=1.0, nlayers=8)
+    hg = M.henyey_greenstein(0.95, 299)
+    n_table = 9001
+    inv = oracle.inverse_table_legendre(hg.legendre, n_table)
+    fwd = oracle.forward_table_legendre(hg.legendre, n_table)
+    hyb = oracle.hybrid_tables(fwd, 7.0)
+    mus, phis = [1.0, 0.6, -0.7], [0.0, 120.0, 300.0]
+    g = make_gpu(d, M.PhaseFunctionTable([hg]), intensityMus=mus, intensityPhis=phis, minInverseTableSize=n_table,
+                 minForwardTableSize=n_table, useHybridPhaseFunsForIntenCalcs=True, hybridPhaseFunWidth=7.0,
+                 numOrdersOrigPhaseFunIntenCalcs=1, surfaceAlbedo=0.25)
+    o = make_oracle(oracle, d, [inv.reshape(1, -1)], [np.asarray(hyb, np.float32).reshape(1, -1)], [fwd.reshape(1, -1)])
+    o.specify(intensityMus=mus, intensityPhis=phis, useHybrid=1, numOrdersOrig=1, surfaceAlbedo=0.25)
+    _parity(oracle, g, o, 8, 6000, 0.8, az=15.0, keys=("fluxUp", "fluxDown", "intensity"))
+
+
 def test_surface_brdf_grid(oracle):
     d = cases.step_cloud(ssa=1.0, nlayers=8)
     xs = np.array([0.0, 100.0, 350.0, 500.0], np.float32)
