@@ -1,0 +1,94 @@
+"""Large-sample parity report: every BASELINE workload on the GPU at (or near) its BASELINE.json size against the CPU
+oracle on all host cores, the oracle's sample produced by a child program while the GPU traces its own.  Prints, per
+workload, the domain means with their standard errors, the z score of every difference (GPU - oracle, in units of the
+combined standard error), the share of columns within 3 sigma and the largest column |z|.  The tests do the same at
+1e6-2e6 photons (tests/test_gpu_baseline_configs.py); this is the long version, run by hand on the GPU box:
+    python tools/parity_large.py [workload ...] > gpurun_out/parity_large.txt
+(test infrastructure: the only place the oracle is used is as the checker.)"""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tools import workloads as W  # noqa: E402
+
+# workload -> (GPU batches, photons per GPU batch, oracle batches per core, photons per oracle batch): 16 cores assumed
+PLAN = {
+    "step16": (100, 1_000_000, 8, 400_000),          # 1e8 on the GPU, 5.1e7 in the oracle (~7 s)
+    "radar64_nadir": (100, 1_000_000, 8, 150_000),   # 1e8 / 1.9e7 (~10 s)
+    "landsat36": (100, 1_000_000, 8, 250_000),       # 1e8 / 3.2e7 (~9 s)
+    "landsat119_7dir": (100, 250_000, 8, 40_000),    # 2.5e7 / 5.1e6 (~20 s)
+}
+
+
+def z_of(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    se = np.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b))
+    return a.mean(), b.mean(), se, (a.mean() - b.mean()) / se if se > 0 else 0.0
+
+
+def columns(gpu, ref, floor=1e-7):
+    g, r = np.stack(gpu).astype(np.float64), np.stack(ref).astype(np.float64)
+    se = np.sqrt(g.var(0, ddof=1) / len(g) + r.var(0, ddof=1) / len(r))
+    z = np.abs(g.mean(0) - r.mean(0)) / np.maximum(se, floor)
+    return float((z <= 3.0).mean()), float(z.max()), z.size
+
+
+def main():
+    import i3rc_monte_carlo_model_amd as M
+
+    names = sys.argv[1:] or list(PLAN)
+    cores = min(16, len(os.sched_getaffinity(0)))
+    worst = 0.0
+    for name in names:
+        nb, n, per_core, n_ref = PLAN[name]
+        _, w = W.get(name)
+        out = os.path.join(tempfile.mkdtemp(), f"oracle_{name}.npz")
+        t0 = time.perf_counter()
+        child = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--config", name, "--cores", str(cores),
+                                  "--batches-per-core", str(per_core), "--photons", str(n_ref), "--save", out],
+                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        g, _ = W.make_integrator(w)
+        rs = [g.computeRadiativeTransfer(M.new_RandomNumberSequence((91, b)), M.new_PhotonStream(w["mu0"], 0.0, n)) for b in range(1, nb + 1)]
+        kernel = g.kernel_name()
+        g.finalize_Integrator()
+        t_gpu = time.perf_counter() - t0
+        so, se = child.communicate(timeout=1500)
+        if child.returncode != 0:
+            print(f"{name}: oracle child failed\n{so}{se}")
+            sys.exit(1)
+        t_all = time.perf_counter() - t0
+        z = np.load(out)
+        nd = len(w["params"].get("intensityMus", []))
+        print(f"== {name}: GPU {nb} x {n} = {nb * n:.3g} photons ({kernel}, {t_gpu:.1f} s incl. set-up); "
+              f"oracle {len(z['means'])} x {n_ref} = {len(z['means']) * n_ref:.3g} photons on {cores} cores ({t_all:.1f} s)")
+        for k, key in enumerate(("fluxUp", "fluxDown", "fluxAbsorbed")):
+            a, b, s, zz = z_of([r[key].mean(dtype=np.float64) for r in rs], z["means"][:, k])
+            worst = max(worst, abs(zz))
+            print(f"   mean {key:12s} GPU {a:.6f}  oracle {b:.6f}  combined se {s:.2e}  z {zz:+.2f}")
+        for d in range(nd):
+            a, b, s, zz = z_of([r["intensity"][d].mean(dtype=np.float64) for r in rs], z["intensityMeans"][:, d])
+            worst = max(worst, abs(zz))
+            print(f"   mean radiance {d} (mu {w['params']['intensityMus'][d]:+.1f}, phi {w['params']['intensityPhis'][d]:5.1f})"
+                  f"  GPU {a:.6f}  oracle {b:.6f}  combined se {s:.2e}  z {zz:+.2f}")
+        for key in ("fluxUp", "fluxDown") + (("intensity",) if nd else ()):
+            if key in z.files:
+                frac, zmax, cnt = columns([r[key] for r in rs], list(z[key]))
+                print(f"   columns {key:10s} {cnt} values: {100 * frac:.2f} % within 3 sigma, max |z| {zmax:.2f}")
+        n_g, n_o = nb * n, n_ref * len(z["nBad"])
+        dg, do = sum(r["counters"]["dropped"] for r in rs) / n_g, z["nBad"].sum() / n_o
+        kg, ko = sum(r["counters"]["scatterings"] for r in rs) / n_g, z["scatterings"].sum() / n_o
+        sg = sum(r["counters"]["cellSteps"] + r["counters"]["shadowSteps"] for r in rs) / n_g
+        print(f"   per photon: dropped GPU {dg:.3e} oracle {do:.3e}; scatterings {kg:.4f} / {ko:.4f}; tracer steps {sg:.2f} / "
+              f"{z['cellSteps'].sum() / n_o:.2f} (GPU leaves out rays whose roulette is lost before the trace: "
+              f"{sum(r['counters']['raysSkipped'] for r in rs) / n_g:.3f} per photon)", flush=True)
+    print(f"largest |z| of a domain mean: {worst:.2f}")
+
+
+if __name__ == "__main__":
+    main()
