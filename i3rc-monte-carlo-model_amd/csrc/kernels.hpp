@@ -10,9 +10,10 @@
 //     next photon, one Philox block for the whole wave, scatter / surface / new photon, new optical depth) that runs
 //     when enough lanes wait for it;
 //   * radiances: an event pushes ONE record into its wave's ray queue (a ring in LDS) and the photon goes on; when the
-//     ring holds a wavefront's worth of local-estimate (shadow) rays the wave changes to RAY MODE, in which every lane
-//     pops an (event, direction) pair and traces it with the same voxel-step phase, popping the next as soon as its
-//     ray ends -- shadow rays run with nearly full wavefronts, independent of the photons that caused them;
+//     ring holds a wavefront's worth of local-estimate (shadow) rays the wave changes to RAY MODE: all lanes turn
+//     (event, direction) pairs into ready rays (a ray whose roulette is already lost is dropped there), lanes take a
+//     ready ray as soon as theirs has ended -- shadow rays run with nearly full wavefronts, independent of the photons
+//     that caused them;
 //   * cell edges (and, when they fit, the extinction grid) are staged in LDS with coalesced loads; grids beyond an
 //     XCD's L2 are read from a copy in 32-cell bricks; flux and radiance tallies are privatised per workgroup in LDS
 //     (ds_add_f32) and flushed once with float64 atomics; large domains tally straight to HBM with float64 atomics;
@@ -300,7 +301,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
 #define I3RC_STEP_AHEAD 2
 #endif
 #ifndef I3RC_LOW_WATER
-#define I3RC_LOW_WATER 56
+#define I3RC_LOW_WATER 64   /* = the ready buffer: with nothing left to expand, a wave leaves its rays unless a whole wavefront of them is in hand */
 #endif
 #ifndef I3RC_THIRD_STEP
 #define I3RC_THIRD_STEP 4   /* a third ray step per pass when the service phase is this much further away: Landsat + 7 directions +2.4 % */
@@ -314,10 +315,15 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
 #ifndef I3RC_PHOTON_STEP_AHEAD
 #define I3RC_PHOTON_STEP_AHEAD 64   /* off: measured -1.6 % (step cloud) ... +2.8 % (Landsat-36), -3 % on the radar field */
 #endif
-  // measured (Landsat + 7 directions, 2e7 photons): low water 16 / 32 / 48 / 56 / 64 -> 3.1 / 4.2 / 4.6 / 4.7 / 4.7e7 photons/s;
-  // two steps per pass +8 %; the radar cases (rays of two steps) do not care
+  // measured (Landsat + 7 directions, 2e7 photons, before the lazy roulette): low water 16 / 32 / 48 / 56 / 64 -> 3.1 / 4.2 / 4.6 / 4.7 /
+  // 4.7e7 photons/s; two steps per pass +8 %.  With the lazy roulette (most rays end in EXPAND): low water 40 / 48 / 56 / 64 ->
+  // 8.2 / 9.1 / 9.2 / 9.4e7 (radar-64 + nadir 5.8 / 5.9 / 6.1 / 6.2e8); expand batch 16 / 32 / 48 / 64 -> radar-64 5.8 / 6.1 /
+  // 6.3 / 6.4e8; both at 64: +5.5 % (radar-64), +3 % (Landsat + 7 directions), +4 % (radar 640 + nadir)
   constexpr int kTurnMin = Rng::kReplay ? 1 : I3RC_TURN_MIN, kTurnForce = Rng::kReplay ? 1 : I3RC_TURN_FORCE;
-  constexpr int kExpandBatch = 32;   // an expand phase runs when the ready buffer has room for this many rays
+#ifndef I3RC_EXPAND_BATCH
+#define I3RC_EXPAND_BATCH 64   /* = the ready buffer: expand when it is empty, a whole wavefront at a time */
+#endif
+  constexpr int kExpandBatch = I3RC_EXPAND_BATCH;   // an expand phase runs when the ready buffer has room for this many rays
   constexpr int kLowWater = I3RC_LOW_WATER, kStepAhead = I3RC_STEP_AHEAD, kPhotonStepAhead = I3RC_PHOTON_STEP_AHEAD;
   bool wantSlots = false, photonsLeft = true;         // wave-uniform
   unsigned qTail = 0u, qHeadEv = 0u, qHeadSub = 0u;   // events pushed / events expanded completely / rays expanded of event qHeadEv
