@@ -35,7 +35,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # Vector-instruction issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles per SIMD once >= 2 waves
 # share it (guide: "v_fma_f32 (wave64) 2 cyc (SIMD-32); one wave alone: 4"), at the 2.4 GHz peak clock.  The kernels
-# run 5 waves per SIMD.  tools/microbench/opcost.hip `issue` measures the same figure on the box (profiles/r02_issue_peak.txt).
+# run 5 waves per SIMD.  tools/microbench/issue_rate.hip measures the actual cost per instruction kind on the box
+# (profiles/*_issue_rate_microbench.txt: 2.5 cycles for the simplest class, 3.6-4.9 for most, 8.2 for transcendentals).
 N_SIMD = 256 * 4
 ISSUE_PEAK = N_SIMD * 2.4e9 / 2.0
 
