@@ -610,6 +610,10 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, plan.ldsBytes) != hipSuccess || occ < 1) occ = 2;
     perCU = std::min(occ, 8);
+    // a field beyond an XCD's L2 (bricks): every wave in flight widens the part of it that is in use; measured on the
+    // 7.8 MB Landsat-119 field (tools/blocks_sweep.py): 4-5 workgroups per CU 6.17e8 photons/s, 6-8 5.83e8.  (The radiance
+    // kernels have the registers for five at most; fields within L2 gain up to 7.)
+    if (place == GRID_BRICKS) perCU = std::min(perCU, 5);
   }
   if (plan.ldsBytes > 48 * 1024)
     HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.ldsBytes));
