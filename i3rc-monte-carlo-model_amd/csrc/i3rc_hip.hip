@@ -204,6 +204,10 @@ int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int n
     auto log2le = [](int n, int cap) { int s = 0; while ((2 << s) <= n && s + 1 <= cap) ++s; return s; };
     h->bsz = log2le(nz, 3);
     h->bsy = log2le(ny, (5 - h->bsz) / 2);
+    if (const char *e = std::getenv("I3RC_BRICK")) {   // tuning knob: "<log2 depth>,<log2 width in y>" (the rest of the 32 cells in x)
+      int bz = 3, by = 1;
+      if (std::sscanf(e, "%d,%d", &bz, &by) == 2 && bz >= 0 && by >= 0 && bz + by <= 5) { h->bsz = log2le(nz, bz); h->bsy = log2le(ny, by); }
+    }
     h->bsx = 5 - h->bsz - h->bsy;
     h->nbx = (nx + (1 << h->bsx) - 1) >> h->bsx; h->nby = (ny + (1 << h->bsy) - 1) >> h->bsy;
     h->nbz = (nz + 1 + (1 << h->bsz) - 1) >> h->bsz;   // (room for the layer nz + 1 of zeros, as in dExt)
