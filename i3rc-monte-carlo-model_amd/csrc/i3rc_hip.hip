@@ -24,6 +24,7 @@ thread_local std::string g_createError;
 // allocations have left their contents behind.
 bool poison() { static const bool on = std::getenv("I3RC_POISON") != nullptr; return on; }
 
+
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
@@ -74,6 +75,18 @@ struct i3rc_hip_integrator {
   double *tally = nullptr;  // device pointer in use (own or bound)
   DevBuf workCounter;
   DevBuf srcBuf[5];
+
+  // i3rc_hip_run_batches: batches in flight, each with a stream, a tally buffer, a work counter and a pinned host copy of its own
+  struct PipeSlot {
+    hipStream_t stream = nullptr;
+    DevBuf tally, counter;
+    double *pinned = nullptr;
+    hipEvent_t done = nullptr;
+    int batch = -1;            // batch whose tallies are on their way into `pinned`
+  };
+  static constexpr int kMaxInFlight = 8;
+  PipeSlot pipe[kMaxInFlight];
+  int64_t pipeTotal = 0;       // layout.total the slots were sized for
 
   hipStream_t ownStream = nullptr, stream = nullptr;
   static constexpr int kEventRing = 64;   // HIP-event pairs of the most recent timed launches
@@ -279,6 +292,11 @@ int i3rc_hip_destroy(i3rc_hip_integrator *h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   if (h->ownStream) { (void)hipStreamSynchronize(h->ownStream); (void)hipStreamDestroy(h->ownStream); }
+  for (auto &sl : h->pipe) {
+    if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
+    if (sl.done) (void)hipEventDestroy(sl.done);
+    if (sl.pinned) (void)hipHostFree(sl.pinned);
+  }
   for (int i = 0; i < i3rc_hip_integrator::kEventRing; ++i) {
     if (h->evStart[i]) (void)hipEventDestroy(h->evStart[i]);
     if (h->evStop[i]) (void)hipEventDestroy(h->evStop[i]);
@@ -674,6 +692,72 @@ int i3rc_hip_launch_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1
     if (launch<PhiloxStream>(h, plan, part, true)) return 1;
   }
   return 0;
+}
+
+// The batch loop of a driver (Example-Drivers/monteCarloDriver.f95:283-326) as one call: see include/i3rc_hip.h
+int i3rc_hip_run_batches(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int nBatches, int64_t nPhotons,
+                         const i3rc_source *src, int inFlight, double *hostTallies) {
+  if (!h) return 1;
+  if (!src || !hostTallies || nBatches < 1) return h->fail("i3rc_hip_run_batches: bad arguments");
+  if (src->kind != 0) return h->fail("i3rc_hip_run_batches: Directional photon streams only (explicit streams differ from batch to batch)");
+  if (nPhotons <= 0) return h->fail("setIllumination: must ask for non-negative number of photons.");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int K = std::min(nBatches, inFlight <= 0 ? 6 : std::min(inFlight, (int)i3rc_hip_integrator::kMaxInFlight));
+  const size_t bytes = (size_t)h->layout.total * sizeof(double);
+  for (int k = 0; k < K; ++k) {   // slots are kept with the handle: pinned memory and streams are expensive to make
+    auto &sl = h->pipe[k];
+    if (!sl.stream) HIPCHK(h, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+    if (!sl.done) HIPCHK(h, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (!sl.counter.p) HIPCHK(h, sl.counter.alloc(sizeof(unsigned long long)));
+    if (!sl.pinned || !sl.tally.p || h->pipeTotal != h->layout.total) {
+      if (sl.pinned) { HIPCHK(h, hipHostFree(sl.pinned)); sl.pinned = nullptr; }
+      HIPCHK(h, hipHostMalloc((void **)&sl.pinned, bytes, hipHostMallocDefault));
+      HIPCHK(h, sl.tally.alloc(bytes));
+    }
+    sl.batch = -1;
+  }
+  h->pipeTotal = h->layout.total;
+  HIPCHK(h, hipStreamSynchronize(h->stream));   // whatever the caller had in flight on the handle's stream comes first
+  hipStream_t const callerStream = h->stream;
+  double *const callerTally = h->tally;
+  int rc = 0;
+  auto collect = [&](i3rc_hip_integrator::PipeSlot &sl) -> int {
+    if (sl.batch < 0) return 0;
+    HIPCHK(h, hipEventSynchronize(sl.done));
+    std::memcpy(hostTallies + (size_t)sl.batch * (size_t)h->layout.total, sl.pinned, bytes);
+    sl.batch = -1;
+    return 0;
+  };
+  const int64_t perLaunch = h->launchLimit > 0 ? h->launchLimit : (int64_t)h->numCU << 22;
+  for (int b = 0; b < nBatches && !rc; ++b) {
+    auto &sl = h->pipe[b % K];
+    if ((rc = collect(sl))) break;
+    h->stream = sl.stream; h->tally = (double *)sl.tally.p;   // (make_problem and launch read these two)
+    LaunchPlan plan;
+    if ((rc = make_problem(h, plan))) break;
+    RunArgs A;
+    std::memset(&A, 0, sizeof(A));
+    A.seed0 = seed0; A.seed1 = seed1 + (uint32_t)b; A.firstPhoton = 0; A.nPhotons = nPhotons;
+    A.workCounter = (unsigned long long *)sl.counter.p;
+    if ((rc = upload_source(h, src, nPhotons, A))) break;
+    if (hipMemsetAsync(sl.tally.p, 0, bytes, sl.stream) != hipSuccess) { rc = h->fail("i3rc_hip_run_batches: clearing a tally buffer failed"); break; }
+    for (int64_t done = 0; done < nPhotons && !rc; done += perLaunch) {   // (very long batches: see i3rc_hip_launch_batch)
+      RunArgs part = A;
+      part.firstPhoton = done;
+      part.nPhotons = std::min(perLaunch, nPhotons - done);
+      rc = launch<PhiloxStream>(h, plan, part, true);
+    }
+    if (rc) break;
+    if (hipMemcpyAsync(sl.pinned, sl.tally.p, bytes, hipMemcpyDeviceToHost, sl.stream) != hipSuccess ||
+        hipEventRecord(sl.done, sl.stream) != hipSuccess) { rc = h->fail("i3rc_hip_run_batches: copying a batch's tallies back failed"); break; }
+    sl.batch = b;
+  }
+  for (int k = 0; k < K; ++k) {   // drain (also after a failure: nothing of this call stays in flight)
+    if (rc) { (void)hipStreamSynchronize(h->pipe[k].stream); h->pipe[k].batch = -1; }
+    else rc = collect(h->pipe[k]);
+  }
+  h->stream = callerStream; h->tally = callerTally;
+  return rc;
 }
 
 int i3rc_hip_run_replay(i3rc_hip_integrator *h, int64_t nPhotons, const i3rc_source *src, const float *randoms,

@@ -106,6 +106,17 @@ module i3rcHipInterface
       type(i3rc_source), intent(in) :: src
       integer(c_int)                :: rc
     end function
+    function i3rc_hip_run_batches(h, seed0, seed1, nBatches, nPhotons, src, inFlight, hostTallies) &
+             bind(C, name = "i3rc_hip_run_batches") result(rc)
+      import
+      type(c_ptr), value            :: h
+      integer(c_int32_t), value     :: seed0, seed1          ! batch k is traced with the key (seed0, seed1 + k)
+      integer(c_int), value         :: nBatches, inFlight
+      integer(c_int64_t), value     :: nPhotons
+      type(i3rc_source), intent(in) :: src
+      real(c_double), intent(out)   :: hostTallies(*)        ! nBatches * layout%total
+      integer(c_int)                :: rc
+    end function
     function i3rc_hip_fetch_tallies(h, host) bind(C, name = "i3rc_hip_fetch_tallies") result(rc)
       import
       type(c_ptr), value          :: h

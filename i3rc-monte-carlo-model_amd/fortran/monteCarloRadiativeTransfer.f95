@@ -56,11 +56,15 @@ module monteCarloRadiativeTransfer
     real, dimension(:, :, :),    pointer :: volumeAbsorption => null(), intensity => null()
     real, dimension(:, :, :, :), pointer :: intensityByComponent => null()
     double precision :: photonsProcessed = 0.d0, photonsDropped = 0.d0
+    ! raw tallies of the batches of the last computeRadiativeTransferBatches (one column per batch)
+    real(c_double), dimension(:, :), pointer :: batchTallies => null()
   end type integrator
 
   public :: integrator
   public :: new_Integrator, copy_Integrator, isReady_Integrator, finalize_Integrator, &
             specifyParameters, computeRadiativeTransfer, reportResults
+  ! Not in the reference: a driver's batch loop as one call, the batches overlapping on the device (see the procedures)
+  public :: computeRadiativeTransferBatches, selectBatchResults
 contains
   ! ------------------------------------------------------------------------------------------------
   ! Creation
@@ -446,7 +450,6 @@ contains
     real, dimension(:), pointer :: x, y, z, mus, phis
     real(c_float), dimension(:), allocatable, target :: sx, sy, sz, smu, sphi
     real(c_double), dimension(:), allocatable :: raw
-    type(c_ptr) :: pIntensity, pByComponent
 
     if(.not. isReady_Integrator(thisIntegrator)) then
       call setStateToFailure(status, "computeRadiativeTransfer: problem not completely specified.")
@@ -480,17 +483,7 @@ contains
                         "computeRadiativeTransfer", status)) return
     allocate(raw(layout%total))
     if(.not. deviceCall(thisIntegrator, i3rc_hip_fetch_tallies(thisIntegrator%device, raw), "computeRadiativeTransfer", status)) return
-    pIntensity = c_null_ptr; pByComponent = c_null_ptr
-    if(thisIntegrator%computeIntensity) then
-      pIntensity   = c_loc(thisIntegrator%intensity(1, 1, 1))
-      pByComponent = c_loc(thisIntegrator%intensityByComponent(1, 1, 1, 0))
-    end if
-    if(.not. deviceCall(thisIntegrator, i3rc_hip_normalise(thisIntegrator%device, raw, c_loc(thisIntegrator%fluxUp(1, 1)),   &
-                        c_loc(thisIntegrator%fluxDown(1, 1)), c_loc(thisIntegrator%fluxAbsorbed(1, 1)),                        &
-                        c_loc(thisIntegrator%volumeAbsorption(1, 1, 1)), pIntensity, pByComponent),                           &
-                        "computeRadiativeTransfer", status)) return
-    thisIntegrator%photonsProcessed = raw(layout%counters + 1 + I3RC_CNT_PHOTONS)
-    thisIntegrator%photonsDropped   = raw(layout%counters + 1 + I3RC_CNT_DROPPED)
+    if(.not. unpackTallies(thisIntegrator, raw, layout, "computeRadiativeTransfer", status)) return
     deallocate(raw)
     if(allocated(sx)) deallocate(sx, sy, sz, smu, sphi)
 
@@ -503,6 +496,97 @@ contains
       call setStateToFailure(status, "computeRadiativeTransfer: Didn't process any photons.")
     end if
   end subroutine computeRadiativeTransfer
+
+  ! raw float64 tallies of one batch -> the normalised results reportResults hands out (:353-395)
+  function unpackTallies(thisIntegrator, raw, layout, caller, status) result(ok)
+    type(integrator),             intent(inout) :: thisIntegrator
+    real(c_double), dimension(:), intent(in   ) :: raw
+    type(i3rc_tally_layout),      intent(in   ) :: layout
+    character(len = *),           intent(in   ) :: caller
+    type(ErrorMessage),           intent(inout) :: status
+    logical :: ok
+    type(c_ptr) :: pIntensity, pByComponent
+    pIntensity = c_null_ptr; pByComponent = c_null_ptr
+    if(thisIntegrator%computeIntensity) then
+      pIntensity   = c_loc(thisIntegrator%intensity(1, 1, 1))
+      pByComponent = c_loc(thisIntegrator%intensityByComponent(1, 1, 1, 0))
+    end if
+    ok = deviceCall(thisIntegrator, i3rc_hip_normalise(thisIntegrator%device, raw, c_loc(thisIntegrator%fluxUp(1, 1)),   &
+                    c_loc(thisIntegrator%fluxDown(1, 1)), c_loc(thisIntegrator%fluxAbsorbed(1, 1)),                        &
+                    c_loc(thisIntegrator%volumeAbsorption(1, 1, 1)), pIntensity, pByComponent), caller, status)
+    if(.not. ok) return
+    thisIntegrator%photonsProcessed = raw(layout%counters + 1 + I3RC_CNT_PHOTONS)
+    thisIntegrator%photonsDropped   = raw(layout%counters + 1 + I3RC_CNT_DROPPED)
+  end function unpackTallies
+
+  ! ------------------------------------------------------------------------------------------------
+  ! Not in the reference: the batch loop of a driver (Example-Drivers/monteCarloDriver.f95:283-326) as one call.
+  !   Batch b = firstBatch ... firstBatch + numBatches - 1 is traced exactly as
+  !     computeRadiativeTransfer(integrator, new_RandomNumberSequence(seed = (/ iseed, b /)),
+  !                              new_PhotonStream(solarMu, solarAzimuth, numberOfPhotons, ...), status)
+  !   traces it (same photons), but several batches share the device at a time (i3rc_hip_run_batches): a batch of 1e5 ... 1e6
+  !   photons ends with a long tail -- a few photons with a thousand scatterings -- that the next batch's photons cover.
+  !   selectBatchResults(integrator, k, status), k = 1 ... numBatches, then makes batch firstBatch + k - 1 the one
+  !   reportResults reports.  The raw tallies of all batches of the call stay with the integrator until the next call.
+  ! ------------------------------------------------------------------------------------------------
+  subroutine computeRadiativeTransferBatches(thisIntegrator, iseed, firstBatch, numBatches, solarMu, solarAzimuth, &
+                                             numberOfPhotons, status, batchesInFlight)
+    type(integrator),   intent(inout) :: thisIntegrator
+    integer,            intent(in   ) :: iseed, firstBatch, numBatches, numberOfPhotons
+    real,               intent(in   ) :: solarMu, solarAzimuth
+    type(ErrorMessage), intent(inout) :: status
+    integer, optional,  intent(in   ) :: batchesInFlight
+    type(i3rc_source)       :: source
+    type(i3rc_tally_layout) :: layout
+    integer :: inFlight
+
+    if(.not. isReady_Integrator(thisIntegrator)) then
+      call setStateToFailure(status, "computeRadiativeTransfer: problem not completely specified.")
+      return
+    end if
+    if(numBatches < 1 .or. numberOfPhotons < 1) then
+      call setStateToFailure(status, "computeRadiativeTransfer: Didn't process any photons.")
+      return
+    end if
+    call ensureTables(thisIntegrator, status)
+    if(stateIsFailure(status)) return
+    inFlight = 0
+    if(present(batchesInFlight)) inFlight = batchesInFlight
+    source%kind = 0; source%solarMu = solarMu; source%solarAzimuth = solarAzimuth
+    if(.not. deviceCall(thisIntegrator, i3rc_hip_get_tally_layout(thisIntegrator%device, layout), &
+                        "computeRadiativeTransfer", status)) return
+    if(associated(thisIntegrator%batchTallies)) deallocate(thisIntegrator%batchTallies)
+    allocate(thisIntegrator%batchTallies(layout%total, numBatches))
+    if(.not. deviceCall(thisIntegrator, i3rc_hip_run_batches(thisIntegrator%device, int(iseed, c_int32_t),              &
+                        int(firstBatch, c_int32_t), int(numBatches, c_int), int(numberOfPhotons, c_int64_t), source,   &
+                        int(inFlight, c_int), thisIntegrator%batchTallies), "computeRadiativeTransfer", status)) then
+      deallocate(thisIntegrator%batchTallies)
+      return
+    end if
+    call selectBatchResults(thisIntegrator, numBatches, status)   ! (as after a loop of computeRadiativeTransfer calls: the last batch)
+  end subroutine computeRadiativeTransferBatches
+
+  subroutine selectBatchResults(thisIntegrator, batch, status)
+    type(integrator),   intent(inout) :: thisIntegrator
+    integer,            intent(in   ) :: batch
+    type(ErrorMessage), intent(inout) :: status
+    type(i3rc_tally_layout) :: layout
+    if(.not. associated(thisIntegrator%batchTallies)) then
+      call setStateToFailure(status, "selectBatchResults: no batches have been computed.")
+      return
+    end if
+    if(batch < 1 .or. batch > size(thisIntegrator%batchTallies, 2)) then
+      call setStateToFailure(status, "selectBatchResults: no such batch.")
+      return
+    end if
+    if(.not. deviceCall(thisIntegrator, i3rc_hip_get_tally_layout(thisIntegrator%device, layout), "selectBatchResults", status)) return
+    if(.not. unpackTallies(thisIntegrator, thisIntegrator%batchTallies(:, batch), layout, "selectBatchResults", status)) return
+    if(thisIntegrator%photonsProcessed > 0.d0) then
+      call setStateToCompleteSuccess(status, "computeRadiativeTransfer: finished with photons")
+    else
+      call setStateToFailure(status, "computeRadiativeTransfer: Didn't process any photons.")
+    end if
+  end subroutine selectBatchResults
 
   ! ------------------------------------------------------------------------------------------------
   ! Reporting
@@ -654,6 +738,7 @@ contains
     if(associated(thisIntegrator%volumeAbsorption))     deallocate(thisIntegrator%volumeAbsorption)
     if(associated(thisIntegrator%intensity))            deallocate(thisIntegrator%intensity)
     if(associated(thisIntegrator%intensityByComponent)) deallocate(thisIntegrator%intensityByComponent)
+    if(associated(thisIntegrator%batchTallies))         deallocate(thisIntegrator%batchTallies)
     thisIntegrator%readyToCompute = .false.; thisIntegrator%computeIntensity = .false.
     thisIntegrator%useSurfaceBDRF = .false.
   end subroutine finalize_Integrator

@@ -15,7 +15,8 @@ program i3rcDriver
   use opticalProperties,           only: domain, read_Domain, getInfo_Domain, finalize_Domain
   use monteCarloIllumination,      only: photonStream, new_PhotonStream, finalize_PhotonStream
   use monteCarloRadiativeTransfer, only: integrator, new_Integrator, specifyParameters, isReady_Integrator, &
-                                         finalize_Integrator, computeRadiativeTransfer, reportResults
+                                         finalize_Integrator, computeRadiativeTransfer, reportResults,           &
+                                         computeRadiativeTransferBatches, selectBatchResults
   use UserInterface,               only: printStatus, getOneArgument
   implicit none
 
@@ -45,6 +46,9 @@ program i3rcDriver
 
   character(len = 256) :: namelistFile
   integer :: nx, ny, nz, nDir, numProcs, thisProc, perProc, batch, firstBatch
+  integer :: inFlight, groupSize, groupStart, inGroup
+  real    :: tallyWords
+  character(len = 32) :: envText
   logical :: wantRadiance
   real    :: t0, t1, t2, cpuSetup
   integer :: nc, v, rc                       ! netCDF result file: file id, variable id, return code
@@ -123,26 +127,36 @@ program i3rcDriver
   numBatches = perProc * numProcs
   if(MasterProc) print *, "Doing ", perProc, " batches on each of ", numProcs, " processors."
   firstBatch = thisProc * perProc + 1
-  do batch = firstBatch, firstBatch + perProc - 1
-    randoms = new_RandomNumberSequence(seed = (/ iseed, batch /))
-    photons = new_PhotonStream(solarMu, solarAzimuth, numberOfPhotons = numPhotonsPerBatch, randomNumbers = randoms, &
-                               status = status)
+  ! The reference's loop -- per batch a sequence seeded (/ iseed, batch /), a photon stream, computeRadiativeTransfer,
+  ! reportResults (monteCarloDriver.f95:283-326) -- runs here as computeRadiativeTransferBatches over groups of batches:
+  ! the same photons batch by batch, but several batches share the GPU at a time, so that the long tail of one batch
+  ! (a few photons with a thousand scatterings) is covered by the next.  A group holds at most 64 batches and 256 MB of
+  ! raw tallies; I3RC_BATCHES_IN_FLIGHT=1 in the environment runs the batches one after the other.
+  inFlight = 0
+  call get_environment_variable("I3RC_BATCHES_IN_FLIGHT", envText, status = rc)
+  if(rc == 0 .and. len_trim(envText) > 0) read(envText, *, iostat = rc) inFlight
+  tallyWords = 3. * nx * ny + real(nx) * ny * nz + 2. * nDir * nx * ny
+  groupSize = max(1, min(64, int(256. * 1024. * 1024. / (8. * tallyWords))))
+  do groupStart = firstBatch, firstBatch + perProc - 1, groupSize
+    inGroup = min(groupSize, firstBatch + perProc - groupStart)
+    call computeRadiativeTransferBatches(mc, iseed, groupStart, inGroup, solarMu, solarAzimuth, numPhotonsPerBatch, status, &
+                                         batchesInFlight = inFlight)
     call printStatus(status)
-    call computeRadiativeTransfer(mc, randoms, photons, status)
-    call reportResults(mc, meanUp, meanDown, meanAbs, up, down, absorbed, profile, volume, status = status)
-    call accumulate0(mMeans(1, :), meanUp); call accumulate0(mMeans(2, :), meanDown); call accumulate0(mMeans(3, :), meanAbs)
-    mUp(:, :, 1)   = mUp(:, :, 1)   + up;       mUp(:, :, 2)   = mUp(:, :, 2)   + up**2
-    mDown(:, :, 1) = mDown(:, :, 1) + down;     mDown(:, :, 2) = mDown(:, :, 2) + down**2
-    mAbs(:, :, 1)  = mAbs(:, :, 1)  + absorbed; mAbs(:, :, 2)  = mAbs(:, :, 2)  + absorbed**2
-    mProfile(:, 1) = mProfile(:, 1) + profile;  mProfile(:, 2) = mProfile(:, 2) + profile**2
-    mVolume(:, :, :, 1) = mVolume(:, :, :, 1) + volume; mVolume(:, :, :, 2) = mVolume(:, :, :, 2) + volume**2
-    if(wantRadiance) then
-      call reportResults(mc, intensity = radiance, status = status)
-      mRad(:, :, :, 1) = mRad(:, :, :, 1) + radiance; mRad(:, :, :, 2) = mRad(:, :, :, 2) + radiance**2
-    end if
-    call finalize_PhotonStream(photons)
-    call finalize_RandomNumberSequence(randoms)
-    call printStatus(status)
+    do batch = 1, inGroup
+      call selectBatchResults(mc, batch, status)
+      call reportResults(mc, meanUp, meanDown, meanAbs, up, down, absorbed, profile, volume, status = status)
+      call accumulate0(mMeans(1, :), meanUp); call accumulate0(mMeans(2, :), meanDown); call accumulate0(mMeans(3, :), meanAbs)
+      mUp(:, :, 1)   = mUp(:, :, 1)   + up;       mUp(:, :, 2)   = mUp(:, :, 2)   + up**2
+      mDown(:, :, 1) = mDown(:, :, 1) + down;     mDown(:, :, 2) = mDown(:, :, 2) + down**2
+      mAbs(:, :, 1)  = mAbs(:, :, 1)  + absorbed; mAbs(:, :, 2)  = mAbs(:, :, 2)  + absorbed**2
+      mProfile(:, 1) = mProfile(:, 1) + profile;  mProfile(:, 2) = mProfile(:, 2) + profile**2
+      mVolume(:, :, :, 1) = mVolume(:, :, :, 1) + volume; mVolume(:, :, :, 2) = mVolume(:, :, :, 2) + volume**2
+      if(wantRadiance) then
+        call reportResults(mc, intensity = radiance, status = status)
+        mRad(:, :, :, 1) = mRad(:, :, :, 1) + radiance; mRad(:, :, :, 2) = mRad(:, :, :, 2) + radiance**2
+      end if
+      call printStatus(status)
+    end do
   end do
 
   ! -- gather over processes, then mean and standard error from the two moments

@@ -397,6 +397,22 @@ class Integrator:
         self.launch(randomNumbers, incomingPhotons)
         return self.finish()
 
+    def computeRadiativeTransferBatches(self, seed, numBatches, solarMu, solarAzimuth, numberOfPhotons, inFlight=0):
+        """A driver's batch loop (monteCarloDriver.f95:283-326) as one call of the C ABI (i3rc_hip_run_batches): batch k
+        is what computeRadiativeTransfer(new_RandomNumberSequence((seed[0], seed[1] + k)), new_PhotonStream(solarMu,
+        solarAzimuth, numberOfPhotons)) gives, but up to inFlight batches share the device, so that one batch's long
+        tail is covered by the next.  Returns the list of per-batch results (as finish() makes them)."""
+        if not self.isReady_Integrator():
+            raise I3RCError("computeRadiativeTransfer: problem not completely specified.")
+        self._ensure_tables()
+        lay = self.layout()
+        raw = np.zeros((int(numBatches), lay.total), np.float64)
+        s = B.Source()
+        s.kind, s.solarMu, s.solarAzimuth = 0, solarMu, solarAzimuth
+        self._check(self._lib.i3rc_hip_run_batches(self._h, int(seed[0]), int(seed[1]), int(numBatches), int(numberOfPhotons),
+                                                   C.byref(s), int(inFlight), raw.ctypes.data_as(B.dp)), "computeRadiativeTransfer")
+        return [self.finish(raw[k]) for k in range(int(numBatches))]
+
     def kernel_ms(self):
         ms = C.c_float(0)
         self._check(self._lib.i3rc_hip_last_kernel_ms(self._h, C.byref(ms)), "kernel_ms")

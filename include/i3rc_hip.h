@@ -152,6 +152,23 @@ int i3rc_hip_zero_tallies(i3rc_hip_integrator *h);
 int i3rc_hip_launch_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int64_t firstPhoton,
                           int64_t nPhotons, const i3rc_source *src);
 
+/* The batch loop of a driver as ONE call (Example-Drivers/monteCarloDriver.f95:283-326: per batch a random-number
+ * sequence seeded (/iseed, batch/), a photon stream of numPhotonsPerBatch photons, computeRadiativeTransfer,
+ * reportResults).  Batch k = 0 .. nBatches-1 is traced with the key (seed0, seed1 + k) into a tally buffer of its own;
+ * its raw tallies (layout of i3rc_hip_get_tally_layout, float64; normalise them with i3rc_hip_normalise) are written
+ * to hostTallies + k * layout.total.  Every batch equals i3rc_hip_zero_tallies + i3rc_hip_launch_batch(seed0,
+ * seed1 + k, 0, nPhotons) + i3rc_hip_fetch_tallies, photon for photon.
+ * Up to inFlight batches (1..8; 0 = 6) are on the device at a time, each on a HIP stream of its own: a batch ends with
+ * a long tail -- the few photons of a million that scatter a thousand times keep a handful of wavefronts busy for a
+ * millisecond -- and the next batch's photons fill the machine meanwhile.  At the reference drivers' batch sizes
+ * (1e5 ... 1e6 photons) that is 2-3 times the throughput of one call per batch.  (Streams share
+ * GPU_MAX_HW_QUEUES hardware queues, default 4: with GPU_MAX_HW_QUEUES=8 in the environment of the process the gain is
+ * another 10-15 %.)
+ * Directional sources only (an explicit stream differs from batch to batch).  Synchronous: returns when all batches
+ * are in hostTallies; the handle's own tally buffer and stream are not touched. */
+int i3rc_hip_run_batches(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int nBatches, int64_t nPhotons,
+                         const i3rc_source *src, int inFlight, double *hostTallies);
+
 /* Test hook: same kernel, but every uniform deviate is read from `randoms` (float32, e.g. the reference's
  * MT19937 stream): photon i consumes randoms[drawStart[i]], randoms[drawStart[i]+1], ... in the reference's
  * draw order.  Optional per-photon outputs (host arrays of n, may be NULL):

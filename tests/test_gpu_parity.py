@@ -520,3 +520,33 @@ def test_kernels_agree_on_random_regular_domains():
         # oracle too: the start height z0 + (1 - spacing(1)) (zMax - z0) rounds to zMax itself there; reference behaviour)
         dropped_all += c["dropped"] == n
     assert dropped_all == 2
+
+
+def test_pipelined_batches_equal_one_call_per_batch():
+    """i3rc_hip_run_batches (several batches on the device at a time, each on a stream and in a tally buffer of its own)
+    gives every batch exactly what zero + launch + fetch gives it: same photons (integer work counters), same tallies up
+    to the order of the float64 additions -- for a flux run with LDS tallies and for a radiance run with a surface."""
+    for d, params, mu0 in ((cases.step_cloud(ssa=0.99), dict(surfaceAlbedo=0.1), 0.7),
+                           (cases.step_cloud(ssa=1.0, nlayers=8), dict(intensityMus=[1.0, 0.4], intensityPhis=[0.0, 80.0],
+                                                                       useRussianRouletteForIntensity=True, zetaMin=0.3, surfaceAlbedo=0.3), 0.8)):
+        g = make_gpu(d, hg_table(), **params)
+        n, nb = 20000, 7
+        one = [g.computeRadiativeTransfer(M.new_RandomNumberSequence((5, 3 + b)), M.new_PhotonStream(mu0, 25.0, n)) for b in range(nb)]
+        before = g.fetch().copy()                                   # the handle's own tallies: the last of those calls
+        for in_flight in (1, 3, 8):
+            many = g.computeRadiativeTransferBatches((5, 3), nb, mu0, 25.0, n, inFlight=in_flight)
+            assert len(many) == nb
+            for a, b in zip(one, many):
+                assert a["counters"] == b["counters"]
+                assert np.allclose(a["raw"], b["raw"], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(g.fetch(), before)                   # ... which the pipelined call leaves alone
+        g.finalize_Integrator()
+    # errors: explicit streams are refused
+    from i3rc_monte_carlo_model_amd import binding as B
+    import ctypes as C
+    g = make_gpu(cases.step_cloud(), hg_table())
+    g._ensure_tables()
+    s = B.Source(); s.kind = 1
+    out = np.zeros(g.layout().total, np.float64)
+    assert B.load().i3rc_hip_run_batches(g._h, 1, 2, 1, 100, C.byref(s), 0, out.ctypes.data_as(B.dp)) != 0
+    assert b"Directional" in B.load().i3rc_hip_last_error(g._h)
