@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'.')
+import os, sys; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import numpy as np
 import i3rc_monte_carlo_model_amd as M
 from oracle import pyoracle as O

@@ -7,7 +7,7 @@ configuration: energy conservation of the tallies, finite radiances, and identic
 second schedule.  usage: fuzz.py [first seed] [count]"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch  # noqa: F401
 import i3rc_monte_carlo_model_amd as M
 from tests import cases
@@ -16,7 +16,7 @@ from tests.test_gpu_parity import hg_table, make_gpu
 if os.environ.get('I3RC_LIB'):   # another build of the library
     M.build.LIB = os.path.abspath(os.environ['I3RC_LIB']); M.build.needs_build = lambda: False
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 1), (int(sys.argv[2]) if len(sys.argv) > 2 else 200)
-log = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "fuzz.log"), "a")
+log = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "gpurun_out", "fuzz.log"), "a")
 def note(*a):
     print(*a, file=log, flush=True); os.fsync(log.fileno())
 

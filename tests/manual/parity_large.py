@@ -3,7 +3,7 @@ oracle on all host cores, the oracle's sample produced by a child program while 
 workload, the domain means with their standard errors, the z score of every difference (GPU - oracle, in units of the
 combined standard error), the share of columns within 3 sigma and the largest column |z|.  The tests do the same at
 1e6-2e6 photons (tests/test_gpu_baseline_configs.py); this is the long version, run by hand on the GPU box:
-    python tools/parity_large.py [workload ...] > gpurun_out/parity_large.txt
+    python tests/manual/parity_large.py [workload ...] > gpurun_out/parity_large.txt
 (test infrastructure: the only place the oracle is used is as the checker.)"""
 import os
 import subprocess
@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tools import workloads as W  # noqa: E402
 

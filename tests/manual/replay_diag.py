@@ -5,7 +5,7 @@ per launch only one lane of the chip works: a disagreement that needs several ph
 between lanes (this is how the miscompiled grid-place flag was found; see tracer.hpp, GridPlace)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch  # noqa: F401  (first: one HIP runtime per process, see tests/conftest.py)
 import i3rc_monte_carlo_model_amd as M
 from oracle import pyoracle as O

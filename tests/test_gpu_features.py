@@ -430,16 +430,16 @@ def test_max_cross_section_in_an_empty_domain_is_ray_tracing(oracle):
 
 
 def test_fuzz_random_configurations_in_a_process_of_their_own():
-    # tools/fuzz.py: random domains, parameters and sources with fresh device memory poisoned; no fault, no hang, the
+    # tests/manual/fuzz.py: random domains, parameters and sources with fresh device memory poisoned; no fault, no hang, the
     # same integer work counters under a second schedule, domain-mean fluxes equal to the oracle's within 5 sigma
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "1", "120"], capture_output=True, text=True, timeout=240,
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "manual", "fuzz.py"), "1", "120"], capture_output=True, text=True, timeout=240,
                        env=dict(os.environ, I3RC_POISON="1", ORACLE="1"))
     assert r.returncode == 0 and "fuzz done 1 120 problems 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     # the same kind of configurations through the replay build against the oracle, photon by photon
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "2000", "100"], capture_output=True, text=True, timeout=240,
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "manual", "fuzz.py"), "2000", "100"], capture_output=True, text=True, timeout=240,
                        env=dict(os.environ, I3RC_POISON="1", REPLAY="1"))
     assert r.returncode == 0 and "fuzz done 2000 100 problems 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
