@@ -87,6 +87,15 @@ struct i3rc_hip_integrator {
   static constexpr int kMaxInFlight = 8;
   PipeSlot pipe[kMaxInFlight];
   int64_t pipeTotal = 0;       // layout.total the slots were sized for
+  // i3rc_hip_compute_batch: batches launched ahead of the caller's loop (oldest first, in slots of the same pool), all
+  // with the signature below
+  struct Ahead { uint32_t seed1; int slot; };
+  std::vector<Ahead> aheadQueue;
+  struct BatchSignature {
+    uint32_t seed0 = 0; int64_t n = 0; float mu = 0.f, az = 0.f; bool set = false;
+    bool operator==(const BatchSignature &o) const { return set && o.set && seed0 == o.seed0 && n == o.n && mu == o.mu && az == o.az; }
+  } aheadSig, lastSig;
+  uint32_t lastSeed1 = 0;
 
   hipStream_t ownStream = nullptr, stream = nullptr;
   static constexpr int kEventRing = 64;   // HIP-event pairs of the most recent timed launches
@@ -141,6 +150,41 @@ static int realloc_tally(i3rc_hip_integrator *h) {
   HIPCHK(h, h->ownTally.alloc((size_t)h->layout.total * sizeof(double)));
   HIPCHK(h, hipMemset(h->ownTally.p, 0, (size_t)h->layout.total * sizeof(double)));
   h->tally = (double *)h->ownTally.p;
+  return 0;
+}
+
+// Batches launched ahead by i3rc_hip_compute_batch read the handle's device arrays: whatever changes those (tables,
+// parameters, surface, directions, tuning) waits for them first and forgets them.
+static void drop_lookahead(i3rc_hip_integrator *h) {
+  for (const auto &a : h->aheadQueue) {
+    (void)hipStreamSynchronize(h->pipe[a.slot].stream);
+    h->pipe[a.slot].batch = -1;
+  }
+  h->aheadQueue.clear();
+  h->aheadSig.set = false; h->lastSig.set = false;
+}
+
+// The slots of i3rc_hip_run_batches / i3rc_hip_compute_batch are kept with the handle (streams and pinned memory are
+// expensive to make); a new tally layout invalidates their buffers.
+static int reset_slots_if_layout_changed(i3rc_hip_integrator *h) {
+  if (h->pipeTotal == h->layout.total) return 0;
+  drop_lookahead(h);
+  for (auto &sl : h->pipe) {
+    if (sl.stream) HIPCHK(h, hipStreamSynchronize(sl.stream));
+    if (sl.pinned) { HIPCHK(h, hipHostFree(sl.pinned)); sl.pinned = nullptr; }
+    sl.batch = -1;
+  }
+  h->pipeTotal = h->layout.total;
+  return 0;
+}
+static int ready_slot(i3rc_hip_integrator *h, int k) {
+  auto &sl = h->pipe[k];
+  const size_t bytes = (size_t)h->layout.total * sizeof(double);
+  if (!sl.stream) HIPCHK(h, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+  if (!sl.done) HIPCHK(h, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  if (!sl.counter.p) HIPCHK(h, sl.counter.alloc(sizeof(unsigned long long)));
+  if (!sl.pinned) HIPCHK(h, hipHostMalloc((void **)&sl.pinned, bytes, hipHostMallocDefault));
+  if (sl.tally.bytes != bytes) HIPCHK(h, sl.tally.alloc(bytes));
   return 0;
 }
 
@@ -307,6 +351,7 @@ int i3rc_hip_destroy(i3rc_hip_integrator *h) {
 
 int i3rc_hip_set_inverse_table(i3rc_hip_integrator *h, int comp, int nSteps, int nEntries, const float *t) {
   if (!h) return 1;
+  drop_lookahead(h);
   if (comp < 1 || comp > h->ncomp) return h->fail("i3rc_hip_set_inverse_table: component out of range");
   if (nSteps < 2 || nEntries < 1 || !t) return h->fail("i3rc_hip_set_inverse_table: bad table");
   if (nEntries < h->maxPfIndex[comp - 1]) return h->fail("i3rc_hip_set_inverse_table: phaseFunctionIndex refers to a missing table entry");
@@ -326,6 +371,7 @@ int i3rc_hip_set_inverse_table(i3rc_hip_integrator *h, int comp, int nSteps, int
 
 int i3rc_hip_set_forward_tables(i3rc_hip_integrator *h, int comp, int nSteps, int nEntries, const float *hybrid, const float *orig) {
   if (!h) return 1;
+  drop_lookahead(h);
   if (comp < 1 || comp > h->ncomp) return h->fail("i3rc_hip_set_forward_tables: component out of range");
   if (nSteps < 2 || nEntries < 1 || !hybrid) return h->fail("i3rc_hip_set_forward_tables: bad table");
   if (nEntries < h->maxPfIndex[comp - 1]) return h->fail("i3rc_hip_set_forward_tables: phaseFunctionIndex refers to a missing table entry");
@@ -343,6 +389,7 @@ int i3rc_hip_set_forward_tables(i3rc_hip_integrator *h, int comp, int nSteps, in
 
 int i3rc_hip_set_params(i3rc_hip_integrator *h, const i3rc_params *p) {
   if (!h) return 1;
+  drop_lookahead(h);
   if (!p) return h->fail("i3rc_hip_set_params: null params");
   if (!p->useSurfaceBDRF && (p->surfaceAlbedo > 1.f || p->surfaceAlbedo < 0.f))
     return h->fail("specifyParameters: surface albedo out of range.");  // :878-879
@@ -354,6 +401,7 @@ int i3rc_hip_set_params(i3rc_hip_integrator *h, const i3rc_params *p) {
 
 int i3rc_hip_set_surface(i3rc_hip_integrator *h, int nxs, int nys, const float *xs, const float *ys, const float *brdf) {
   if (!h) return 1;
+  drop_lookahead(h);
   if (nxs < 1 || nys < 1 || !xs || !ys || !brdf) return h->fail("i3rc_hip_set_surface: bad surface grid");
   for (int i = 0; i < nxs; ++i) if (!(xs[i + 1] > xs[i])) return h->fail("new_SurfaceDescription: positions must be unique, increasing.");
   for (int i = 0; i < nys; ++i) if (!(ys[i + 1] > ys[i])) return h->fail("new_SurfaceDescription: positions must be unique, increasing.");
@@ -370,6 +418,7 @@ int i3rc_hip_set_surface(i3rc_hip_integrator *h, int nxs, int nys, const float *
 
 int i3rc_hip_set_directions(i3rc_hip_integrator *h, int nDir, const float *dirCos) {
   if (!h) return 1;
+  drop_lookahead(h);
   if (nDir < 0 || nDir > I3RC_MAX_DIRECTIONS) return h->fail("i3rc_hip_set_directions: 0 <= nDir <= 20 required");
   if (nDir > 0 && !dirCos) return h->fail("i3rc_hip_set_directions: null directions");
   for (int d = 0; d < nDir; ++d)
@@ -427,6 +476,7 @@ int i3rc_hip_zero_tallies(i3rc_hip_integrator *h) {
 /* Tunables for experiments (not part of the reference API): event-phase ballot threshold, blocks per CU. */
 int i3rc_hip_set_tuning(i3rc_hip_integrator *h, int evThreshold, int blocksPerCU) {
   if (!h) return 1;
+  drop_lookahead(h);
   if (evThreshold >= 0 && evThreshold <= 64) h->evThreshold = evThreshold;   // 0 = default
   if (blocksPerCU >= 0 && blocksPerCU <= 8) h->blocksPerCU = blocksPerCU;
   return 0;
@@ -434,6 +484,7 @@ int i3rc_hip_set_tuning(i3rc_hip_integrator *h, int evThreshold, int blocksPerCU
 
 int i3rc_hip_set_light_threshold(i3rc_hip_integrator *h, int lanes) {
   if (!h) return 1;
+  drop_lookahead(h);
   if (lanes < 0 || lanes > 64) return h->fail("i3rc_hip_set_light_threshold: need 1..64 lanes (0 = default)");
   h->lightThreshold = lanes;
   return 0;
@@ -441,6 +492,7 @@ int i3rc_hip_set_light_threshold(i3rc_hip_integrator *h, int lanes) {
 
 int i3rc_hip_set_launch_limit(i3rc_hip_integrator *h, int64_t photons) {
   if (!h) return 1;
+  drop_lookahead(h);
   if (photons < 0) return h->fail("i3rc_hip_set_launch_limit: negative limit");
   h->launchLimit = photons;
   return 0;
@@ -448,6 +500,7 @@ int i3rc_hip_set_launch_limit(i3rc_hip_integrator *h, int64_t photons) {
 
 int i3rc_hip_select_kernel(i3rc_hip_integrator *h, int variant) {
   if (!h) return 1;
+  drop_lookahead(h);
   if (variant < I3RC_KERNEL_AUTO || variant > I3RC_KERNEL_LANE) return h->fail("i3rc_hip_select_kernel: unknown variant");
   h->kernelVariant = variant;
   return 0;
@@ -704,19 +757,12 @@ int i3rc_hip_run_batches(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1,
   HIPCHK(h, hipSetDevice(h->device));
   const int K = std::min(nBatches, inFlight <= 0 ? 6 : std::min(inFlight, (int)i3rc_hip_integrator::kMaxInFlight));
   const size_t bytes = (size_t)h->layout.total * sizeof(double);
-  for (int k = 0; k < K; ++k) {   // slots are kept with the handle: pinned memory and streams are expensive to make
-    auto &sl = h->pipe[k];
-    if (!sl.stream) HIPCHK(h, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
-    if (!sl.done) HIPCHK(h, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-    if (!sl.counter.p) HIPCHK(h, sl.counter.alloc(sizeof(unsigned long long)));
-    if (!sl.pinned || !sl.tally.p || h->pipeTotal != h->layout.total) {
-      if (sl.pinned) { HIPCHK(h, hipHostFree(sl.pinned)); sl.pinned = nullptr; }
-      HIPCHK(h, hipHostMalloc((void **)&sl.pinned, bytes, hipHostMallocDefault));
-      HIPCHK(h, sl.tally.alloc(bytes));
-    }
-    sl.batch = -1;
+  drop_lookahead(h);               // (i3rc_hip_compute_batch shares the slots)
+  if (reset_slots_if_layout_changed(h)) return 1;
+  for (int k = 0; k < K; ++k) {
+    if (ready_slot(h, k)) return 1;
+    h->pipe[k].batch = -1;
   }
-  h->pipeTotal = h->layout.total;
   HIPCHK(h, hipStreamSynchronize(h->stream));   // whatever the caller had in flight on the handle's stream comes first
   hipStream_t const callerStream = h->stream;
   double *const callerTally = h->tally;
@@ -758,6 +804,82 @@ int i3rc_hip_run_batches(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1,
   }
   h->stream = callerStream; h->tally = callerTally;
   return rc;
+}
+
+// computeRadiativeTransfer for one batch of a driver's loop, looking ahead: see include/i3rc_hip.h
+int i3rc_hip_compute_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int64_t nPhotons, const i3rc_source *src,
+                           int lookAhead, double *hostTallies) {
+  if (!h) return 1;
+  if (!src || !hostTallies) return h->fail("i3rc_hip_compute_batch: bad arguments");
+  if (src->kind != 0) return h->fail("i3rc_hip_compute_batch: Directional photon streams only");
+  if (nPhotons <= 0) return h->fail("setIllumination: must ask for non-negative number of photons.");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int depth = std::max(0, std::min(lookAhead, (int)i3rc_hip_integrator::kMaxInFlight - 1));
+  const size_t bytes = (size_t)h->layout.total * sizeof(double);
+  if (reset_slots_if_layout_changed(h)) return 1;   // (a change of the layout has dropped the queue already: set_directions)
+  auto free_slot = [&]() -> int {
+    for (int k = 0; k < i3rc_hip_integrator::kMaxInFlight; ++k) if (h->pipe[k].batch < 0) return k;
+    return -1;
+  };
+  hipStream_t const callerStream = h->stream;
+  double *const callerTally = h->tally;
+  auto start = [&](int k, uint32_t s1) -> int {   // zero, trace, copy back: asynchronous on the slot's stream
+    if (ready_slot(h, k)) return 1;
+    auto &sl = h->pipe[k];
+    h->stream = sl.stream; h->tally = (double *)sl.tally.p;
+    int rc = 0;
+    LaunchPlan plan;
+    RunArgs A;
+    std::memset(&A, 0, sizeof(A));
+    A.seed0 = seed0; A.seed1 = s1; A.firstPhoton = 0; A.nPhotons = nPhotons;
+    A.workCounter = (unsigned long long *)sl.counter.p;
+    rc = make_problem(h, plan) || upload_source(h, src, nPhotons, A);
+    if (!rc && hipMemsetAsync(sl.tally.p, 0, bytes, sl.stream) != hipSuccess) rc = h->fail("i3rc_hip_compute_batch: clearing a tally buffer failed");
+    const int64_t perLaunch = h->launchLimit > 0 ? h->launchLimit : (int64_t)h->numCU << 22;
+    for (int64_t done = 0; done < nPhotons && !rc; done += perLaunch) {
+      RunArgs part = A;
+      part.firstPhoton = done;
+      part.nPhotons = std::min(perLaunch, nPhotons - done);
+      rc = launch<PhiloxStream>(h, plan, part, true);
+    }
+    if (!rc && (hipMemcpyAsync(sl.pinned, sl.tally.p, bytes, hipMemcpyDeviceToHost, sl.stream) != hipSuccess ||
+                hipEventRecord(sl.done, sl.stream) != hipSuccess))
+      rc = h->fail("i3rc_hip_compute_batch: copying a batch's tallies back failed");
+    h->stream = callerStream; h->tally = callerTally;
+    if (!rc) sl.batch = (int)s1;
+    return rc;
+  };
+  i3rc_hip_integrator::BatchSignature sig;
+  sig.seed0 = seed0; sig.n = nPhotons; sig.mu = src->solarMu; sig.az = src->solarAzimuth; sig.set = true;
+  // batches launched ahead serve this call only if the next of them is exactly this batch
+  if (!h->aheadQueue.empty() && !(h->aheadSig == sig && h->aheadQueue.front().seed1 == seed1)) drop_lookahead(h);
+  int mine;
+  if (!h->aheadQueue.empty()) {
+    mine = h->aheadQueue.front().slot;
+    h->aheadQueue.erase(h->aheadQueue.begin());
+  } else {
+    mine = free_slot();
+    if (mine < 0) return h->fail("i3rc_hip_compute_batch: no free slot");
+    if (start(mine, seed1)) { drop_lookahead(h); return 1; }
+  }
+  h->pipe[mine].batch = (int)seed1;   // (in use until its tallies have been handed over)
+  // look ahead once the caller's loop shows: the same batch as last time with the next seed word (monteCarloDriver.f95:277)
+  const bool inLoop = h->lastSig == sig && h->lastSeed1 + 1u == seed1;
+  h->lastSig = sig; h->lastSeed1 = seed1;
+  if (depth > 0 && (inLoop || !h->aheadQueue.empty())) {
+    h->aheadSig = sig;
+    while ((int)h->aheadQueue.size() < depth) {
+      const uint32_t next = (h->aheadQueue.empty() ? seed1 : h->aheadQueue.back().seed1) + 1u;
+      const int k = free_slot();
+      if (k < 0 || start(k, next)) break;   // (a failed look-ahead is not this batch's failure: the error text stays for the next call)
+      h->aheadQueue.push_back({next, k});
+    }
+  }
+  auto &sl = h->pipe[mine];
+  if (hipEventSynchronize(sl.done) != hipSuccess) { drop_lookahead(h); sl.batch = -1; return h->fail("i3rc_hip_compute_batch: waiting for the batch failed"); }
+  std::memcpy(hostTallies, sl.pinned, bytes);
+  sl.batch = -1;
+  return 0;
 }
 
 int i3rc_hip_run_replay(i3rc_hip_integrator *h, int64_t nPhotons, const i3rc_source *src, const float *randoms,

@@ -106,6 +106,17 @@ module i3rcHipInterface
       type(i3rc_source), intent(in) :: src
       integer(c_int)                :: rc
     end function
+    function i3rc_hip_compute_batch(h, seed0, seed1, nPhotons, src, lookAhead, hostTallies) &
+             bind(C, name = "i3rc_hip_compute_batch") result(rc)
+      import
+      type(c_ptr), value            :: h
+      integer(c_int32_t), value     :: seed0, seed1
+      integer(c_int64_t), value     :: nPhotons
+      type(i3rc_source), intent(in) :: src
+      integer(c_int), value         :: lookAhead            ! batches (seed1 + 1, ...) launched behind this one once a loop shows
+      real(c_double), intent(out)   :: hostTallies(*)       ! layout%total
+      integer(c_int)                :: rc
+    end function
     function i3rc_hip_run_batches(h, seed0, seed1, nBatches, nPhotons, src, inFlight, hostTallies) &
              bind(C, name = "i3rc_hip_run_batches") result(rc)
       import

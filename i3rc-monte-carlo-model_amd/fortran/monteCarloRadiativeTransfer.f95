@@ -475,14 +475,25 @@ contains
     call getSeedWords(randomNumbers, seed0, seed1)
     call reservePhotonStreams(randomNumbers, remaining, firstPhoton)   ! (a sequence used again goes on with fresh photon streams)
 
-    ! tallies are overwritten, not accumulated, on every call (reference :296-309)
-    if(.not. deviceCall(thisIntegrator, i3rc_hip_zero_tallies(thisIntegrator%device), "computeRadiativeTransfer", status)) return
-    if(.not. deviceCall(thisIntegrator, i3rc_hip_launch_batch(thisIntegrator%device, int(seed0, c_int32_t), int(seed1, c_int32_t), &
-                        int(firstPhoton, c_int64_t), int(remaining, c_int64_t), source), "computeRadiativeTransfer", status)) return
     if(.not. deviceCall(thisIntegrator, i3rc_hip_get_tally_layout(thisIntegrator%device, layout), &
                         "computeRadiativeTransfer", status)) return
     allocate(raw(layout%total))
-    if(.not. deviceCall(thisIntegrator, i3rc_hip_fetch_tallies(thisIntegrator%device, raw), "computeRadiativeTransfer", status)) return
+    if(lazy .and. firstPhoton == 0) then
+      ! A Directional batch of a fresh sequence -- what a driver's batch loop asks for, once per batch, with
+      ! seed = (/iseed, batch/) (monteCarloDriver.f95:277-297).  A call cannot return before the batch's last photon has,
+      ! and the last photons of a batch are the few with a thousand scatterings: the library looks ahead -- once two
+      ! calls in a row show the loop it traces the following batches behind this one (i3rc_hip_compute_batch), so that
+      ! the next call finds its batch under way or done.  I3RC_LOOK_AHEAD = 0 ... 7 in the environment (default 3).
+      if(.not. deviceCall(thisIntegrator, i3rc_hip_compute_batch(thisIntegrator%device, int(seed0, c_int32_t),            &
+                          int(seed1, c_int32_t), int(remaining, c_int64_t), source, int(lookAheadDepth(remaining), c_int), &
+                          raw), "computeRadiativeTransfer", status)) return
+    else
+      ! tallies are overwritten, not accumulated, on every call (reference :296-309)
+      if(.not. deviceCall(thisIntegrator, i3rc_hip_zero_tallies(thisIntegrator%device), "computeRadiativeTransfer", status)) return
+      if(.not. deviceCall(thisIntegrator, i3rc_hip_launch_batch(thisIntegrator%device, int(seed0, c_int32_t), int(seed1, c_int32_t), &
+                          int(firstPhoton, c_int64_t), int(remaining, c_int64_t), source), "computeRadiativeTransfer", status)) return
+      if(.not. deviceCall(thisIntegrator, i3rc_hip_fetch_tallies(thisIntegrator%device, raw), "computeRadiativeTransfer", status)) return
+    end if
     if(.not. unpackTallies(thisIntegrator, raw, layout, "computeRadiativeTransfer", status)) return
     deallocate(raw)
     if(allocated(sx)) deallocate(sx, sy, sz, smu, sphi)
@@ -496,6 +507,22 @@ contains
       call setStateToFailure(status, "computeRadiativeTransfer: Didn't process any photons.")
     end if
   end subroutine computeRadiativeTransfer
+
+  ! batches to trace ahead of a driver's loop: none for batches so long that their tail does not matter
+  integer function lookAheadDepth(numberOfPhotons)
+    integer, intent(in) :: numberOfPhotons
+    integer, save :: depth = -1
+    character(len = 16) :: text
+    integer :: rc
+    if(depth < 0) then
+      depth = 3
+      call get_environment_variable("I3RC_LOOK_AHEAD", text, status = rc)
+      if(rc == 0 .and. len_trim(text) > 0) read(text, *, iostat = rc) depth
+      depth = max(0, min(7, depth))
+    end if
+    lookAheadDepth = depth
+    if(numberOfPhotons > 20000000) lookAheadDepth = 0
+  end function lookAheadDepth
 
   ! raw float64 tallies of one batch -> the normalised results reportResults hands out (:353-395)
   function unpackTallies(thisIntegrator, raw, layout, caller, status) result(ok)

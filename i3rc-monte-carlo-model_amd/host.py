@@ -397,6 +397,25 @@ class Integrator:
         self.launch(randomNumbers, incomingPhotons)
         return self.finish()
 
+    def computeRadiativeTransferLookingAhead(self, randomNumbers, incomingPhotons, lookAhead=3):
+        """computeRadiativeTransfer through i3rc_hip_compute_batch: one batch of a driver's loop, with the following batches
+        launched ahead once the loop shows (same batch, next seed word).  Directional streams of a fresh sequence only."""
+        if not self.isReady_Integrator():
+            raise I3RCError("computeRadiativeTransfer: problem not completely specified.")
+        if incomingPhotons.kind != 0 or randomNumbers.photonsDrawn != 0:
+            return self.computeRadiativeTransfer(randomNumbers, incomingPhotons)
+        if not incomingPhotons.morePhotonsExist():
+            raise I3RCError("computeRadiativeTransfer: Didn't process any photons.")
+        self._ensure_tables()
+        raw = np.zeros(self.layout().total, np.float64)
+        s = B.Source()
+        s.kind, s.solarMu, s.solarAzimuth = 0, incomingPhotons.solarMu, incomingPhotons.solarAzimuth
+        self._check(self._lib.i3rc_hip_compute_batch(self._h, randomNumbers.seed[0], randomNumbers.seed[1], incomingPhotons.n,
+                                                     C.byref(s), int(lookAhead), raw.ctypes.data_as(B.dp)), "computeRadiativeTransfer")
+        randomNumbers.photonsDrawn += incomingPhotons.n
+        incomingPhotons.currentPhoton = incomingPhotons.n + 1
+        return self.finish(raw)
+
     def computeRadiativeTransferBatches(self, seed, numBatches, solarMu, solarAzimuth, numberOfPhotons, inFlight=0):
         """A driver's batch loop (monteCarloDriver.f95:283-326) as one call of the C ABI (i3rc_hip_run_batches): batch k
         is what computeRadiativeTransfer(new_RandomNumberSequence((seed[0], seed[1] + k)), new_PhotonStream(solarMu,

@@ -550,3 +550,39 @@ def test_pipelined_batches_equal_one_call_per_batch():
     out = np.zeros(g.layout().total, np.float64)
     assert B.load().i3rc_hip_run_batches(g._h, 1, 2, 1, 100, C.byref(s), 0, out.ctypes.data_as(B.dp)) != 0
     assert b"Directional" in B.load().i3rc_hip_last_error(g._h)
+
+
+def test_looking_ahead_never_changes_a_batch():
+    """i3rc_hip_compute_batch launches the following batches of a driver's loop ahead of the caller: whatever the caller does
+    next -- goes on with the loop, jumps to another seed, changes the photon count, the sun, a parameter, the directions --
+    every batch equals the plain zero + launch + fetch of the same batch (same photons, tallies up to summation order)."""
+    d = cases.step_cloud(ssa=0.99, nlayers=8)
+    params = dict(intensityMus=[1.0, 0.4], intensityPhis=[0.0, 80.0], useRussianRouletteForIntensity=True, zetaMin=0.3, surfaceAlbedo=0.3)
+    plain, ahead = make_gpu(d, hg_table(), **params), make_gpu(d, hg_table(), **params)
+
+    def both(seed, n, mu0=0.8, az=25.0, look=3):
+        a = plain.computeRadiativeTransfer(M.new_RandomNumberSequence(seed), M.new_PhotonStream(mu0, az, n))
+        b = ahead.computeRadiativeTransferLookingAhead(M.new_RandomNumberSequence(seed), M.new_PhotonStream(mu0, az, n), lookAhead=look)
+        assert a["counters"] == b["counters"], (seed, n)
+        assert np.allclose(a["raw"], b["raw"], rtol=1e-5, atol=1e-6)
+
+    both((7, 0), 1)                                     # the drivers' one-photon warm-up
+    for b in range(1, 9):
+        both((7, b), 20000)                             # the loop: from the second batch on the next ones are under way
+    both((7, 20), 20000)                                # a jump: the batches launched ahead are discarded
+    both((7, 21), 20000); both((7, 22), 20000)
+    both((7, 23), 5000)                                 # another photon count
+    both((7, 24), 5000); both((7, 25), 5000, mu0=0.6)   # another sun in mid-loop
+    both((7, 26), 5000, mu0=0.6); both((7, 27), 5000, mu0=0.6)
+    for g in (plain, ahead):                            # a parameter changes while batches are under way
+        g.specifyParameters(surfaceAlbedo=0.6)
+    both((7, 28), 5000, mu0=0.6); both((7, 29), 5000, mu0=0.6); both((7, 30), 5000, mu0=0.6)
+    for g in (plain, ahead):                            # ... and the directions (another tally layout)
+        g.specifyParameters(intensityMus=[0.9], intensityPhis=[10.0])
+    both((7, 31), 5000, mu0=0.6); both((7, 32), 5000, mu0=0.6); both((7, 33), 5000, mu0=0.6, look=7)
+    both((8, 34), 5000, mu0=0.6, look=0); both((8, 35), 5000, mu0=0.6, look=0)
+    # the plain path on the same handle is not disturbed by batches launched ahead
+    r = ahead.computeRadiativeTransfer(M.new_RandomNumberSequence((8, 35)), M.new_PhotonStream(0.6, 25.0, 5000))
+    q = plain.computeRadiativeTransfer(M.new_RandomNumberSequence((8, 35)), M.new_PhotonStream(0.6, 25.0, 5000))
+    assert r["counters"] == q["counters"]
+    plain.finalize_Integrator(); ahead.finalize_Integrator()
