@@ -846,7 +846,7 @@ int i3rc_hip_compute_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed
                 hipEventRecord(sl.done, sl.stream) != hipSuccess))
       rc = h->fail("i3rc_hip_compute_batch: copying a batch's tallies back failed");
     h->stream = callerStream; h->tally = callerTally;
-    if (!rc) sl.batch = (int)s1;
+    if (!rc) sl.batch = 0;   // in use (any value >= 0; i3rc_hip_run_batches keeps a batch number here)
     return rc;
   };
   i3rc_hip_integrator::BatchSignature sig;
@@ -862,7 +862,7 @@ int i3rc_hip_compute_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed
     if (mine < 0) return h->fail("i3rc_hip_compute_batch: no free slot");
     if (start(mine, seed1)) { drop_lookahead(h); return 1; }
   }
-  h->pipe[mine].batch = (int)seed1;   // (in use until its tallies have been handed over)
+  h->pipe[mine].batch = 0;   // (in use until its tallies have been handed over)
   // look ahead once the caller's loop shows: the same batch as last time with the next seed word (monteCarloDriver.f95:277)
   const bool inLoop = h->lastSig == sig && h->lastSeed1 + 1u == seed1;
   h->lastSig = sig; h->lastSeed1 = seed1;
