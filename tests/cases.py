@@ -126,6 +126,17 @@ def landsat_cloud(ssa=1.0, nlayers=119):
     return dict(xe=xe, ye=ye, ze=ze, ext=np.ascontiguousarray(ext), ssa=s, pf=pf)
 
 
+def landsat_tiled(tiles=2, ssa=1.0):
+    """The Landsat scene repeated tiles x tiles times in x and y (256 x 256 x 119 = 31 MB of extinction for tiles = 2): a
+    field well beyond the 4 MB of an XCD's L2, the size of a production LES cloud field.  Periodic boundaries make every
+    tile's photons statistically those of the single scene: fluxes and radiances have the single scene's means."""
+    d = landsat_cloud(ssa=ssa)
+    nx, ny = d["ext"].shape[2], d["ext"].shape[1]
+    rep = lambda a: np.ascontiguousarray(np.tile(a, (1, tiles, tiles)))
+    return dict(xe=f32(30.0) * np.arange(0, nx * tiles + 1, dtype=np.float32), ye=f32(30.0) * np.arange(0, ny * tiles + 1, dtype=np.float32),
+                ze=d["ze"], ext=rep(d["ext"]), ssa=rep(d["ssa"]), pf=rep(d["pf"]))
+
+
 def c1_phase_function():
     """Deirmendjian C1 tabulated phase function (1801 angle/value pairs), i3rcRadarCloud.f95:70-76."""
     inp = _inputs()

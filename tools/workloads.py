@@ -43,6 +43,12 @@ WORKLOADS = {
     "landsat36_7dir": dict(label="i3rcLandsatCloud 128x128x36 + 7 radiance directions + Lambertian surface 0.2, mu0=0.5",
                            baseline_config=4, domain=("landsat_cloud", dict(nlayers=36)), moments=299, mu0=0.5,
                            params=dict(**DIRS7, **RRI), surface=0.2, photons=125_000_000, cpu_photons=8_000),
+    # beyond BASELINE.json: a field of production size (31 MB of extinction: 8 times an XCD's L2), the Landsat scene tiled 2 x 2
+    "landsat_tiled": dict(label="Landsat scene tiled 2x2: 256x256x119 (31 MB field), mu0=1, flux", baseline_config=3,
+                          domain=("landsat_tiled", {}), moments=299, mu0=1.0, params={}, photons=125_000_000, cpu_photons=40_000),
+    "landsat_tiled_7dir": dict(label="Landsat scene tiled 2x2: 256x256x119 + 7 radiance directions + Lambertian surface 0.2, mu0=0.5",
+                               baseline_config=4, domain=("landsat_tiled", {}), moments=299, mu0=0.5,
+                               params=dict(**DIRS7, **RRI), surface=0.2, photons=125_000_000, cpu_photons=6_000),
 }
 # Work per photon of the REFERENCE'S ALGORITHM on the four bench workloads (S tracer iterations incl. local-estimate rays,
 # K scatterings, E boundary tallies): the figures SURVEY.md 8(d)'s byte formula is evaluated with.  Recorded from runs in
