@@ -182,6 +182,8 @@ struct RngInit<ReplayStream> {
 // bounds are wave-uniform and held in scalar registers (readfirstlane tells the compiler so).
 struct Reservoir {
   long long next, end;
+  bool more;       // (XCD-aware order) a refill may still yield photons; in index order: end < nPhotons says so
+  int slabTry;     // (XCD-aware order) slabs of this wave's round that have run dry
   __device__ __forceinline__ void refill() {   // call in uniform control flow only
     const ColdArgs k = cold_args();
     unsigned long long *const counter = k->A.workCounter;
@@ -195,7 +197,95 @@ struct Reservoir {
     next = b < nPhotons ? b : nPhotons;
     end = b + chunk < nPhotons ? b + chunk : nPhotons;
   }
+  // XCD-aware order: positions in RunArgs::slabIds instead of photon numbers.  A wave takes from the slab of its own XCD
+  // (whose L2 then holds that eighth of the field) and goes round the other slabs when that one has run dry.
+  __device__ __forceinline__ void refill_slabs() {   // call in uniform control flow only
+    const ColdArgs k = cold_args();
+    SlabMeta *const m = k->A.slabMeta;
+    const unsigned chunk = (unsigned)k->A.chunk;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    next = end = 0; more = false;
+    for (; slabTry < 8; ++slabTry) {
+      const int s = (int)((xcc + (unsigned)slabTry) & 7u);
+      const unsigned cnt = m->count[s], off = m->offset[s];
+      unsigned base = 0;
+      if ((threadIdx.x & 63) == 0) base = atomicAdd(&m->take[s], chunk);
+      base = __builtin_amdgcn_readfirstlane((unsigned)__shfl(base, 0, 64));
+      if (base < cnt) {
+        next = (long long)off + base;
+        end = (long long)off + (base + chunk < cnt ? base + chunk : cnt);
+        more = true;
+        break;
+      }
+    }
+  }
 };
+
+// The two passes that sort a launch's photons by start slab: a photon's start position is the first two deviates of its own
+// stream (block 0, words 0 and 1: photon_kernel, part C), so its slab -- the eighth of the domain in y -- is known before it
+// is traced.  Pass 1 counts per workgroup (each workgroup owns a contiguous range of the launch's photons), the scan turns
+// the counts into every workgroup's first position in every slab's list, pass 2 writes the photon numbers there: no global
+// atomics, the same list for the same launch every time.  Both passes recompute the photon's first Philox block (about 1 ms
+// for 1e8 photons; a first version with one global counter per slab took 490 ms: 1.5 million waves on eight words).
+constexpr int kSlabSortBlocks = 2048;
+__device__ __forceinline__ int start_slab(uint32_t seed0, uint32_t seed1, unsigned long long photon) {
+  const Philox4 o = philox4x32_10((uint32_t)photon, (uint32_t)(photon >> 32), 0u, 0u, seed0, seed1);
+  const int s = (int)(u32_to_unit_float(o.v[1]) * 8.0f);
+  return s > 7 ? 7 : s;
+}
+__global__ void __launch_bounds__(256) slab_count_kernel(uint32_t seed0, uint32_t seed1, long long firstPhoton, long long n, long long span,
+                                                         unsigned *blockCounts) {
+  __shared__ unsigned cnt[8];
+  if (threadIdx.x < 8) cnt[threadIdx.x] = 0u;
+  __syncthreads();
+  const long long lo = (long long)blockIdx.x * span, hi = lo + span < n ? lo + span : n;
+  unsigned mine[8] = {};   // (per wave: only lane 0's copy is used)
+  for (long long base = lo; base < hi; base += 256) {   // uniform trip count within the block
+    const long long i = base + threadIdx.x;
+    const int s = i < hi ? start_slab(seed0, seed1, (unsigned long long)(firstPhoton + i)) : -1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mine[k] += (unsigned)__popcll(__ballot(s == k));
+  }
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 8; ++k) atomicAdd(&cnt[k], mine[k]);
+  __syncthreads();
+  if (threadIdx.x < 8) blockCounts[blockIdx.x * 8 + threadIdx.x] = cnt[threadIdx.x];
+}
+// one thread per slab: the slab's size, then (after all sizes are known) every workgroup's first position in its list
+__global__ void slab_scan_kernel(int nBlocks, const unsigned *blockCounts, SlabMeta *m, unsigned *blockBase) {
+  __shared__ unsigned total[8];
+  const int s = (int)threadIdx.x;
+  unsigned c = 0;
+  for (int b = 0; b < nBlocks; ++b) c += blockCounts[b * 8 + s];
+  total[s] = c;
+  __syncthreads();
+  unsigned off = 0;
+  for (int k = 0; k < s; ++k) off += total[k];
+  m->count[s] = c; m->offset[s] = off; m->take[s] = 0u; m->fill[s] = 0u;
+  for (int b = 0; b < nBlocks; ++b) { blockBase[b * 8 + s] = off; off += blockCounts[b * 8 + s]; }
+}
+__global__ void __launch_bounds__(256) slab_fill_kernel(uint32_t seed0, uint32_t seed1, long long firstPhoton, long long n, long long span,
+                                                        const unsigned *blockBase, uint32_t *ids) {
+  __shared__ unsigned cursor[8];
+  if (threadIdx.x < 8) cursor[threadIdx.x] = blockBase[blockIdx.x * 8 + threadIdx.x];
+  __syncthreads();
+  const long long lo = (long long)blockIdx.x * span, hi = lo + span < n ? lo + span : n;
+  for (long long base = lo; base < hi; base += 256) {
+    const long long i = base + threadIdx.x;
+    const int s = i < hi ? start_slab(seed0, seed1, (unsigned long long)(firstPhoton + i)) : -1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const unsigned long long mask = __ballot(s == k);
+      if (mask == 0ull) continue;
+      const int leader = __builtin_ctzll(mask);
+      unsigned at = 0;
+      if ((int)(threadIdx.x & 63) == leader) at = atomicAdd(&cursor[k], (unsigned)__popcll(mask));
+      at = (unsigned)__shfl(at, leader, 64);
+      if (s == k) ids[at + (unsigned)lanes_below(mask)] = (uint32_t)i;
+    }
+  }
+}
 
 #ifndef I3RC_RADIANCE_WAVES
 #define I3RC_RADIANCE_WAVES 5   /* (the Landsat + 7 directions case gains 9 % over 4; 6 would spill) */
@@ -271,8 +361,12 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
   long long pid = -1;                 // photon number within the launch (NEED_PID builds)
   int fate = -1, fateCol = -1;        // REPLAY builds
   float fateW = 0.0f;
+  // XCD-aware photon order: flux kernels on fields beyond an XCD's L2 (bricks), when the host has sorted the launch's photons
+  constexpr bool SLABS = GRID == GRID_BRICKS && !INTENSITY && !Rng::kReplay;
+  const bool slabs = SLABS && A.slabIds != nullptr;
   Reservoir res;
-  res.refill();
+  res.slabTry = 0;
+  if (slabs) res.refill_slabs(); else res.refill();
 
   // ---- Radiance (local estimate) through a per-wave RAY QUEUE -------------------------------------------------------
   // A scattering or reflection event does not trace its D local-estimate (shadow) rays itself and the photon does not
@@ -671,7 +765,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
         int rank = lanes_below(newMask);
         long long mine = -1;
         long long avail = res.end - res.next;
-        if (avail < (long long)need && res.end < Ae.nPhotons) {   // drain the reservoir, then refill it (chunk >= 64 covers the rest)
+        if (avail < (long long)need && (slabs ? res.more : res.end < Ae.nPhotons)) {   // drain the reservoir, then refill it (chunk >= 64 covers the rest)
           if (isNew && rank < (int)avail) mine = res.next + rank;
           wc.photons += (unsigned)avail;                        // numPhotonsProcessed :459
           need -= (int)avail;
@@ -680,7 +774,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
           // atomics of a hand-over all go to the same nine addresses, from every wave of the chip
           if ((++refills & 3u) == 0u || wc.steps > 0x40000000u || wc.shadow > 0x40000000u) flush_counters();
           else adapt_thresholds();
-          res.refill();
+          if (slabs) res.refill_slabs(); else res.refill();
           avail = res.end - res.next;
         }
         const int taken = (int)(avail < (long long)need ? avail : (long long)need);   // < need only when the batch is exhausted
@@ -690,6 +784,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
         if (isNew) {
           if (mine < 0) st = ST_DONE;
           else {
+            if (SLABS && slabs) mine = (long long)Ae.slabIds[mine];   // position in the sorted list -> photon number
             RngInit<Rng>::start(rng, Ae, mine);
             if (NEED_PID) pid = mine;
           }

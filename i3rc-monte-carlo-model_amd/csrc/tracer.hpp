@@ -67,10 +67,15 @@ struct DevProblem {
   int rayQueueCap;                    // radiance runs: events a wave's ray queue holds (power of two; kRecWords floats each)
 };
 
+// XCD-aware photon order (fields beyond an XCD's L2): the photons of a launch sorted by the eighth of the domain (in y)
+// they start in -- slabIds holds photon numbers relative to firstPhoton, slab after slab; see slab_count_kernel
+struct SlabMeta { unsigned count[8], offset[8], fill[8], take[8]; };
 struct RunArgs {
   uint32_t seed0, seed1;
   long long firstPhoton, nPhotons;
   unsigned long long *workCounter;    // device word, zeroed before launch
+  const uint32_t *slabIds;            // null: photons are handed out in index order
+  SlabMeta *slabMeta;
   int srcKind; float solarMu, solarPhi;
   float solarDx, solarDy, solarDz;    // makeDirectionCosines(solarMu, solarPhi) evaluated once on the host
   int chunk;                          // photon indices a wave reserves per visit of the work counter

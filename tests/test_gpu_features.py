@@ -481,3 +481,45 @@ def test_changing_the_directions_under_a_bound_tally_buffer_is_refused_without_s
     torch.cuda.synchronize()
     assert float(buf2[lay2.total:].abs().sum()) == 0.0         # nothing written past the layout
     assert buf2[lay2.counters].item() == 20000.0
+
+
+def test_xcd_aware_photon_order_traces_the_same_photons():
+    """Flux kernels on a field beyond an XCD's L2 (bricks) hand every wave photons that start in the eighth of the domain its
+    XCD looks after (the launch's photons sorted by start slab first: kernels.hpp, slab_count_kernel).  Which wave traces a
+    photon never matters: integer work counters and tallies equal those of the index-order run (I3RC_SLABS=0), for a whole
+    batch, a batch cut into launches and a batch run through the pipelined entry point."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = r'''
+import json, sys
+sys.path.insert(0, %r)
+import numpy as np
+import i3rc_monte_carlo_model_amd as M
+from i3rc_monte_carlo_model_amd import binding as B
+from tests import cases
+d = cases.landsat_cloud()
+dom = M.new_Domain(d["xe"], d["ye"], d["ze"]); dom.addOpticalComponent("c", d["ext"], d["ssa"], d["pf"], M.PhaseFunctionTable([M.henyey_greenstein(0.85, 64)]))
+g = M.new_Integrator(dom); g.specifyParameters(surfaceAlbedo=0.2)
+out = []
+r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((4, 9)), M.new_PhotonStream(0.6, 30.0, 300001))
+out.append((g.kernel_name(), r["counters"], float(r["fluxUp"].mean(dtype=np.float64)), float(r["fluxDown"].mean(dtype=np.float64)), r["fluxUp"][::16, ::16].tolist()))
+assert B.load().i3rc_hip_set_launch_limit(g._h, 70000) == 0          # five launches
+r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((4, 9)), M.new_PhotonStream(0.6, 30.0, 300001))
+out.append((g.kernel_name(), r["counters"], float(r["fluxUp"].mean(dtype=np.float64)), float(r["fluxDown"].mean(dtype=np.float64)), r["fluxUp"][::16, ::16].tolist()))
+assert B.load().i3rc_hip_set_launch_limit(g._h, 0) == 0
+rs = g.computeRadiativeTransferBatches((4, 9), 3, 0.6, 30.0, 300001, inFlight=3)
+out.append((g.kernel_name(), rs[0]["counters"], float(rs[0]["fluxUp"].mean(dtype=np.float64)), float(rs[0]["fluxDown"].mean(dtype=np.float64)), rs[0]["fluxUp"][::16, ::16].tolist()))
+print(json.dumps(out))
+''' % root
+    res = {}
+    for slabs in ("1", "0"):
+        p = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env=dict(os.environ, I3RC_SLABS=slabs, I3RC_POISON="1"))
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        res[slabs] = json.loads(p.stdout.strip().splitlines()[-1])
+    ref = res["0"][0]
+    assert "GRID_BRICKS" in ref[0]
+    for slabs in ("1", "0"):
+        for name, counters, up, down, field in res[slabs]:
+            assert counters == ref[1], (slabs, counters, ref[1])
+            assert abs(up - ref[2]) < 1e-6 and abs(down - ref[3]) < 1e-6
+            assert np.allclose(np.array(field), np.array(ref[4]), rtol=1e-4, atol=1e-5)
