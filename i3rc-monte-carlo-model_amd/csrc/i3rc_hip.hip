@@ -724,12 +724,15 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
       const size_t tableBytes = sizeof(unsigned) * 8 * kSlabSortBlocks;
       if (sb.blockCounts.bytes != tableBytes) { HIPCHK(h, sb.blockCounts.alloc(tableBytes)); HIPCHK(h, sb.blockBase.alloc(tableBytes)); }
       const long long span = ((A.nPhotons + kSlabSortBlocks - 1) / kSlabSortBlocks + 255) / 256 * 256;   // photons per workgroup of the sort
+      int tx = 1, ty = 8;   // the squarest of the four tilings (ties: more cuts in y, whose rows are further apart in memory)
+      for (int cx = 2; cx <= 8; cx *= 2)
+        if ((double)h->nx / cx + (double)h->ny / (8 / cx) < (double)h->nx / tx + (double)h->ny / ty) { tx = cx; ty = 8 / cx; }
       hipLaunchKernelGGL(slab_count_kernel, dim3(kSlabSortBlocks), dim3(256), 0, h->stream, A.seed0, A.seed1, A.firstPhoton, A.nPhotons, span,
-                         (unsigned *)sb.blockCounts.p);
+                         tx, ty, (unsigned *)sb.blockCounts.p);
       hipLaunchKernelGGL(slab_scan_kernel, dim3(1), dim3(8), 0, h->stream, (int)kSlabSortBlocks, (const unsigned *)sb.blockCounts.p,
                          (SlabMeta *)sb.meta.p, (unsigned *)sb.blockBase.p);
       hipLaunchKernelGGL(slab_fill_kernel, dim3(kSlabSortBlocks), dim3(256), 0, h->stream, A.seed0, A.seed1, A.firstPhoton, A.nPhotons, span,
-                         (const unsigned *)sb.blockBase.p, (uint32_t *)sb.ids.p);
+                         tx, ty, (const unsigned *)sb.blockBase.p, (uint32_t *)sb.ids.p);
       HIPCHK(h, hipGetLastError());
       B.slabIds = (const uint32_t *)sb.ids.p; B.slabMeta = (SlabMeta *)sb.meta.p;
     }
