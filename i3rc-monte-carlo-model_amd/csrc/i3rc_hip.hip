@@ -699,7 +699,9 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
     // a field beyond an XCD's L2 (bricks): every wave in flight widens the part of it that is in use; measured on the
     // 7.8 MB Landsat-119 field (tools/blocks_sweep.py): 4-5 workgroups per CU 6.17e8 photons/s, 6-8 5.83e8.  (The radiance
     // kernels have the registers for five at most; fields within L2 gain up to 7.)
-    if (place == GRID_BRICKS) perCU = std::min(perCU, 5);
+    // With the XCD-aware photon order: Landsat-119 5 ... 8 alike (6.5e8); the scene tiled 2 x 2 (31 MB): 4 workgroups 5.41e8,
+    // 5 5.02e8, 6-8 4.6e8.
+    if (place == GRID_BRICKS) perCU = std::min(perCU, ncell_bytes(h) > ((size_t)16 << 20) ? 4 : 5);
   }
   if (plan.ldsBytes > 48 * 1024)
     HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.ldsBytes));
