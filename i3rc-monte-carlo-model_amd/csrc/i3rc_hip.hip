@@ -713,13 +713,15 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
   // the photons a wave traces start in "its" eighth of the domain -- workgroups are dealt round-robin over the XCDs, the
   // kernel reads its XCC id -- an XCD's L2 has an eighth of the field (and its surroundings) to hold.  The launch's
   // photons are sorted by start slab first (their start position is their own first Philox block): two passes over the
-  // photon numbers, about 1 % of the launch.  Flux kernels only: local-estimate rays cross the whole domain.
+  // photon numbers, about 1 % of the launch.  Radiance runs: local-estimate rays cross much of the domain, but from one
+  // tile they keep to a tube per direction -- nothing gained on the 7.8 MB Landsat field (9.49 against 9.45e7 photons/s:
+  // left in index order), +20 % on a 31 MB field (6.9 -> 8.3e7 with 7 directions).
   // Measured ceiling (tools/locality_experiment.py): +9 ... 14 % on the 7.8 MB Landsat field, +36 % on a 62 MB field.
   // I3RC_SLABS=0 switches it off.
   static const bool slabsOn = !(std::getenv("I3RC_SLABS") && std::atoi(std::getenv("I3RC_SLABS")) == 0);
   B.slabIds = nullptr; B.slabMeta = nullptr;
   if constexpr (!Rng::kReplay) {
-    if (slabsOn && place == GRID_BRICKS && !plan.intensity && A.srcKind == 0 && A.nPhotons >= 1024 && A.nPhotons < ((long long)1 << 32)) {
+    if (slabsOn && place == GRID_BRICKS && (!plan.intensity || ncell_bytes(h) > ((size_t)16 << 20)) && A.srcKind == 0 && A.nPhotons >= 1024 && A.nPhotons < ((long long)1 << 32)) {
       auto &sb = h->slabBufs[h->stream];
       if (sb.ids.bytes < (size_t)A.nPhotons * sizeof(uint32_t)) HIPCHK(h, sb.ids.alloc((size_t)A.nPhotons * sizeof(uint32_t)));
       if (!sb.meta.p || sb.meta.bytes != sizeof(SlabMeta)) HIPCHK(h, sb.meta.alloc(sizeof(SlabMeta)));

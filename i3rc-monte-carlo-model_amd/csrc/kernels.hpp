@@ -181,9 +181,7 @@ struct RngInit<ReplayStream> {
 // round (the returning atomic costs microseconds; every wave would pay it in ~97 % of its event phases).  The two
 // bounds are wave-uniform and held in scalar registers (readfirstlane tells the compiler so).
 struct Reservoir {
-  long long next, end;
-  bool more;       // (XCD-aware order) a refill may still yield photons; in index order: end < nPhotons says so
-  int slabTry;     // (XCD-aware order) slabs of this wave's round that have run dry
+  long long next, end;   // (XCD-aware order: positions in the sorted list; end < 0: every tile has run dry)
   __device__ __forceinline__ void refill() {   // call in uniform control flow only
     const ColdArgs k = cold_args();
     unsigned long long *const counter = k->A.workCounter;
@@ -198,14 +196,17 @@ struct Reservoir {
     end = b + chunk < nPhotons ? b + chunk : nPhotons;
   }
   // XCD-aware order: positions in RunArgs::slabIds instead of photon numbers.  A wave takes from the slab of its own XCD
-  // (whose L2 then holds that eighth of the field) and goes round the other slabs when that one has run dry.
-  __device__ __forceinline__ void refill_slabs() {   // call in uniform control flow only
+  // (whose L2 then holds that eighth of the field) and goes round the other slabs when that one has run dry.  How many
+  // slabs of its round have run dry the wave keeps in LDS (read and written at refills only: no register for it in
+  // kernels that have none to spare).
+  __device__ __forceinline__ void refill_slabs(int *tried) {   // call in uniform control flow only
     const ColdArgs k = cold_args();
     SlabMeta *const m = k->A.slabMeta;
     const unsigned chunk = (unsigned)k->A.chunk;
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    next = end = 0; more = false;
+    next = end = -1;   // (nothing left: avail = 0 and end < 0)
+    int slabTry = __builtin_amdgcn_readfirstlane(*tried);
     for (; slabTry < 8; ++slabTry) {
       const int s = (int)((xcc + (unsigned)slabTry) & 7u);
       const unsigned cnt = m->count[s], off = m->offset[s];
@@ -215,10 +216,10 @@ struct Reservoir {
       if (base < cnt) {
         next = (long long)off + base;
         end = (long long)off + (base + chunk < cnt ? base + chunk : cnt);
-        more = true;
         break;
       }
     }
+    if ((threadIdx.x & 63) == 0) *tried = slabTry;
   }
 };
 
@@ -363,12 +364,14 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
   long long pid = -1;                 // photon number within the launch (NEED_PID builds)
   int fate = -1, fateCol = -1;        // REPLAY builds
   float fateW = 0.0f;
-  // XCD-aware photon order: flux kernels on fields beyond an XCD's L2 (bricks), when the host has sorted the launch's photons
-  constexpr bool SLABS = GRID == GRID_BRICKS && !INTENSITY && !Rng::kReplay;
-  const bool slabs = SLABS && A.slabIds != nullptr;
+  // XCD-aware photon order: kernels on fields beyond an XCD's L2 (bricks), when the host has sorted the launch's photons
+  constexpr bool SLABS = GRID == GRID_BRICKS && !Rng::kReplay;
+  __shared__ int slabsTried[4];            // per wave (see Reservoir::refill_slabs)
   Reservoir res;
-  res.slabTry = 0;
-  if (slabs) res.refill_slabs(); else res.refill();
+  if (SLABS && A.slabIds != nullptr) {
+    if ((threadIdx.x & 63) == 0) slabsTried[threadIdx.x >> 6] = 0;
+    res.refill_slabs(&slabsTried[threadIdx.x >> 6]);
+  } else res.refill();
 
   // ---- Radiance (local estimate) through a per-wave RAY QUEUE -------------------------------------------------------
   // A scattering or reflection event does not trace its D local-estimate (shadow) rays itself and the photon does not
@@ -767,7 +770,8 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
         int rank = lanes_below(newMask);
         long long mine = -1;
         long long avail = res.end - res.next;
-        if (avail < (long long)need && (slabs ? res.more : res.end < Ae.nPhotons)) {   // drain the reservoir, then refill it (chunk >= 64 covers the rest)
+        const bool slabs = SLABS && Ae.slabIds != nullptr;
+        if (avail < (long long)need && (slabs ? res.end >= 0 : res.end < Ae.nPhotons)) {   // drain the reservoir, then refill it (chunk >= 64 covers the rest)
           if (isNew && rank < (int)avail) mine = res.next + rank;
           wc.photons += (unsigned)avail;                        // numPhotonsProcessed :459
           need -= (int)avail;
@@ -776,7 +780,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
           // atomics of a hand-over all go to the same nine addresses, from every wave of the chip
           if ((++refills & 3u) == 0u || wc.steps > 0x40000000u || wc.shadow > 0x40000000u) flush_counters();
           else adapt_thresholds();
-          if (slabs) res.refill_slabs(); else res.refill();
+          if (slabs) res.refill_slabs(&slabsTried[threadIdx.x >> 6]); else res.refill();
           avail = res.end - res.next;
         }
         const int taken = (int)(avail < (long long)need ? avail : (long long)need);   // < need only when the batch is exhausted
@@ -786,7 +790,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
         if (isNew) {
           if (mine < 0) st = ST_DONE;
           else {
-            if (SLABS && slabs) mine = (long long)Ae.slabIds[mine];   // position in the sorted list -> photon number
+            if (slabs) mine = (long long)Ae.slabIds[mine];   // position in the sorted list -> photon number
             RngInit<Rng>::start(rng, Ae, mine);
             if (NEED_PID) pid = mine;
           }
