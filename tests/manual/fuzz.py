@@ -151,8 +151,15 @@ for seed in range(first, first + count):
     if not res: continue
     r = res[0]
     c0, c1 = ({k: x["counters"][k] for k in KEYS} for x in res)
+    entry = []
+    if not explicit:   # the same batch through the pipelined and the looking-ahead entry points (g: the second schedule's handle)
+        many = g.computeRadiativeTransferBatches((seed, 0), 3, mu0, az, n, inFlight=int(rng.integers(1, 5)))
+        for b in (0, 1, 2):
+            q = g.computeRadiativeTransferLookingAhead(M.new_RandomNumberSequence((seed, b)), M.new_PhotonStream(mu0, az, n), lookAhead=int(rng.integers(0, 4)))
+            if {k: q["counters"][k] for k in KEYS} != {k: many[b]["counters"][k] for k in KEYS}: entry.append(("look-ahead / pipelined", b))
+        if {k: many[1]["counters"][k] for k in KEYS} != c0: entry.append(("pipelined / plain", {k: many[1]["counters"][k] for k in KEYS}, c0))
     tot = float(r["fluxUp"].mean() + r["fluxAbsorbed"].mean()) + (float(r["fluxDown"].mean()) * (1.0 - p["surfaceAlbedo"]) if "surfaceAlbedo" in p else 0.0)
-    problems = []
+    problems = list(entry)
     if c0 != c1: problems.append(("schedule", c0, c1))
     if not all(np.isfinite(r[k]).all() for k in ("fluxUp", "fluxDown", "fluxAbsorbed", "volumeAbsorption")): problems.append("non-finite flux")
     if nd and not np.isfinite(r["intensity"]).all(): problems.append("non-finite radiance")
