@@ -296,13 +296,19 @@ __global__ void __launch_bounds__(256) slab_fill_kernel(uint32_t seed0, uint32_t
 #ifndef I3RC_MIN_WAVES
 #define I3RC_MIN_WAVES 5
 #endif
+// The specialised flux kernels need 54 vector registers: told to plan for eight waves per SIMD (instead of five) the
+// compiler schedules them differently -- step cloud 3.13 -> 3.27e9 photons/s on the same box, 32 layers 2.56 -> 2.67e9,
+// radar 640 flux 1.24 -> 1.29e9, Landsat-36 -0.5 %; the bricked kernels (at most five workgroups per CU anyway) lose 1 %.
+#ifndef I3RC_FLUX_WAVES
+#define I3RC_FLUX_WAVES 8
+#endif
 // GENERAL = false is the specialisation for the common problem class -- regular grid, ray tracing, one component,
 // Lambertian albedo (no BRDF grid), Directional source, production RNG: the rare paths (grid searches, periodic
 // re-wrapping loops, max-cross-section moves, BRDF lookups, component selection) are compiled out, which shrinks the
 // loop's code and its scalar-register pressure.  GENERAL = true keeps every path behind run-time switches.
 // (radiance kernels keep two rays per lane live -- the photon's and a shadow ray's: 4 waves per SIMD give them 128 vector registers)
 template <class Rng, bool INTENSITY, bool GENERAL, int GRID>
-__global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_WAVES) : I3RC_MIN_WAVES) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
+__global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_WAVES) : ((GENERAL || GRID == GRID_BRICKS) ? I3RC_MIN_WAVES : I3RC_FLUX_WAVES)) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   {

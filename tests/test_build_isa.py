@@ -58,7 +58,8 @@ def test_production_kernels_keep_their_state_in_registers():
     own resource figures, hipcc -Rpass-analysis=kernel-resource-usage): round 1's general radiance kernel carried
     26-29 spilled vector registers and 116 bytes of scratch per lane.  Scalar-register spills (held in vector-register
     lanes, no memory traffic) are bounded: the specialised kernels -- every BASELINE configuration runs one of them --
-    may have a handful, the flux kernels none."""
+    may have a handful.  (The specialised flux kernels on LDS / linear grids are compiled for eight waves per SIMD, whose
+    scalar-register budget costs them ~10 spills and still gains 4 %: kernels.hpp, I3RC_FLUX_WAVES; the bricked one none.)"""
     import sys
 
     sys.path.insert(0, ROOT)
@@ -70,7 +71,8 @@ def test_production_kernels_keep_their_state_in_registers():
     for r in rows:
         assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, (r["name"], r["VGPRs Spill"], r["ScratchSize [bytes/lane]"])
         if ", false, GRID" in r["name"]:                       # specialised (GENERAL = false)
-            limit = 0 if r["name"].startswith("photon_kernel<PhiloxStream, false") else 16
+            limit = 16
+            if r["name"].startswith("photon_kernel<PhiloxStream, false"): limit = 0 if "GRID_BRICKS" in r["name"] else 12
             assert r["SGPRs Spill"] <= limit, (r["name"], r["SGPRs Spill"])
     # the replay build (test infrastructure on the device) must not use scratch either
     for r in everything:
