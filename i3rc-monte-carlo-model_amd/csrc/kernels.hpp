@@ -520,13 +520,18 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
         Ray sr;                                             // (every field is set when a lane takes a ray, before any use: no initial
         int rst = R_EMPTY, sInfo;                           //  values, which would cost a register copy each at every pass of the photon loop)
         float sW, sNorm, sTauFree;                          // state; component | direction << 8 | stage << 16 (bit 24: see EXPAND); weight, phase-function factor, free path
+        // (One back edge only: EXPAND runs in a loop of its own and SERVICE goes on into the step phase.  With three ways
+        // back to the loop's head -- after an expand, after a service, after the steps -- the compiler kept the rays' 27
+        // registers in one set at the head and in another at the latch and copied them to and fro, some forty vector
+        // moves in every pass: "Exchanging two register sets")
         for (;;) {
-          const int ringRays = (int)((qTail - qHeadEv) * (unsigned)P.nDir - qHeadSub);   // rays waiting in the ring, not yet expanded
-          const int ready = (int)(rdTail - rdHead);                                        // ready-made rays
-          if (ringRays > 0 && ready <= kReadyRays - kExpandBatch) {
+          for (;;) {
+            const int ringRays0 = (int)((qTail - qHeadEv) * (unsigned)P.nDir - qHeadSub);
+            const int ready0 = (int)(rdTail - rdHead);
+            if (!(ringRays0 > 0 && ready0 <= kReadyRays - kExpandBatch)) break;
             // ------------------------------------------------------------ EXPAND phase: (event, direction) -> ready ray
-            const int room = kReadyRays - ready;
-            const int n = ringRays < room ? ringRays : room;
+            const int room = kReadyRays - ready0;
+            const int n = ringRays0 < room ? ringRays0 : room;
             const int lane = (int)(threadIdx.x & 63);
             PROF_BEGIN();
             const ColdArgs kx = cold_args();   // (the problem through the kernarg segment, as in the event phase)
@@ -597,15 +602,17 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
               raysSkipped += (unsigned)n - kept;
             }
             PROF_END(PH_EXPAND, n);
-            continue;   // (the loop's only other back edge: see below)
           }
+          const int ringRays = (int)((qTail - qHeadEv) * (unsigned)P.nDir - qHeadSub);   // rays waiting in the ring, not yet expanded
+          const int ready = (int)(rdTail - rdHead);                                        // ready-made rays
           const unsigned long long actMask = __ballot(rst == R_TRACE), endMask = __ballot(rst == R_ENDED);
           const int nAct = (int)__popcll(actMask), nIdle = 64 - nAct;
           // with photons still to run, the wave leaves its rays once there is nothing left to hand out and few are under way
           // (no more rays can be made ready at this point: the ring is empty, or the ready buffer is full)
           const bool leaving = ringRays == 0 && photonsLeft && ready + nAct < kLowWater;   // too few for a wavefront: gather more first
           const bool canServe = endMask != 0ull || (!leaving && ready > 0 && nIdle > 0);
-          if (canServe && (nIdle >= liThr || nAct == 0 || leaving)) {
+          const bool serve = canServe && (nIdle >= liThr || nAct == 0 || leaving);
+          if (serve) {
             // ------------------------------------------------------------ SERVICE phase (shadow-ray ends and starts)
             PROF_BEGIN();
             const ColdArgs kx = cold_args();
@@ -663,21 +670,25 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
             wc.calls += started;
             raysStarted += started;
             PROF_END(PH_SERVICE, __popcll(endMask) + take);
-            continue;
           }
-          if (nAct == 0 || leaving) {
-            // rays still under way go back to the ready buffer as they are (ready + nAct < kLowWater <= kReadyRays: they fit)
+          // rays still under way go back to the ready buffer as they are.  (A wave that leaves has taken no new rays in the
+          // service phase just before, but rays that ended there may have begun their second leg: with those the rays under
+          // way may no longer fit beside the ready ones -- then the wave stays, as it did when the next pass re-counted.)
+          const unsigned long long backMask = __ballot(rst == R_TRACE);   // (after the service phase, if there was one)
+          const int nBack = (int)__popcll(backMask);
+          const int readyNow = (int)(rdTail - rdHead);
+          if ((leaving && ready + nBack < kLowWater) || (nBack == 0 && readyNow == 0 && ringRays == 0)) {
             if (rst == R_TRACE) {
-              lds_float *out = rdBase + ((rdTail + (unsigned)lanes_below(actMask)) & (unsigned)(kReadyRays - 1));
+              lds_float *out = rdBase + ((rdTail + (unsigned)lanes_below(backMask)) & (unsigned)(kReadyRays - 1));
               out[0] = sr.x; out[kReadyRays] = sr.y; out[2 * kReadyRays] = sr.z;
               out[3 * kReadyRays] = __int_as_float(sr.ix); out[4 * kReadyRays] = __int_as_float(sr.iy); out[5 * kReadyRays] = __int_as_float(sr.iz);
               out[6 * kReadyRays] = __int_as_float(sInfo);
               out[7 * kReadyRays] = sW; out[8 * kReadyRays] = sNorm; out[9 * kReadyRays] = sTauFree;
               out[10 * kReadyRays] = sr.target; out[11 * kReadyRays] = sr.acc;
             }
-            rdTail += (unsigned)nAct;
-            wc.calls -= (unsigned)nAct;      // (they are counted again when they are taken up: one tracer call each, whatever the schedule)
-            raysStarted -= (unsigned)nAct;
+            rdTail += (unsigned)nBack;
+            wc.calls -= (unsigned)nBack;      // (they are counted again when they are taken up: one tracer call each, whatever the schedule)
+            raysStarted -= (unsigned)nBack;
             break;
           }
           // -------------------------------------------------------------- VOXEL-STEP phase (shadow rays)
@@ -693,11 +704,17 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
             }
             PROF_END(PH_RAYSTEP, nTracing);
           };
-          ray_step();
-          if (liThr - nIdle > kStepAhead) ray_step();
+          const int idleNow = 64 - nBack;   // (a service phase has handed rays out)
+          // (lanes still idle after a service phase and rays left to make ready or to hand out: no step with a wave part
+          // full, the next pass expands / serves again first -- as a `continue` after the service phase did, without its back edge)
+          const bool fillFirst = serve && idleNow >= liThr && (ringRays > 0 || readyNow > 0);
+          if (!fillFirst) {
+            ray_step();
+            if (liThr - idleNow > kStepAhead) ray_step();
 #if I3RC_THIRD_STEP < 64
-          if (liThr - nIdle > kStepAhead + I3RC_THIRD_STEP) ray_step();
+            if (liThr - idleNow > kStepAhead + I3RC_THIRD_STEP) ray_step();
 #endif
+          }
         }
         // what the photons' rays derive from their directions is worked out again here, so that those eleven registers per
         // lane are free during the ray loop (the radiance kernels then fit five waves per SIMD)
