@@ -71,6 +71,42 @@ def run_cpu_baseline(a):
         return {"value": None, "unit": "photons/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
 
 
+def wait_for_ranks(procs, poll_s=0.2, grace_s=10.0):
+    """Wait for all rank processes; when one exits non-zero the others are terminated (then killed) instead of being
+    left in a rendezvous or a barrier.  Returns rank 0's stdout / stderr and every exit code."""
+    import threading
+
+    captured = {}
+
+    def drain():   # rank 0's pipes are read while we poll, so that a long line never blocks the child
+        captured["out"], captured["err"] = procs[0].communicate()
+
+    t = threading.Thread(target=drain, daemon=True)
+    t.start()
+    failed = False
+    while True:
+        codes = [p.poll() for p in procs]
+        if any(c not in (None, 0) for c in codes):
+            failed = True
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(poll_s)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + grace_s
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    t.join(timeout=grace_s)
+    return captured.get("out", ""), captured.get("err", ""), [p.returncode for p in procs]
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # launcher: no GPU call, no torch import in this process
 # ------------------------------------------------------------------------------------------------------------------
@@ -78,20 +114,29 @@ def launcher(a):
     cpu_baseline = None
     if a.gpus == 1 and not a.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(a)   # before any rank exists: the host cores are free
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(a.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), I3RC_BENCH_SPAWNED="1")
-        if cpu_baseline is not None and r == 0:   # rank 0 writes the line: it quotes the oracle's work counters in its roofline
-            env["I3RC_BENCH_CPU_BASELINE"] = json.dumps(cpu_baseline)
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # Ranks rendezvous on a port found by bind-and-close: somebody else may take it before rank 0 binds it (EADDRINUSE in
+    # its stderr) -- then the whole set is started again on a fresh port.  All children are polled: the first one that
+    # fails takes the others with it (they would sit in the rendezvous or in a barrier until its timeout).
+    for attempt in range(3):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs = []
+        for r in range(a.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), I3RC_BENCH_SPAWNED="1")
+            if cpu_baseline is not None and r == 0:   # rank 0 writes the line: it quotes the oracle's work counters in its roofline
+                env["I3RC_BENCH_CPU_BASELINE"] = json.dumps(cpu_baseline)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                          stderr=subprocess.PIPE if r == 0 else None, text=True))
+        out0, err0, codes = wait_for_ranks(procs)
+        sys.stderr.write(err0 or "")
+        if any(codes) and attempt < 2 and ("EADDRINUSE" in (err0 or "") or "Address already in use" in (err0 or "")):
+            sys.stderr.write(f"bench.py: port {port} was taken before the ranks met; starting them again on another one\n")
+            continue
+        break
     if any(codes):
         sys.stderr.write(f"bench.py: rank exit codes {codes}\n")
         sys.stdout.write(out0 or "")

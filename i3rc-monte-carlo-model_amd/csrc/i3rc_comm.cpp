@@ -48,12 +48,15 @@ std::string env_str(const char *a, const char *dflt) {
 
 // ---- rendezvous: rank 0 -> everyone, n bytes -----------------------------------------------------------------------
 // Its own port: I3RC_COMM_PORT, else MASTER_PORT + 1 -- under torchrun / SLURM launchers MASTER_PORT itself is held by
-// the launcher's store, which would answer a connecting rank with bytes that are not ours (hence also the header below).
+// the launcher's store, which would answer a connecting rank with bytes that are not ours (hence also the headers below).
+// A launcher only promises that MASTER_PORT is free: where MASTER_PORT + 1 may belong to somebody else, set I3RC_COMM_PORT
+// (INTEGRATION.md); rank 0 fails at once when it cannot bind the port, the others when the listener there is not ours.
 int rendezvous_port() {
   if (std::getenv("I3RC_COMM_PORT")) return std::atoi(std::getenv("I3RC_COMM_PORT"));
   return env_int("MASTER_PORT", nullptr, 29499) + 1;
 }
-struct RendezvousHeader { uint32_t magic, bytes; };
+struct RendezvousHeader { uint32_t magic, bytes; };   // rank 0 -> rank r, followed by the blob
+struct RendezvousHello { uint32_t magic, rank; };     // rank r -> rank 0, first thing on the connection
 constexpr uint32_t kMagic = 0x69337263u;   // "i3rc"
 
 bool send_all(int fd, const void *buf, size_t n) {
@@ -90,13 +93,29 @@ int rendezvous_broadcast(void *blob, size_t n) {
     }
     timeval tv{120, 0};                                   // a rank that never shows up must not hang the others for ever
     (void)setsockopt(srv, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
-    for (int peer = 1; peer < g_size; ++peer) {
+    // Every rank says hello first -- the magic word and its rank number -- and only such a connection counts as a peer and
+    // is handed the blob: a stray connection (a port scanner, another job probing MASTER_PORT + 1) is closed and forgotten
+    // instead of taking a real rank's place.
+    std::string seen((size_t)g_size, 0);
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(120);
+    for (int peers = 1; peers < g_size;) {
+      if (std::chrono::steady_clock::now() > deadline) { ::close(srv); return fail("i3rc_comm_init: timed out waiting for the other processes"); }
       const int fd = ::accept(srv, nullptr, nullptr);
       if (fd < 0) { ::close(srv); return fail("i3rc_comm_init: timed out waiting for the other processes"); }
+      timeval hv{5, 0};                                   // a connection that says nothing is not one of ours
+      (void)setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &hv, sizeof(hv));
+      RendezvousHello hello{0u, 0u};
+      if (!recv_all(fd, &hello, sizeof(hello)) || hello.magic != kMagic || hello.rank == 0u || hello.rank >= (uint32_t)g_size ||
+          seen[hello.rank]) {
+        ::close(fd);
+        continue;
+      }
       const RendezvousHeader hdr{kMagic, (uint32_t)n};
       const bool ok = send_all(fd, &hdr, sizeof(hdr)) && send_all(fd, blob, n);
       ::close(fd);
       if (!ok) { ::close(srv); return fail("i3rc_comm_init: sending the rendezvous blob failed"); }
+      seen[hello.rank] = 1;
+      ++peers;
     }
     ::close(srv);
     return 0;
@@ -116,7 +135,8 @@ int rendezvous_broadcast(void *blob, size_t n) {
       timeval tv{30, 0};                                    // a listener that is not ours may never send anything
       (void)setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
       RendezvousHeader hdr{0u, 0u};
-      const bool ok = recv_all(fd, &hdr, sizeof(hdr)) && hdr.magic == kMagic && hdr.bytes == (uint32_t)n && recv_all(fd, blob, n);
+      const RendezvousHello hello{kMagic, (uint32_t)g_rank};
+      const bool ok = send_all(fd, &hello, sizeof(hello)) && recv_all(fd, &hdr, sizeof(hdr)) && hdr.magic == kMagic && hdr.bytes == (uint32_t)n && recv_all(fd, blob, n);
       ::close(fd);
       if (ok) return 0;
       return fail("i3rc_comm_init: " + host + ":" + std::to_string(port) + " did not answer with the rendezvous blob "

@@ -103,6 +103,27 @@ struct i3rc_hip_integrator {
   } aheadSig, lastSig;
   uint32_t lastSeed1 = 0;
 
+  // Fused multi-batch launches (i3rc_hip_run_batches / the look-ahead of i3rc_hip_compute_batch on problems the
+  // specialised flux kernels run): a GROUP of consecutive batches is ONE grid (photon_kernel<PhiloxBatchStream, ...>), every
+  // batch with tally blocks of its own -- `replicas` of them, summed by reduce_replicas_kernel into `compact` --, so that
+  // one batch's tail is filled by the next batch's photons inside the launch.  Up to kFusedSlots groups are in flight, each
+  // on a stream of its own (the tail of a group is covered by the next group; its copy to the host by the one after).
+  struct FusedSlot {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    DevBuf blocks, compact, counter;
+    double *pinned = nullptr; size_t pinnedBytes = 0;
+    int *abortFlag = nullptr;      // host-coherent word the kernel polls (RunArgs::abortFlag)
+    int first = 0, count = 0;      // batches first .. first + count - 1 of the call (count = 0: free)
+    uint32_t seed1 = 0;            // seed word of the group's first batch
+    int next = 0;                  // look-ahead: batches of the group handed to the caller so far
+  };
+  static constexpr int kFusedSlots = 3;
+  FusedSlot fused[kFusedSlots];
+  std::vector<int> aheadGroups;    // look-ahead: slots of the groups launched ahead, oldest first
+  int aheadGroupSize = 0;          // size of the next group to launch ahead (grows 8, 16, 32, 64)
+  int fusion = -1;                 // -1: automatic, 0: never fuse, 1: fuse whatever the batch size (i3rc_hip_set_batch_fusion)
+
   // XCD-aware photon order (launch): the sorted photon numbers and the slab bookkeeping of a launch, per stream (launches
   // on different streams -- i3rc_hip_run_batches -- are in flight together)
   struct SlabBufs { DevBuf ids, meta, blockCounts, blockBase; };
@@ -167,6 +188,17 @@ static int realloc_tally(i3rc_hip_integrator *h) {
 // Batches launched ahead by i3rc_hip_compute_batch read the handle's device arrays: whatever changes those (tables,
 // parameters, surface, directions, tuning) waits for them first and forgets them.
 static void drop_lookahead(i3rc_hip_integrator *h) {
+  for (const int k : h->aheadGroups) {   // fused groups launched ahead: called off (their waves take no further chunks), then awaited
+    auto &g = h->fused[k];
+    if (g.abortFlag) __atomic_store_n(g.abortFlag, 1, __ATOMIC_RELEASE);
+  }
+  for (const int k : h->aheadGroups) {
+    auto &g = h->fused[k];
+    (void)hipStreamSynchronize(g.stream);
+    g.count = 0;
+  }
+  h->aheadGroups.clear();
+  h->aheadGroupSize = 0;
   for (const auto &a : h->aheadQueue) {
     (void)hipStreamSynchronize(h->pipe[a.slot].stream);
     h->pipe[a.slot].batch = -1;
@@ -352,6 +384,13 @@ int i3rc_hip_destroy(i3rc_hip_integrator *h) {
     if (sl.done) (void)hipEventDestroy(sl.done);
     if (sl.pinned) (void)hipHostFree(sl.pinned);
   }
+  for (auto &g : h->fused) {
+    if (g.abortFlag) __atomic_store_n(g.abortFlag, 1, __ATOMIC_RELEASE);
+    if (g.stream) { (void)hipStreamSynchronize(g.stream); (void)hipStreamDestroy(g.stream); }
+    if (g.done) (void)hipEventDestroy(g.done);
+    if (g.pinned) (void)hipHostFree(g.pinned);
+    if (g.abortFlag) (void)hipHostFree(g.abortFlag);
+  }
   for (int i = 0; i < i3rc_hip_integrator::kEventRing; ++i) {
     if (h->evStart[i]) (void)hipEventDestroy(h->evStart[i]);
     if (h->evStop[i]) (void)hipEventDestroy(h->evStop[i]);
@@ -517,6 +556,14 @@ int i3rc_hip_select_kernel(i3rc_hip_integrator *h, int variant) {
   return 0;
 }
 
+int i3rc_hip_set_batch_fusion(i3rc_hip_integrator *h, int mode) {
+  if (!h) return 1;
+  drop_lookahead(h);
+  if (mode < -1 || mode > 1) return h->fail("i3rc_hip_set_batch_fusion: mode is -1 (automatic), 0 (never) or 1 (whenever possible)");
+  h->fusion = mode;
+  return 0;
+}
+
 /* Older name of i3rc_hip_select_kernel(h, on ? I3RC_KERNEL_GENERAL : I3RC_KERNEL_AUTO). */
 int i3rc_hip_force_general_kernel(i3rc_hip_integrator *h, int on) {
   return i3rc_hip_select_kernel(h, on ? I3RC_KERNEL_GENERAL : I3RC_KERNEL_AUTO);
@@ -554,7 +601,7 @@ bool common_class(const i3rc_hip_integrator *h, int srcKind) {
 
 size_t ncell_bytes(const i3rc_hip_integrator *h) { return sizeof(float) * (size_t)h->nx * h->ny * h->nz; }
 
-int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan) {
+int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false) {
   DevProblem &P = plan.P;
   std::memset(&P, 0, sizeof(P));
   for (int c = 0; c < h->ncomp; ++c)
@@ -619,11 +666,12 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan) {
   if (lds > kLdsBudget) return h->fail("domain edge vectors do not fit in LDS");
   const size_t budget = kLdsBudget;
   P.ldsTallies = 0;
-  if (lds + 3 * ncol * sizeof(float) <= kLdsBudget / 2) { P.ldsTallies = 1; lds += 3 * ncol * sizeof(float); }
+  // (a fused multi-batch launch tallies per batch, straight into global memory: no partial sums in LDS)
+  if (!fused && lds + 3 * ncol * sizeof(float) <= kLdsBudget / 2) { P.ldsTallies = 1; lds += 3 * ncol * sizeof(float); }
   P.ldsIntensity = 0;
   {
     const size_t nInt = (size_t)(h->ncomp + 1) * h->nDir * ncol * sizeof(float);
-    if (h->nDir > 0 && nInt <= 16 * 1024 && lds + nInt <= kLdsBudget) { P.ldsIntensity = 1; lds += nInt; }
+    if (!fused && h->nDir > 0 && nInt <= 16 * 1024 && lds + nInt <= kLdsBudget) { P.ldsIntensity = 1; lds += nInt; }
   }
   P.ldsGrid = 0;
   if (lds + ncell * sizeof(float) <= budget) { P.ldsGrid = 1; lds += ncell * sizeof(float); }
@@ -760,6 +808,170 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
   return 0;
 }
 
+
+// ---- fused multi-batch launches ---------------------------------------------------------------------------------------
+// out[b][e] = sum over the replicas r of blocks[b * R + r][e]
+__global__ void __launch_bounds__(256) reduce_replicas_kernel(const double *blocks, double *out, long long nBlocksOut, int R, long long stride) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nBlocksOut * stride) return;
+  const long long b = i / stride, e = i - b * stride;
+  const double *src = blocks + (size_t)b * R * stride + e;
+  double v = 0.0;
+  for (int r = 0; r < R; ++r) v += src[(size_t)r * stride];
+  out[i] = v;
+}
+
+// Can the batches of a driver's loop share one grid?  The specialised flux kernels only (so far): the common problem class
+// without radiance directions, production streams.
+bool fusable(const i3rc_hip_integrator *h, int64_t nPhotons) {
+  static const bool envOff = std::getenv("I3RC_FUSED") && std::atoi(std::getenv("I3RC_FUSED")) == 0;
+  if (envOff || h->fusion == 0) return false;
+  return common_class(h, 0) && h->nDir == 0 && h->kernelVariant != I3RC_KERNEL_GENERAL && nPhotons < ((int64_t)1 << 31) &&
+         h->layout.total < ((int64_t)1 << 31);
+}
+
+// Replicas of a batch's tally block: enough that the hot words of a small domain (fluxUp / fluxDown of nx * ny columns) are
+// spread over some 256 cache lines -- measured (tools/microbench/atomic_rate.hip): 64 hot float64 in one block take 4.1e8
+// atomics/s from the whole chip, in 8 blocks 1.7e9, in 64 blocks 1.3e10; the step cloud needs 3.4e9.
+int fused_replicas(const i3rc_hip_integrator *h) {
+  const int64_t ncol = (int64_t)h->nx * h->ny, hotLines = 2 * ((ncol + 15) / 16);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(64, 256 / hotLines));
+}
+
+// Batches per group: device memory for the blocks (<= 1 GiB) and the pinned copy (<= 256 MiB) bound it; beyond that a
+// group wants some 1e8 photons (its tail, a millisecond, is covered by the next group anyway).
+int fused_group_size(const i3rc_hip_integrator *h, int nBatches, int64_t nPhotons) {
+  const int64_t blockBytes = h->layout.total * 8, R = fused_replicas(h);
+  int64_t g = std::min<int64_t>(((int64_t)1 << 30) / (blockBytes * R), ((int64_t)256 << 20) / blockBytes);
+  static const int64_t target = std::getenv("I3RC_FUSED_GROUP_PHOTONS") ? std::atoll(std::getenv("I3RC_FUSED_GROUP_PHOTONS")) : 100000000ll;
+  g = std::min<int64_t>(g, (target + nPhotons - 1) / nPhotons);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(g, nBatches));
+}
+
+int ready_fused_slot(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g, int count, int R) {
+  const size_t outBytes = (size_t)count * h->layout.total * sizeof(double);
+  if (!g.stream) HIPCHK(h, hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+  if (!g.done) HIPCHK(h, hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+  if (!g.counter.p) HIPCHK(h, g.counter.alloc(sizeof(unsigned long long)));
+  if (!g.abortFlag) HIPCHK(h, hipHostMalloc((void **)&g.abortFlag, sizeof(int), hipHostMallocCoherent | hipHostMallocMapped));
+  if (g.pinnedBytes < outBytes) {
+    if (g.pinned) { HIPCHK(h, hipHostFree(g.pinned)); g.pinned = nullptr; g.pinnedBytes = 0; }
+    HIPCHK(h, hipHostMalloc((void **)&g.pinned, outBytes, hipHostMallocDefault));
+    g.pinnedBytes = outBytes;
+  }
+  if (g.blocks.bytes < outBytes * R) HIPCHK(h, g.blocks.alloc(outBytes * R));
+  if (R > 1 && g.compact.bytes < outBytes) HIPCHK(h, g.compact.alloc(outBytes));
+  return 0;
+}
+
+// One group: `count` batches with the keys (seed0, seed1 .. seed1 + count - 1), nPhotons photons each, traced by ONE grid;
+// zero, trace, sum the replicas, copy to the slot's pinned buffer -- all asynchronous on the slot's stream.
+int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g, uint32_t seed0, uint32_t seed1, int count,
+                       int64_t nPhotons, const i3rc_source *src, bool timeIt) {
+  const int R = fused_replicas(h);
+  if (ready_fused_slot(h, g, count, R)) return 1;
+  hipStream_t const callerStream = h->stream;
+  double *const callerTally = h->tally;
+  h->stream = g.stream; h->tally = (double *)g.blocks.p;   // (make_problem reads these two)
+  LaunchPlan plan;
+  RunArgs A;
+  std::memset(&A, 0, sizeof(A));
+  A.seed0 = seed0; A.seed1 = seed1; A.firstPhoton = 0; A.nPhotons = nPhotons;
+  A.workCounter = (unsigned long long *)g.counter.p;
+  int rc = make_problem(h, plan, true) || upload_source(h, src, nPhotons, A);
+  h->stream = callerStream; h->tally = callerTally;
+  if (rc) return 1;
+  // (chunks: a wave takes this many photons of ONE batch per visit of the work counter; a lane hands its counts over when
+  // its batch changes, so longer chunks mean fewer atomics, shorter ones a shorter end of the launch)
+  static const int chunkEnv = std::getenv("I3RC_FUSED_CHUNK") ? std::max(64, std::atoi(std::getenv("I3RC_FUSED_CHUNK"))) : 0;
+  A.chunk = chunkEnv > 0 ? chunkEnv : 512;
+  if ((int64_t)A.chunk > nPhotons) A.chunk = (int)std::max<int64_t>(64, nPhotons);
+  A.nBatches = (unsigned)count;
+  A.chunksPerBatch = (unsigned)((nPhotons + A.chunk - 1) / A.chunk);
+  A.replicas = R;
+  A.blockStride = h->layout.total;
+  A.abortFlag = g.abortFlag;
+  if ((uint64_t)count * R >= ((uint64_t)1 << 31)) return h->fail("fused launch: too many tally blocks");
+  using Kernel = void (*)(DevProblem, RunArgs, int, int);
+  static const Kernel kernels[3] = {photon_kernel<PhiloxBatchStream, false, false, GRID_LDS>, photon_kernel<PhiloxBatchStream, false, false, GRID_GLOBAL>,
+                                    photon_kernel<PhiloxBatchStream, false, false, GRID_BRICKS>};
+  const int place = plan.P.ldsGrid ? GRID_LDS : (plan.P.extBrick ? GRID_BRICKS : GRID_GLOBAL);
+  const void *fn = (const void *)kernels[place];
+  {
+    static const char *const placeName[3] = {"GRID_LDS", "GRID_GLOBAL", "GRID_BRICKS"};
+    static thread_local char name[96];
+    std::snprintf(name, sizeof(name), "photon_kernel<PhiloxBatchStream, false, false, %s>", placeName[place]);
+    h->lastKernelName = name;
+  }
+  int perCU = h->blocksPerCU;
+  if (perCU <= 0) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, plan.ldsBytes) != hipSuccess || occ < 1) occ = 2;
+    perCU = std::min(occ, 8);
+    if (place == GRID_BRICKS) perCU = std::min(perCU, ncell_bytes(h) > ((size_t)16 << 20) ? 4 : 5);   // (as in launch())
+  }
+  if (plan.ldsBytes > 48 * 1024)
+    HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.ldsBytes));
+  long long blocks = (long long)h->numCU * perCU;
+  const long long need = ((long long)count * nPhotons + 255) / 256;
+  if (blocks > need) blocks = std::max(1ll, need);
+  const size_t outBytes = (size_t)count * h->layout.total * sizeof(double);
+  *g.abortFlag = 0;
+  HIPCHK(h, hipMemsetAsync(g.blocks.p, 0, outBytes * R, g.stream));
+  HIPCHK(h, hipMemsetAsync(g.counter.p, 0, sizeof(unsigned long long), g.stream));
+  const int slot = (int)(h->timedLaunches % i3rc_hip_integrator::kEventRing);
+  if (timeIt) HIPCHK(h, hipEventRecord(h->evStart[slot], g.stream));
+  {
+    const int evThreshold = h->evThreshold > 0 ? h->evThreshold : -40;
+    hipLaunchKernelGGL(kernels[place], dim3((unsigned)blocks), dim3(256), plan.ldsBytes, g.stream, plan.P, A, evThreshold, -24);
+  }
+  HIPCHK(h, hipGetLastError());
+  if (timeIt) { HIPCHK(h, hipEventRecord(h->evStop[slot], g.stream)); h->timedLaunches++; }
+  const double *result = (const double *)g.blocks.p;
+  if (R > 1) {
+    const long long n = (long long)count * h->layout.total;
+    hipLaunchKernelGGL(reduce_replicas_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream, (const double *)g.blocks.p,
+                       (double *)g.compact.p, (long long)count, R, (long long)h->layout.total);
+    HIPCHK(h, hipGetLastError());
+    result = (const double *)g.compact.p;
+  }
+  HIPCHK(h, hipMemcpyAsync(g.pinned, result, outBytes, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(h, hipEventRecord(g.done, g.stream));
+  g.count = count; g.seed1 = seed1; g.next = 0;
+  return 0;
+}
+
+int run_batches_fused(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int nBatches, int64_t nPhotons, const i3rc_source *src,
+                      double *hostTallies) {
+  const int G = fused_group_size(h, nBatches, nPhotons);
+  const size_t blockBytes = (size_t)h->layout.total * sizeof(double);
+  drop_lookahead(h);
+  HIPCHK(h, hipStreamSynchronize(h->stream));   // whatever the caller had in flight on the handle's stream comes first
+  for (auto &g : h->fused) g.count = 0;
+  int rc = 0;
+  auto collect = [&](i3rc_hip_integrator::FusedSlot &g) -> int {
+    if (g.count == 0) return 0;
+    HIPCHK(h, hipEventSynchronize(g.done));
+    std::memcpy(hostTallies + (size_t)g.first * (size_t)h->layout.total, g.pinned, (size_t)g.count * blockBytes);
+    g.count = 0;
+    return 0;
+  };
+  int k = 0;
+  for (int first = 0; first < nBatches && !rc; first += G, ++k) {
+    auto &g = h->fused[k % i3rc_hip_integrator::kFusedSlots];
+    if ((rc = collect(g))) break;
+    const int count = std::min(G, nBatches - first);
+    rc = launch_fused_group(h, g, seed0, seed1 + (uint32_t)first, count, nPhotons, src, true);
+    if (!rc) g.first = first;
+  }
+  for (int j = 0; j < i3rc_hip_integrator::kFusedSlots; ++j) {   // drain in launch order (also after a failure: nothing stays in flight)
+    auto &g = h->fused[(k + j) % i3rc_hip_integrator::kFusedSlots];
+    if (rc) { if (g.stream) (void)hipStreamSynchronize(g.stream); g.count = 0; }
+    else rc = collect(g);
+  }
+  return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -800,6 +1012,10 @@ int i3rc_hip_run_batches(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1,
   if (src->kind != 0) return h->fail("i3rc_hip_run_batches: Directional photon streams only (explicit streams differ from batch to batch)");
   if (nPhotons <= 0) return h->fail("setIllumination: must ask for non-negative number of photons.");
   HIPCHK(h, hipSetDevice(h->device));
+  // batches that the specialised flux kernels run share one grid, group by group (see FusedSlot); one long batch alone, or
+  // batches of a size at which a launch's tail no longer matters, go one launch each as before
+  if (fusable(h, nPhotons) && (h->fusion == 1 || (nBatches >= 2 && nPhotons <= 20000000)))
+    return run_batches_fused(h, seed0, seed1, nBatches, nPhotons, src, hostTallies);
   const int K = std::min(nBatches, inFlight <= 0 ? 6 : std::min(inFlight, (int)i3rc_hip_integrator::kMaxInFlight));
   const size_t bytes = (size_t)h->layout.total * sizeof(double);
   drop_lookahead(h);               // (i3rc_hip_compute_batch shares the slots)

@@ -67,28 +67,33 @@ __device__ __forceinline__ ColdArgs cold_args() {
 }
 
 
-template <class PR>
+// BATCHED (fused multi-batch launch): every lane tallies into the block of ITS photon's batch (blk, worked out once per event
+// phase), straight in global memory -- the hot words of a small domain are spread over several replicas of the block instead
+// of being gathered in LDS, whose partial sums would have to be kept per batch.
+template <class PR, bool BATCHED = false>
 struct Tally {
   const PR &P;
   const Lds &L;
+  double *blk;   // BATCHED: the lane's tally block (else the launch's one buffer, P.tally)
   // (the tally buffer's base addresses stay in scalar registers: reading them from the kernarg segment at every
   // tally -- see cold_args -- was measured: -8 % where the tallies go to global memory, nothing gained elsewhere)
+  __device__ __forceinline__ double *base() const { return BATCHED ? blk : P.tally; }
   __device__ __forceinline__ void down(int col, float w) const {
-    if (P.ldsTallies) lds_add(&L.tDown[col], w); else add_global(P.tally + P.oDown + col, w);
+    if (!BATCHED && P.ldsTallies) lds_add(&L.tDown[col], w); else add_global(base() + P.oDown + col, w);
   }
   // intensityByComponent(ix, iy, d, comp) (:574-579, :662-667)
   __device__ __forceinline__ void radiance(int comp, int d, int col, float v) const {
     const int i = (comp * P.nDir + d) * (P.nx * P.ny) + col;
-    if (P.ldsIntensity) lds_add(&L.tInt[i], v); else add_global(P.tally + P.oInt + i, v);
+    if (!BATCHED && P.ldsIntensity) lds_add(&L.tInt[i], v); else add_global(base() + P.oInt + i, v);
   }
   // upward flux at the top (:513) or downward flux at the surface (:531): one atomic for either
   __device__ __forceinline__ void boundary(bool top, int col, float w) const {
-    if (P.ldsTallies) lds_add((top ? L.tUp : L.tDown) + col, w);
-    else add_global(P.tally + (top ? P.oUp : P.oDown) + col, w);
+    if (!BATCHED && P.ldsTallies) lds_add((top ? L.tUp : L.tDown) + col, w);
+    else add_global(base() + (top ? P.oUp : P.oDown) + col, w);
   }
   __device__ __forceinline__ void absorbed(int col, int cell, float w) const {
-    if (P.ldsTallies) lds_add(&L.tAbs[col], w); else add_global(P.tally + P.oAbs + col, w);
-    add_global(P.tally + P.oVol + cell, w);
+    if (!BATCHED && P.ldsTallies) lds_add(&L.tAbs[col], w); else add_global(base() + P.oAbs + col, w);
+    add_global(base() + P.oVol + cell, w);
   }
 };
 
@@ -155,7 +160,7 @@ __device__ __forceinline__ void intensity_contribution(const PR &P, const Lds &L
       add_global(P.tally + P.oExc + component * P.nDir + d, con - P.maxContrib);
       con = P.maxContrib;
     }
-    const Tally<PR> tl{P, L};
+    const Tally<PR> tl{P, L, nullptr};
     tl.radiance(component, d, (r.iy - 1) * P.nx + (r.ix - 1), con);
   }
 }
@@ -169,6 +174,10 @@ struct RngInit<PhiloxStream> {
   static __device__ __forceinline__ void start(PhiloxStream &g, const AR &A, long long i) {
     g.start((uint64_t)(A.firstPhoton + i));
   }
+};
+template <>
+struct RngInit<PhiloxBatchStream> {
+  static __device__ __forceinline__ void init(PhiloxBatchStream &g, const RunArgs &A) { g.init(A.seed0, A.seed1); }
 };
 template <>
 struct RngInit<ReplayStream> {
@@ -194,6 +203,28 @@ struct Reservoir {
     const long long b = (long long)(((unsigned long long)hi << 32) | lo);
     next = b < nPhotons ? b : nPhotons;
     end = b + chunk < nPhotons ? b + chunk : nPhotons;
+  }
+  // Fused multi-batch launch: the work counter hands out chunk numbers; a chunk lies within one batch (RunArgs).  `batch` is
+  // the batch of the photons in hand (wave-uniform); end < 0 once the launch's chunks have run out or the host has called
+  // the launch off (a look-ahead that is not wanted any more ends within one chunk per wave).
+  unsigned batch;
+  __device__ __forceinline__ void refill_batched() {   // call in uniform control flow only
+    const ColdArgs k = cold_args();
+    unsigned long long *const counter = k->A.workCounter;
+    const unsigned chunk = (unsigned)k->A.chunk, perBatch = k->A.chunksPerBatch;
+    const unsigned long long total = (unsigned long long)k->A.nBatches * perBatch;
+    const long long nPhotons = k->A.nPhotons;
+    unsigned long long c = total;
+    if ((threadIdx.x & 63) == 0 && __hip_atomic_load(k->A.abortFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0)
+      c = atomicAdd(counter, 1ull);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)__shfl((unsigned)c, 0, 64));
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)__shfl((unsigned)(c >> 32), 0, 64));
+    c = ((unsigned long long)hi << 32) | lo;
+    if (c >= total) { next = 0; end = -1; return; }
+    const unsigned b = (unsigned)(c / perBatch), j = (unsigned)(c - (unsigned long long)b * perBatch);
+    batch = b;
+    next = (long long)j * chunk;
+    end = next + chunk < nPhotons ? next + chunk : nPhotons;
   }
   // XCD-aware order: positions in RunArgs::slabIds instead of photon numbers.  A wave takes from the slab of its own XCD
   // (whose L2 then holds that eighth of the field) and goes round the other slabs when that one has run dry.  How many
@@ -342,6 +373,8 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
   __syncthreads();
 
   constexpr bool REPLAY = Rng::kReplay;        // per-photon fates are recorded by i3rc_hip_run_replay only
+  constexpr bool BATCHED = Rng::kBatched;      // fused multi-batch launch: every lane knows its photon's batch (rng.batch)
+  static_assert(!BATCHED || (!INTENSITY && !GENERAL), "fused multi-batch launches: specialised flux kernels");
   constexpr bool NEED_PID = REPLAY || GENERAL; // explicit photon sources are indexed by photon number
   const size_t ncell = (size_t)P.nx * P.ny * P.nz;
   const bool rayTracing = GENERAL ? (P.useRayTracing != 0) : true;
@@ -374,10 +407,48 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
   constexpr bool SLABS = GRID == GRID_BRICKS && !Rng::kReplay;
   __shared__ int slabsTried[4];            // per wave (see Reservoir::refill_slabs)
   Reservoir res;
-  if (SLABS && A.slabIds != nullptr) {
+  if constexpr (BATCHED) res.refill_batched();
+  else if (SLABS && A.slabIds != nullptr) {
     if ((threadIdx.x & 63) == 0) slabsTried[threadIdx.x >> 6] = 0;
     res.refill_slabs(&slabsTried[threadIdx.x >> 6]);
   } else res.refill();
+
+  // ---- BATCHED: work counters per batch --------------------------------------------------------------------------------
+  // The wave's scalar counters (wc) cannot tell the batches of its lanes apart: they only steer the thresholds here.  What
+  // a batch's counter block is owed is gathered per LANE -- voxel steps in a register of their own, scatterings | roulette
+  // plays and surface arrivals | exits through the top as two pairs of 16-bit counts, the deviates in the stream's own
+  // count -- and handed over (a handful of atomics) when the lane's next photon belongs to another batch, when a count is
+  // about to leave its 16 bits, and at the end.  Tracer calls need no count: every photon ends in exactly one of four ways
+  // (top, surface, roulette, tracer error) and every event that does not end it starts a trace, so a batch's calls are its
+  // scatterings + surface arrivals + exits through the top + dropped photons.  Photons are counted where they are handed
+  // out (wave-uniform: resTaken), dropped ones at once (rare).
+  uint32_t accSteps = 0u, accA = 0u, accB = 0u;   // steps; scatterings | roulette << 16; surface arrivals | exits top << 16
+  uint32_t resTaken = 0u;                         // photons of the reservoir's batch handed out since the last hand-over
+  const unsigned rep = BATCHED ? blockIdx.x % (unsigned)A.replicas : 0u;
+  auto lane_block = [&](uint32_t b) -> double * {   // tally block of batch b for this workgroup (RunArgs)
+    const ColdArgs k = cold_args();
+    return k->P.tally + (size_t)(b * (unsigned)k->A.replicas + rep) * (size_t)(unsigned)k->A.blockStride;
+  };
+  auto flush_lane = [&]() {                         // (the lanes that call it; uses the batch the lane has had so far)
+    if constexpr (BATCHED) {
+      double *const c = lane_block(rng.batch) + cold_args()->P.oCnt;
+      const uint32_t scat = accA & 0xffffu, roul = accA >> 16, surf = accB & 0xffffu, top = accB >> 16;
+      if (accSteps) unsafeAtomicAdd(c + I3RC_CNT_CELL_STEPS, (double)accSteps);
+      if (scat) unsafeAtomicAdd(c + I3RC_CNT_SCATTERINGS, (double)scat);
+      if (roul) unsafeAtomicAdd(c + I3RC_CNT_ROULETTE, (double)roul);
+      if (surf) unsafeAtomicAdd(c + I3RC_CNT_SURFACE_HITS, (double)surf);
+      if (top) unsafeAtomicAdd(c + I3RC_CNT_EXITS_TOP, (double)top);
+      if (scat + surf + top) unsafeAtomicAdd(c + I3RC_CNT_TRACER_CALLS, (double)(scat + surf + top));
+      const uint32_t draws = rng.take_used();
+      if (draws) unsafeAtomicAdd(c + I3RC_CNT_RNG_DRAWS, (double)draws);
+      accSteps = accA = accB = 0u;
+    }
+  };
+  auto hand_over_taken = [&](uint32_t b) {          // uniform control flow
+    if (resTaken != 0u && (threadIdx.x & 63) == 0)
+      unsafeAtomicAdd(lane_block(b) + cold_args()->P.oCnt + I3RC_CNT_PHOTONS, (double)resTaken);
+    resTaken = 0u;
+  };
 
   // ---- Radiance (local estimate) through a per-wave RAY QUEUE -------------------------------------------------------
   // A scattering or reflection event does not trace its D local-estimate (shadow) rays itself and the photon does not
@@ -474,7 +545,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
   auto flush_counters = [&]() {
     adapt_thresholds();
     raysSeen = 0u;
-    if ((threadIdx.x & 63) == 0) {
+    if (!BATCHED && (threadIdx.x & 63) == 0) {   // (BATCHED: per lane and batch, see flush_lane)
       const uint32_t c[9] = {wc.photons, wc.dropped, wc.steps, wc.scat, wc.surf, wc.top, wc.roul, wc.shadow, wc.calls};
       const ColdArgs ka = cold_args();
       double *const counters = ka->P.tally + ka->P.oCnt;
@@ -556,7 +627,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
                 proj += rec[7 * cap] * L.dirCos[3 * dIdx]; proj += rec[8 * cap] * L.dirCos[3 * dIdx + 1]; proj += rec[9 * cap] * uz;
                 if (fabsf(proj) > 1.0f) proj = copysignf(1.0f, proj);
                 const float ang = acosf(proj);
-                const int pfi = info >> 16;
+                const int pfi = (int)((unsigned)info >> 16);   // (table entries up to 65535: the record's upper half is unsigned)
                 const CompTables ct = GENERAL ? load_tables(Px.comp[comp - 1]) : load_tables(Px.comp0);
                 const float *tab = ((info & 0x100) ? ct.fwdOrig : ct.fwd) + (size_t)(pfi - 1) * ct.nFwd;
                 norm = fast_div(lookup_phase_fast(tab, ct.nFwd, ang), (4.0f * kPi) * fabsf(uz));
@@ -617,7 +688,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
             PROF_BEGIN();
             const ColdArgs kx = cold_args();
             const auto &Px = kx->P;
-            const Tally<ColdProblem> tally{Px, L};
+            const Tally<ColdProblem> tally{Px, L, nullptr};
             bool secondLeg = false;
             if (rst == R_ENDED) {                                           // the ray that just ended (:1517-1596)
               const float tauB = sr.acc;
@@ -752,7 +823,13 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
       const ColdArgs ke = cold_args();
       const auto &Pe = ke->P;
       const auto &Ae = ke->A;
-      const Tally<ColdProblem> tally{Pe, L};
+      if constexpr (BATCHED) {   // a 16-bit count about to overflow (one event adds at most one to each): hand over now
+        const bool full = ((accA | accB) & 0x80008000u) != 0u || accSteps >= 0x80000000u;
+        if (__ballot(full) != 0ull) { if (full) flush_lane(); }
+      }
+      double *laneBlk = nullptr;
+      if constexpr (BATCHED) laneBlk = lane_block(rng.batch);
+      const Tally<ColdProblem, BATCHED> tally{Pe, L, laneBlk};
       PROF_BEGIN();
       // ---- part A: endings that need no random number -- tracer drop, exit through the top, arrival at a black
       //      surface -- are tallied first so that the lanes can be given their next photon before the wave
@@ -765,6 +842,13 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
       wc.dropped += count_lanes(dropped);
       wc.top += count_lanes(atTop);
       wc.surf += count_lanes(atSurface);
+      if constexpr (BATCHED) {
+        accB += (atSurface ? 1u : 0u) + (atTop ? 0x10000u : 0u);
+        if (dropped) {
+          unsafeAtomicAdd(tally.blk + Pe.oCnt + I3RC_CNT_DROPPED, 1.0);
+          unsafeAtomicAdd(tally.blk + Pe.oCnt + I3RC_CNT_TRACER_CALLS, 1.0);
+        }
+      }
       if (dropped || atTop || atBlack) {
         // one merged branch for the three endings: a single tally atomic and a single bookkeeping block
         if (!dropped) {
@@ -788,6 +872,35 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
       // ---- part B (uniform): hand out photon indices from the wave's reservoir
       const bool isNew = wantEvent && st == ST_NEW;
       const unsigned long long newMask = __ballot(isNew);
+      if constexpr (BATCHED) {
+        if (newMask != 0ull) {
+          int need = __popcll(newMask);
+          int rank = lanes_below(newMask);
+          long long mine = -1;
+          unsigned mineBatch = 0u;
+          for (;;) {   // (uniform; a batch's last chunk may be short of `need`: then the next chunk serves the rest)
+            const long long left = res.end - res.next;
+            const int avail = left > 0 ? (left < 64 ? (int)left : 64) : 0;
+            const int take = avail < need ? avail : need;
+            if (isNew && mine < 0 && rank >= 0 && rank < take) { mine = res.next + rank; mineBatch = res.batch; }
+            res.next += take; resTaken += (unsigned)take; wc.photons += (unsigned)take;
+            need -= take; rank -= take;
+            if (need == 0 || res.end < 0) break;
+            if ((++refills & 3u) == 0u || wc.steps > 0x40000000u) flush_counters();   // (re-fits the thresholds; the counts go per lane)
+            else adapt_thresholds();
+            const unsigned oldBatch = res.batch;
+            res.refill_batched();
+            if (res.end < 0 || res.batch != oldBatch) hand_over_taken(oldBatch);
+          }
+          if (isNew) {
+            if (mine < 0) st = ST_DONE;   // (only when the launch has no chunks left)
+            else {
+              if (mineBatch != rng.batch && (accSteps | accA | accB) != 0u) flush_lane();
+              rng.start((uint64_t)(Ae.firstPhoton + mine), mineBatch);
+            }
+          }
+        }
+      } else
       if (newMask != 0ull) {
         int need = __popcll(newMask);
         int rank = lanes_below(newMask);
@@ -814,7 +927,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
           if (mine < 0) st = ST_DONE;
           else {
             if (slabs) mine = (long long)Ae.slabIds[mine];   // position in the sorted list -> photon number
-            RngInit<Rng>::start(rng, Ae, mine);
+            if constexpr (!BATCHED) RngInit<Rng>::start(rng, Ae, mine);
             if (NEED_PID) pid = mine;
           }
         }
@@ -948,7 +1061,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
               if (defer) {                                                // :654-668: pushed after this event, traced in ray mode
                 pendingShadow = true; wI = w;
                 inDx = r.dx; inDy = r.dy; inDz = r.dz;                     // incoming direction
-                evInfo = comp | ((Pe.useHybrid && order <= Pe.numOrdersOrig) ? 0x100 : 0) | (pfi << 16);
+                evInfo = comp | ((Pe.useHybrid && order <= Pe.numOrdersOrig) ? 0x100 : 0) | (int)((unsigned)pfi << 16);
               } else if (INTENSITY)
                 intensity_contribution<GRID>(Pe, L, rng, nested, w, r.x, r.y, r.z, r.ix, r.iy, r.iz, r.dx, r.dy, r.dz, comp, order);
               if (Pe.useRR && w < 0.5f) {                                  // :673-680
@@ -1000,6 +1113,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
         }
         qTail += (unsigned)__popcll(pushMask);
       }
+      if constexpr (BATCHED) accA += (didScatter ? 1u : 0u) + (didRoulette ? 0x10000u : 0u);
       wc.scat += count_lanes(didScatter);
       wc.roul += count_lanes(didRoulette);
       wc.calls += count_lanes(startedTrace);
@@ -1014,6 +1128,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
       wc.steps += nTracing;
       PROF_BEGIN();
       if (tracing) {
+        if constexpr (BATCHED) accSteps++;
         const StepResult s = trace_step<GRID>(P, L, r, true);
         // (an exit through the top, or onto a black surface, ends the photon: such lanes wait for the turnover quorum)
         if (s != STEP_CONTINUE)
@@ -1038,6 +1153,11 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
 #endif
 
   // ------------------------------------------------------------------ epilogue: flush tallies + counters
+  if constexpr (BATCHED) {   // what the lanes still hold for their last batches; the tallies themselves are in global memory already
+    flush_lane();
+    hand_over_taken(res.batch);
+    return;
+  }
   __syncthreads();
   {
     const ColdArgs ka = cold_args();   // (offsets and sizes straight from the kernarg segment: see cold_args)

@@ -52,18 +52,24 @@ __host__ __device__ inline float u32_to_unit_float(uint32_t u) {
 // fourth counter word (kernels.hpp, ray mode).  Which word serves which purpose is this code's own convention: the production streams are not the
 // reference's Mersenne Twister sequence anyway, and every production kernel follows the same convention (tests
 // compare them photon by photon).  The replay stream hands out the reference's deviates in the reference's order.
-struct PhiloxStream {
+// BATCHED (fused multi-batch launches, kernels.hpp): the lanes of a wave carry photons of DIFFERENT batches of a driver's
+// loop -- the key's second word is seed1 + the lane's batch number (the driver's seed = (/iseed, batch/)), a vector value:
+// its ten round keys cost ten vector adds per block, the price of filling one batch's tail with the next batch's photons.
+template <bool BATCHED>
+struct PhiloxStreamT {
   static constexpr bool kReplay = false;
+  static constexpr bool kBatched = BATCHED;
   uint32_t k0, k1;           // key: the same for every photon of a launch (wave-uniform, lives in scalar registers)
+  uint32_t batch;            // BATCHED: batch of this lane's photon, relative to the launch's first (else unused, 0)
   uint32_t id_lo, id_hi, block;
   uint32_t e0, e1, e2, e3;   // the event's block
   uint32_t b0, b1, b2, b3;   // block behind next()
   int have;                  // unused words of that block: next() hands out b[4 - have]
-  uint32_t used;             // deviates consumed by this lane (all its photons)
+  uint32_t used;             // deviates consumed by this lane (all its photons; BATCHED: since the lane's last hand-over)
 
   // once per lane, in uniform control flow
   __device__ inline void init(uint32_t seed0, uint32_t seed1) {
-    k0 = seed0; k1 = seed1;
+    k0 = seed0; k1 = seed1; batch = 0u;
     id_lo = id_hi = 0u; block = 0u; have = 0; used = 0u; b0 = b1 = b2 = b3 = 0u; e0 = e1 = e2 = e3 = 0u;
   }
   // next photon of this lane
@@ -71,6 +77,8 @@ struct PhiloxStream {
     id_lo = (uint32_t)photon; id_hi = (uint32_t)(photon >> 32);
     block = 0u; have = 0;
   }
+  __device__ inline void start(uint64_t photon, uint32_t photonBatch) { start(photon); batch = photonBatch; }
+  __device__ inline uint32_t take_used() { const uint32_t u = used; used = 0u; return u; }   // BATCHED: per-batch hand-over
   __device__ inline void close() {}
   // Philox coordinates of the event in progress (its block was made by begin_event): a local-estimate ray of this
   // event draws from the block with the same first three counter words and its direction number + 1 in the fourth
@@ -86,7 +94,7 @@ struct PhiloxStream {
     // (which then spill).
     uint32_t s0 = k0, s1 = k1;
     asm volatile("" : "+s"(s0), "+s"(s1));
-    const Philox4 o = philox4x32_10(id_lo, id_hi, block, 0u, s0, s1);
+    const Philox4 o = philox4x32_10(id_lo, id_hi, block, 0u, s0, BATCHED ? s1 + batch : s1);
     block++;
     return o;
   }
@@ -126,9 +134,14 @@ struct PhiloxStream {
   }
 };
 
+// (types of their own, not aliases: kernel names -- rocprofv3, tools/kernel_resources.py -- keep the plain form)
+struct PhiloxStream : PhiloxStreamT<false> {};
+struct PhiloxBatchStream : PhiloxStreamT<true> {};
+
 // Test stream: deviates come from a buffer (the reference's MT19937 floats); see i3rc_hip_run_replay.
 struct ReplayStream {
   static constexpr bool kReplay = true;   // consume deviates exactly where the reference does
+  static constexpr bool kBatched = false;
   const float *buf;
   int64_t pos, end;
   int64_t photonStart;

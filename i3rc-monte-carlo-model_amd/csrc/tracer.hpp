@@ -80,6 +80,16 @@ struct RunArgs {
   float solarDx, solarDy, solarDz;    // makeDirectionCosines(solarMu, solarPhi) evaluated once on the host
   int chunk;                          // photon indices a wave reserves per visit of the work counter
   const float *sx, *sy, *sz, *smu, *sphi;   // explicit stream (device)
+  // Fused multi-batch launch (PhiloxBatchStream kernels; i3rc_hip_run_batches): nBatches batches of a driver's loop in
+  // ONE grid.  Batch b has the key (seed0, seed1 + b) and the photons firstPhoton .. firstPhoton + nPhotons - 1; the work
+  // counter counts CHUNKS (chunk c = photons [j chunk, (j + 1) chunk) of batch c / chunksPerBatch, j = c mod chunksPerBatch:
+  // a chunk never straddles two batches).  Tallies of batch b go to block b * replicas + r of the tally buffer (blocks of
+  // blockStride float64 in the handle's tally layout), r = workgroup number mod replicas: a small domain's few hot
+  // words take 4e8 float64 atomics/s in one block and 1.3e10/s in 64 of them (tools/microbench/atomic_rate.hip).
+  unsigned nBatches, chunksPerBatch;
+  int replicas;
+  long long blockStride;
+  const int *abortFlag;               // host-coherent word: once non-zero, waves take no further chunks (a discarded look-ahead)
   // replay
   const float *randoms; long long nRandoms; const long long *drawStart;
   int32_t *fate, *fateColumn; float *fateWeight; int32_t *fateOrder, *drawsUsed;

@@ -432,6 +432,11 @@ class Integrator:
                                                    C.byref(s), int(inFlight), raw.ctypes.data_as(B.dp)), "computeRadiativeTransfer")
         return [self.finish(raw[k]) for k in range(int(numBatches))]
 
+    def set_batch_fusion(self, mode):
+        """-1: automatic (default), 0: every batch a launch of its own, 1: fuse a loop's batches into one grid whenever the
+        problem allows (i3rc_hip_set_batch_fusion)."""
+        self._check(self._lib.i3rc_hip_set_batch_fusion(self._h, int(mode)), "set_batch_fusion")
+
     def kernel_ms(self):
         ms = C.c_float(0)
         self._check(self._lib.i3rc_hip_last_kernel_ms(self._h, C.byref(ms)), "kernel_ms")

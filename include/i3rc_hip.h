@@ -239,6 +239,13 @@ int i3rc_hip_set_light_threshold(i3rc_hip_integrator *h, int lanes);
  * 1e9 on an MI355X): workgroups keep partial sums in float32, which stops counting at 2^24. */
 int i3rc_hip_set_launch_limit(i3rc_hip_integrator *h, int64_t photons);
 
+/* Fusion of a loop's batches (i3rc_hip_run_batches, the look-ahead of i3rc_hip_compute_batch): -1 = automatic (default:
+ * problems the specialised flux kernels run, two batches or more of at most 2e7 photons), 0 = never (every batch a launch
+ * of its own, several in flight), 1 = whenever the problem allows.  Environment: I3RC_FUSED=0 switches fusion off for the
+ * process, I3RC_FUSED_CHUNK (photons a wavefront takes from one batch at a time, default 512) and
+ * I3RC_FUSED_GROUP_PHOTONS (photons per fused launch, default 1e8) are tuning knobs. */
+int i3rc_hip_set_batch_fusion(i3rc_hip_integrator *h, int mode);
+
 /* Test / tuning knob.  A launch normally (AUTO) runs the one-photon-per-lane kernel specialised for the common
  * problem class (regular x / y grid, ray tracing, one component, no BRDF grid, Directional source) when the problem is
  * in it, else the general kernel.  All kernels trace the same photon paths from the same per-photon random streams,

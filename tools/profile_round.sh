@@ -27,7 +27,10 @@ for w in step16 radar64_nadir landsat36 landsat119_7dir; do
 done
 python3 $R/tools/pmc_to_json.py --collect $R/profiles/${TAG}_pmc.json $O/pmc_*/summary.txt > /dev/null && cp $R/profiles/${TAG}_pmc.json $O/pmc.json
 for w in step16 radar64_nadir landsat36 landsat119_7dir; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$w -- python3 $R/bench.py --config $w --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_prof_$w.json 2> $O/bench_prof_$w.err || echo "stats $w failed"
+  # the profiled program is the rank itself (RANK set: bench.py's main() runs worker() at once), never bench.py's launcher --
+  # a launcher hop after `--` would be traced only through the inherited preload, after the profiler library has touched the GPU
+  ( export RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$w -- python3 $R/bench.py --config $w --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_prof_$w.json 2> $O/bench_prof_$w.err ) || echo "stats $w failed"
   python3 $R/bench.py --config $w > $O/bench_$w.json 2> $O/bench_$w.err || echo "bench $w failed"
   echo "$w done: $(python3 -c "import json;j=json.load(open('$O/bench_$w.json'));print('%.3e photons/s'%j['value'], j['roofline']['kernel'])")"
 done
