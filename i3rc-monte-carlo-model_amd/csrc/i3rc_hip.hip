@@ -111,7 +111,7 @@ struct i3rc_hip_integrator {
   struct FusedSlot {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
-    DevBuf blocks, compact, counter;
+    DevBuf blocks, compact, counter, counterBlocks;
     double *pinned = nullptr; size_t pinnedBytes = 0;
     int *abortFlag = nullptr;      // host-coherent word the kernel polls (RunArgs::abortFlag)
     int first = 0, count = 0;      // batches first .. first + count - 1 of the call (count = 0: free)
@@ -821,6 +821,18 @@ __global__ void __launch_bounds__(256) reduce_replicas_kernel(const double *bloc
   out[i] = v;
 }
 
+// counters of batch b of the group = sum over the copies of its counter block (RunArgs::counterBlocks), into the batch's tally block
+__global__ void __launch_bounds__(256) reduce_counters_kernel(const double *counterBlocks, double *out, long long nBlocksOut, long long stride, int oCnt) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nBlocksOut * I3RC_NUM_COUNTERS) return;
+  const long long b = i / I3RC_NUM_COUNTERS;
+  const int k = (int)(i - b * I3RC_NUM_COUNTERS);
+  const double *src = counterBlocks + (size_t)b * kCounterReplicas * I3RC_NUM_COUNTERS + k;
+  double v = 0.0;
+  for (int r = 0; r < kCounterReplicas; ++r) v += src[(size_t)r * I3RC_NUM_COUNTERS];
+  out[(size_t)b * stride + oCnt + k] = v;
+}
+
 // Can the batches of a driver's loop share one grid?  The specialised flux kernels only (so far): the common problem class
 // without radiance directions, production streams.
 bool fusable(const i3rc_hip_integrator *h, int64_t nPhotons) {
@@ -861,6 +873,8 @@ int ready_fused_slot(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g, 
   }
   if (g.blocks.bytes < outBytes * R) HIPCHK(h, g.blocks.alloc(outBytes * R));
   if (R > 1 && g.compact.bytes < outBytes) HIPCHK(h, g.compact.alloc(outBytes));
+  const size_t cntBytes = (size_t)count * kCounterReplicas * I3RC_NUM_COUNTERS * sizeof(double);
+  if (g.counterBlocks.bytes < cntBytes) HIPCHK(h, g.counterBlocks.alloc(cntBytes));
   return 0;
 }
 
@@ -891,6 +905,7 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
   A.replicas = R;
   A.blockStride = h->layout.total;
   A.abortFlag = g.abortFlag;
+  A.counterBlocks = (double *)g.counterBlocks.p;
   if ((uint64_t)count * R >= ((uint64_t)1 << 31)) return h->fail("fused launch: too many tally blocks");
   using Kernel = void (*)(DevProblem, RunArgs, int, int);
   static const Kernel kernels[3] = {photon_kernel<PhiloxBatchStream, false, false, GRID_LDS>, photon_kernel<PhiloxBatchStream, false, false, GRID_GLOBAL>,
@@ -919,6 +934,7 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
   *g.abortFlag = 0;
   HIPCHK(h, hipMemsetAsync(g.blocks.p, 0, outBytes * R, g.stream));
   HIPCHK(h, hipMemsetAsync(g.counter.p, 0, sizeof(unsigned long long), g.stream));
+  HIPCHK(h, hipMemsetAsync(g.counterBlocks.p, 0, (size_t)count * kCounterReplicas * I3RC_NUM_COUNTERS * sizeof(double), g.stream));
   const int slot = (int)(h->timedLaunches % i3rc_hip_integrator::kEventRing);
   if (timeIt) HIPCHK(h, hipEventRecord(h->evStart[slot], g.stream));
   {
@@ -934,6 +950,12 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
                        (double *)g.compact.p, (long long)count, R, (long long)h->layout.total);
     HIPCHK(h, hipGetLastError());
     result = (const double *)g.compact.p;
+  }
+  {
+    const long long n = (long long)count * I3RC_NUM_COUNTERS;
+    hipLaunchKernelGGL(reduce_counters_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream, (const double *)g.counterBlocks.p,
+                       const_cast<double *>(result), (long long)count, (long long)h->layout.total, (int)h->layout.counters);
+    HIPCHK(h, hipGetLastError());
   }
   HIPCHK(h, hipMemcpyAsync(g.pinned, result, outBytes, hipMemcpyDeviceToHost, g.stream));
   HIPCHK(h, hipEventRecord(g.done, g.stream));
@@ -1112,6 +1134,36 @@ int i3rc_hip_compute_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed
   };
   i3rc_hip_integrator::BatchSignature sig;
   sig.seed0 = seed0; sig.n = nPhotons; sig.mu = src->solarMu; sig.az = src->solarAzimuth; sig.set = true;
+  // Problems whose batches can share a grid (fusable) are looked ahead in GROUPS: 8, 16, 32, 64 ... batches per fused
+  // launch, up to three groups under way, the caller served from the oldest.  Such launches are not timed (the ring of
+  // i3rc_hip_kernel_ms_history holds launches the caller asked for), and a group that is not wanted after all is called
+  // off through its abort word: its waves stop at their next visit of the work counter.
+  const bool fuse = depth > 0 && fusable(h, nPhotons) && (h->fusion == 1 || nPhotons <= 20000000);
+  auto top_up = [&]() {
+    while ((int)h->aheadGroups.size() < i3rc_hip_integrator::kFusedSlots) {
+      int k = -1;
+      for (int j = 0; j < i3rc_hip_integrator::kFusedSlots; ++j) if (h->fused[j].count == 0) { k = j; break; }
+      if (k < 0) break;
+      uint32_t next = seed1 + 1u;
+      if (!h->aheadGroups.empty()) { const auto &last = h->fused[h->aheadGroups.back()]; next = last.seed1 + (uint32_t)last.count; }
+      h->aheadGroupSize = h->aheadGroupSize <= 0 ? 8 : std::min(64, 2 * h->aheadGroupSize);
+      const int size = fused_group_size(h, h->aheadGroupSize, nPhotons);
+      if (launch_fused_group(h, h->fused[k], seed0, next, size, nPhotons, src, false)) { h->fused[k].count = 0; break; }   // (not this batch's failure)
+      h->aheadGroups.push_back(k);
+    }
+  };
+  if (!h->aheadGroups.empty()) {
+    auto &g = h->fused[h->aheadGroups.front()];
+    if (fuse && h->aheadSig == sig && g.seed1 + (uint32_t)g.next == seed1) {
+      if (hipEventSynchronize(g.done) != hipSuccess) { drop_lookahead(h); return h->fail("i3rc_hip_compute_batch: waiting for the batch failed"); }
+      std::memcpy(hostTallies, g.pinned + (size_t)g.next * (size_t)h->layout.total, bytes);
+      if (++g.next == g.count) { g.count = 0; h->aheadGroups.erase(h->aheadGroups.begin()); }
+      h->lastSig = sig; h->lastSeed1 = seed1;
+      top_up();
+      return 0;
+    }
+    drop_lookahead(h);
+  }
   // batches launched ahead serve this call only if the next of them is exactly this batch
   if (!h->aheadQueue.empty() && !(h->aheadSig == sig && h->aheadQueue.front().seed1 == seed1)) drop_lookahead(h);
   int mine;
@@ -1127,7 +1179,10 @@ int i3rc_hip_compute_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed
   // look ahead once the caller's loop shows: the same batch as last time with the next seed word (monteCarloDriver.f95:277)
   const bool inLoop = h->lastSig == sig && h->lastSeed1 + 1u == seed1;
   h->lastSig = sig; h->lastSeed1 = seed1;
-  if (depth > 0 && (inLoop || !h->aheadQueue.empty())) {
+  if (fuse && inLoop) {
+    h->aheadSig = sig;
+    top_up();
+  } else if (depth > 0 && (inLoop || !h->aheadQueue.empty())) {
     h->aheadSig = sig;
     while ((int)h->aheadQueue.size() < depth) {
       const uint32_t next = (h->aheadQueue.empty() ? seed1 : h->aheadQueue.back().seed1) + 1u;

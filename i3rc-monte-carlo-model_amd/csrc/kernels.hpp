@@ -333,13 +333,17 @@ __global__ void __launch_bounds__(256) slab_fill_kernel(uint32_t seed0, uint32_t
 #ifndef I3RC_FLUX_WAVES
 #define I3RC_FLUX_WAVES 8
 #endif
+// (the fused multi-batch kernels carry five more vector registers per lane: the batch and the per-lane counts)
+#ifndef I3RC_FUSED_WAVES
+#define I3RC_FUSED_WAVES 8
+#endif
 // GENERAL = false is the specialisation for the common problem class -- regular grid, ray tracing, one component,
 // Lambertian albedo (no BRDF grid), Directional source, production RNG: the rare paths (grid searches, periodic
 // re-wrapping loops, max-cross-section moves, BRDF lookups, component selection) are compiled out, which shrinks the
 // loop's code and its scalar-register pressure.  GENERAL = true keeps every path behind run-time switches.
 // (radiance kernels keep two rays per lane live -- the photon's and a shadow ray's: 4 waves per SIMD give them 128 vector registers)
 template <class Rng, bool INTENSITY, bool GENERAL, int GRID>
-__global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_WAVES) : ((GENERAL || GRID == GRID_BRICKS) ? I3RC_MIN_WAVES : I3RC_FLUX_WAVES)) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
+__global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_WAVES) : ((GENERAL || GRID == GRID_BRICKS) ? I3RC_MIN_WAVES : (Rng::kBatched ? I3RC_FUSED_WAVES : I3RC_FLUX_WAVES))) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   {
@@ -429,24 +433,47 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
     const ColdArgs k = cold_args();
     return k->P.tally + (size_t)(b * (unsigned)k->A.replicas + rep) * (size_t)(unsigned)k->A.blockStride;
   };
-  auto flush_lane = [&]() {                         // (the lanes that call it; uses the batch the lane has had so far)
+  auto counter_block = [&](uint32_t b) -> double * {   // ... and its counter block
+    return cold_args()->A.counterBlocks + (size_t)(b * (unsigned)kCounterReplicas + (blockIdx.x & (unsigned)(kCounterReplicas - 1))) * I3RC_NUM_COUNTERS;
+  };
+  // (uniform control flow: the lanes with `want` hand their counts over.  The counts of all lanes that share a batch --
+  // nearly always all of them -- are summed across the wave first and one lane adds them to the batch's counter block:
+  // sixty-four lanes adding to the same seven words one after the other cost a launch 6 ms at its end and made chunks of
+  // 256 photons half as fast as chunks of 1024.)
+  auto flush_lanes = [&](bool want) {
     if constexpr (BATCHED) {
-      double *const c = lane_block(rng.batch) + cold_args()->P.oCnt;
-      const uint32_t scat = accA & 0xffffu, roul = accA >> 16, surf = accB & 0xffffu, top = accB >> 16;
-      if (accSteps) unsafeAtomicAdd(c + I3RC_CNT_CELL_STEPS, (double)accSteps);
-      if (scat) unsafeAtomicAdd(c + I3RC_CNT_SCATTERINGS, (double)scat);
-      if (roul) unsafeAtomicAdd(c + I3RC_CNT_ROULETTE, (double)roul);
-      if (surf) unsafeAtomicAdd(c + I3RC_CNT_SURFACE_HITS, (double)surf);
-      if (top) unsafeAtomicAdd(c + I3RC_CNT_EXITS_TOP, (double)top);
-      if (scat + surf + top) unsafeAtomicAdd(c + I3RC_CNT_TRACER_CALLS, (double)(scat + surf + top));
-      const uint32_t draws = rng.take_used();
-      if (draws) unsafeAtomicAdd(c + I3RC_CNT_RNG_DRAWS, (double)draws);
-      accSteps = accA = accB = 0u;
+      unsigned long long todo = __ballot(want);
+      while (todo != 0ull) {
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)rng.batch, (int)__builtin_ctzll(todo));
+        const bool sel = want && rng.batch == b;
+        // (one sum at a time, each ending in a scalar register: six at once cost the kernel six spilled vector registers)
+        auto wave_total = [](uint32_t x) -> uint32_t {
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) x += (uint32_t)__shfl_xor((int)x, off, 64);
+          return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+        };
+        const uint32_t steps = wave_total(sel ? accSteps : 0u);
+        const uint32_t scat = wave_total(sel ? (accA & 0xffffu) : 0u), roul = wave_total(sel ? (accA >> 16) : 0u);
+        const uint32_t surf = wave_total(sel ? (accB & 0xffffu) : 0u), top = wave_total(sel ? (accB >> 16) : 0u);
+        const uint32_t draws = wave_total(sel ? rng.take_used() : 0u);
+        if ((threadIdx.x & 63) == 0) {
+          double *const c = counter_block(b);
+          if (steps) unsafeAtomicAdd(c + I3RC_CNT_CELL_STEPS, (double)steps);
+          if (scat) unsafeAtomicAdd(c + I3RC_CNT_SCATTERINGS, (double)scat);
+          if (roul) unsafeAtomicAdd(c + I3RC_CNT_ROULETTE, (double)roul);
+          if (surf) unsafeAtomicAdd(c + I3RC_CNT_SURFACE_HITS, (double)surf);
+          if (top) unsafeAtomicAdd(c + I3RC_CNT_EXITS_TOP, (double)top);
+          if (scat + surf + top) unsafeAtomicAdd(c + I3RC_CNT_TRACER_CALLS, (double)(scat + surf + top));
+          if (draws) unsafeAtomicAdd(c + I3RC_CNT_RNG_DRAWS, (double)draws);
+        }
+        if (sel) accSteps = accA = accB = 0u;
+        todo &= ~__ballot(sel);
+      }
     }
   };
   auto hand_over_taken = [&](uint32_t b) {          // uniform control flow
     if (resTaken != 0u && (threadIdx.x & 63) == 0)
-      unsafeAtomicAdd(lane_block(b) + cold_args()->P.oCnt + I3RC_CNT_PHOTONS, (double)resTaken);
+      unsafeAtomicAdd(counter_block(b) + I3RC_CNT_PHOTONS, (double)resTaken);
     resTaken = 0u;
   };
 
@@ -825,7 +852,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
       const auto &Ae = ke->A;
       if constexpr (BATCHED) {   // a 16-bit count about to overflow (one event adds at most one to each): hand over now
         const bool full = ((accA | accB) & 0x80008000u) != 0u || accSteps >= 0x80000000u;
-        if (__ballot(full) != 0ull) { if (full) flush_lane(); }
+        if (__ballot(full) != 0ull) flush_lanes(full);
       }
       double *laneBlk = nullptr;
       if constexpr (BATCHED) laneBlk = lane_block(rng.batch);
@@ -845,8 +872,9 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
       if constexpr (BATCHED) {
         accB += (atSurface ? 1u : 0u) + (atTop ? 0x10000u : 0u);
         if (dropped) {
-          unsafeAtomicAdd(tally.blk + Pe.oCnt + I3RC_CNT_DROPPED, 1.0);
-          unsafeAtomicAdd(tally.blk + Pe.oCnt + I3RC_CNT_TRACER_CALLS, 1.0);
+          double *const c = counter_block(rng.batch);
+          unsafeAtomicAdd(c + I3RC_CNT_DROPPED, 1.0);
+          unsafeAtomicAdd(c + I3RC_CNT_TRACER_CALLS, 1.0);
         }
       }
       if (dropped || atTop || atBlack) {
@@ -892,12 +920,12 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
             res.refill_batched();
             if (res.end < 0 || res.batch != oldBatch) hand_over_taken(oldBatch);
           }
+          // a lane whose next photon belongs to another batch hands over what it has counted for the batch it leaves
+          const bool leaves = isNew && mine >= 0 && mineBatch != rng.batch && (accSteps | accA | accB | rng.used) != 0u;
+          if (__ballot(leaves) != 0ull) flush_lanes(leaves);
           if (isNew) {
             if (mine < 0) st = ST_DONE;   // (only when the launch has no chunks left)
-            else {
-              if (mineBatch != rng.batch && (accSteps | accA | accB) != 0u) flush_lane();
-              rng.start((uint64_t)(Ae.firstPhoton + mine), mineBatch);
-            }
+            else rng.start((uint64_t)(Ae.firstPhoton + mine), mineBatch);
           }
         }
       } else
@@ -1154,7 +1182,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
 
   // ------------------------------------------------------------------ epilogue: flush tallies + counters
   if constexpr (BATCHED) {   // what the lanes still hold for their last batches; the tallies themselves are in global memory already
-    flush_lane();
+    flush_lanes(true);
     hand_over_taken(res.batch);
     return;
   }

@@ -89,6 +89,10 @@ struct RunArgs {
   unsigned nBatches, chunksPerBatch;
   int replicas;
   long long blockStride;
+  // ... and its work counters to counterBlocks[(b * kCounterReplicas + workgroup mod kCounterReplicas) * I3RC_NUM_COUNTERS + k]:
+  // a batch's counters are one cache line, and one line takes about 1e8 atomics/s -- with the counters in the tally block
+  // itself (one replica for large domains) every batch of 1e6 Landsat photons paid 0.4 ms for them
+  double *counterBlocks;
   const int *abortFlag;               // host-coherent word: once non-zero, waves take no further chunks (a discarded look-ahead)
   // replay
   const float *randoms; long long nRandoms; const long long *drawStart;
@@ -113,6 +117,7 @@ constexpr int kRecWords = 14;   // x y z | ix iy iz | weight | incoming directio
 // ... and one ready-made shadow ray of the wave's ready buffer (kReadyRays of them, one expand phase's worth)
 constexpr int kReadyWords = 12;  // x y z | ix iy iz | component, direction, stage | weight | phase-function factor | free path | target | optical path so far
 constexpr int kReadyRays = 64;
+constexpr int kCounterReplicas = 64;   // fused multi-batch launches: copies of a batch's counter block (RunArgs::counterBlocks)
 
 // Fortran SPACING() for real(4)
 __device__ __forceinline__ float spacingf(float x) {

@@ -130,13 +130,14 @@ program i3rcDriver
   ! The reference's loop -- per batch a sequence seeded (/ iseed, batch /), a photon stream, computeRadiativeTransfer,
   ! reportResults (monteCarloDriver.f95:283-326) -- runs here as computeRadiativeTransferBatches over groups of batches:
   ! the same photons batch by batch, but several batches share the GPU at a time, so that the long tail of one batch
-  ! (a few photons with a thousand scatterings) is covered by the next.  A group holds at most 64 batches and 256 MB of
-  ! raw tallies; I3RC_BATCHES_IN_FLIGHT=1 in the environment runs the batches one after the other.
+  ! (a few photons with a thousand scatterings) is covered by the next -- flux problems of the common class even share ONE
+  ! kernel launch per hundred batches or so (i3rc_hip_run_batches).  A group holds at most 4096 batches and 256 MB of raw
+  ! tallies; I3RC_BATCHES_IN_FLIGHT=1 (and I3RC_FUSED=0) in the environment runs the batches one after the other.
   inFlight = 0
   call get_environment_variable("I3RC_BATCHES_IN_FLIGHT", envText, status = rc)
   if(rc == 0 .and. len_trim(envText) > 0) read(envText, *, iostat = rc) inFlight
   tallyWords = 3. * nx * ny + real(nx) * ny * nz + 2. * nDir * nx * ny
-  groupSize = max(1, min(64, int(256. * 1024. * 1024. / (8. * tallyWords))))
+  groupSize = max(1, min(4096, int(256. * 1024. * 1024. / (8. * tallyWords))))
   do groupStart = firstBatch, firstBatch + perProc - 1, groupSize
     inGroup = min(groupSize, firstBatch + perProc - groupStart)
     call computeRadiativeTransferBatches(mc, iseed, groupStart, inGroup, solarMu, solarAzimuth, numPhotonsPerBatch, status, &

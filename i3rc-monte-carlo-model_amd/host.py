@@ -332,6 +332,7 @@ class Integrator:
             o = t if forward_orig is None else f32(np.atleast_2d(forward_orig))
             self._check(self._lib.i3rc_hip_set_forward_tables(self._h, component, t.shape[1], t.shape[0], pf(t), pf(o)), "set_tables")
             self._fwd_size[component - 1] = max(t.shape[1], 10 ** 9)
+            self._fwd_stale = False          # (tables handed over ready-made are the ones to use)
 
     # -- computeRadiativeTransfer :262-398
     def launch(self, randomNumbers, incomingPhotons, firstPhoton=None, zero=True):

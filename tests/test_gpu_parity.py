@@ -586,3 +586,111 @@ def test_looking_ahead_never_changes_a_batch():
     q = plain.computeRadiativeTransfer(M.new_RandomNumberSequence((8, 35)), M.new_PhotonStream(0.6, 25.0, 5000))
     assert r["counters"] == q["counters"]
     plain.finalize_Integrator(); ahead.finalize_Integrator()
+
+
+def _same_batches(one, many, what):
+    assert len(one) == len(many), what
+    for b, (a, f) in enumerate(zip(one, many)):
+        assert a["counters"] == f["counters"], (what, b, {k: (a["counters"][k], f["counters"][k]) for k in a["counters"] if a["counters"][k] != f["counters"][k]})
+        assert np.allclose(a["raw"], f["raw"], rtol=1e-5, atol=1e-6), (what, b)
+
+
+def test_fused_batches_equal_one_launch_per_batch():
+    """A fused multi-batch launch (photon_kernel<PhiloxBatchStream, ...>: the batches of a loop in ONE grid, every lane with
+    the batch of its photon in its Philox key, per-batch tally blocks in global memory) gives every batch exactly what a launch
+    of its own gives it -- integer work counters identical, tallies equal to the order of the additions -- whatever the
+    batch size (shorter than a wavefront, not a multiple of a chunk, one batch only), with absorption (volume tallies), a
+    reflecting surface, a slant sun, for the extinction grid in LDS, in global memory and in bricks."""
+    problems = [("step cloud, absorbing, surface", cases.step_cloud(ssa=0.9), dict(surfaceAlbedo=0.3), 0.7, [(20000, 7), (50, 5), (1000, 1), (777, 33)]),
+                ("step cloud, conservative", cases.step_cloud(nlayers=16), dict(), 1.0, [(30011, 12)]),
+                ("radar field (grid in global memory)", cases.radar_cloud(), dict(surfaceAlbedo=0.1), 0.9, [(20000, 5)]),
+                ("Landsat field (bricks), absorbing", cases.landsat_cloud(ssa=0.98), dict(), 0.5, [(15000, 3)])]
+    for what, d, params, mu0, runs in problems:
+        g = make_gpu(d, hg_table(), **params)
+        for n, nb in runs:
+            g.set_batch_fusion(0)
+            one = g.computeRadiativeTransferBatches((5, 3), nb, mu0, 25.0, n)
+            assert "PhiloxStream" in g.kernel_name()
+            g.set_batch_fusion(1)
+            fused = g.computeRadiativeTransferBatches((5, 3), nb, mu0, 25.0, n)
+            assert "PhiloxBatchStream" in g.kernel_name(), g.kernel_name()
+            _same_batches(one, fused, (what, n, nb))
+            plain = g.computeRadiativeTransfer(M.new_RandomNumberSequence((5, 3 + nb - 1)), M.new_PhotonStream(mu0, 25.0, n))
+            _same_batches([plain], [fused[-1]], (what, n, nb, "plain call"))
+            assert all(r["counters"]["photons"] == n for r in fused)
+        g.finalize_Integrator()
+
+
+def test_fused_groups_and_chunks_do_not_matter(monkeypatch):
+    """Group size (batches per fused launch) and chunk size (photons a wave takes from one batch at a time) only schedule
+    work: the same batches come out, whether the loop is one launch or many, the chunks long or short."""
+    import subprocess, sys, json, os
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r)\n"
+            "import i3rc_monte_carlo_model_amd as M\nfrom tests import cases\nfrom tests.test_gpu_parity import make_gpu, hg_table\n"
+            "g = make_gpu(cases.step_cloud(ssa=0.95), hg_table(), surfaceAlbedo=0.2)\ng.set_batch_fusion(1)\n"
+            "r = g.computeRadiativeTransferBatches((9, 1), 21, 0.8, 10.0, 4000)\n"
+            "print(json.dumps([[x['counters'], [float(v) for v in x['raw']]] for x in r]))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({}, {"I3RC_FUSED_GROUP_PHOTONS": "9000", "I3RC_FUSED_CHUNK": "64"}, {"I3RC_FUSED_GROUP_PHOTONS": "30000", "I3RC_FUSED_CHUNK": "4096"}):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    for other in outs[1:]:
+        for (c0, r0), (c1, r1) in zip(outs[0], other):
+            assert c0 == c1
+            assert np.allclose(r0, r1, rtol=1e-5, atol=1e-6)
+
+
+def test_looking_ahead_in_fused_groups_never_changes_a_batch():
+    """The look-ahead of i3rc_hip_compute_batch on a flux problem launches GROUPS of following batches as fused launches
+    (8, 16, 32 ... batches): a loop, a jump (the groups are called off through their abort word), another photon count, another
+    sun, a parameter change in mid-loop -- every batch equals the plain zero + launch + fetch of the same batch."""
+    d = cases.step_cloud(ssa=0.99, nlayers=8)
+    params = dict(surfaceAlbedo=0.3)
+    plain, ahead = make_gpu(d, hg_table(), **params), make_gpu(d, hg_table(), **params)
+    plain.set_batch_fusion(0)
+
+    def both(seed, n, mu0=0.8, az=25.0, look=3):
+        a = plain.computeRadiativeTransfer(M.new_RandomNumberSequence(seed), M.new_PhotonStream(mu0, az, n))
+        b = ahead.computeRadiativeTransferLookingAhead(M.new_RandomNumberSequence(seed), M.new_PhotonStream(mu0, az, n), lookAhead=look)
+        assert a["counters"] == b["counters"], (seed, n)
+        assert np.allclose(a["raw"], b["raw"], rtol=1e-5, atol=1e-6)
+
+    both((7, 0), 1)                                     # the drivers' one-photon warm-up
+    for b in range(1, 40):
+        both((7, b), 20000)                             # the loop: served from the first group, then the second, the third
+    both((7, 100), 20000)                               # a jump: the groups launched ahead are called off
+    both((7, 101), 20000); both((7, 102), 20000); both((7, 103), 20000)
+    both((7, 104), 5000)                                # another photon count
+    both((7, 105), 5000); both((7, 106), 5000, mu0=0.6)   # another sun in mid-loop
+    both((7, 107), 5000, mu0=0.6); both((7, 108), 5000, mu0=0.6)
+    for g in (plain, ahead):                            # a parameter changes while groups are under way
+        g.specifyParameters(surfaceAlbedo=0.6)
+    for b in range(109, 120):
+        both((7, b), 5000, mu0=0.6)
+    both((8, 120), 5000, mu0=0.6, look=0); both((8, 121), 5000, mu0=0.6, look=0)
+    r = ahead.computeRadiativeTransfer(M.new_RandomNumberSequence((8, 121)), M.new_PhotonStream(0.6, 25.0, 5000))
+    q = plain.computeRadiativeTransfer(M.new_RandomNumberSequence((8, 121)), M.new_PhotonStream(0.6, 25.0, 5000))
+    assert r["counters"] == q["counters"]
+    plain.finalize_Integrator(); ahead.finalize_Integrator()
+
+
+def test_phase_function_entries_beyond_32767():
+    """Radiance runs pack the phase-function table entry into the upper half of a ray record's info word: an entry beyond
+    32767 must come back as itself (unsigned), not as a negative offset.  A table of 40000 identical entries with every cell
+    pointing at the last one gives exactly the run with one entry."""
+    d = cases.step_cloud(ssa=1.0, nlayers=8)
+    t = hg_table()
+    inv, fwd = t.inverse_table(129), t.forward_table(181)
+    params = dict(intensityMus=[1.0, 0.5], intensityPhis=[0.0, 30.0], useRussianRouletteForIntensity=True, zetaMin=0.3)
+    res = []
+    hg = M.henyey_greenstein(0.85, 64)
+    for entries in (1, 40000):
+        dd = dict(d, pf=np.full(d["ext"].shape, entries, np.int32))
+        g = make_gpu(dd, M.PhaseFunctionTable([hg] * entries), **params)   # (the tables themselves are handed over ready-made)
+        g.set_tables(1, inverse=np.repeat(inv, entries, axis=0), forward=np.repeat(fwd, entries, axis=0))
+        res.append(g.computeRadiativeTransfer(M.new_RandomNumberSequence((3, 1)), M.new_PhotonStream(0.8, 0.0, 30000)))
+        g.finalize_Integrator()
+    assert res[0]["counters"] == res[1]["counters"]
+    assert np.allclose(res[0]["raw"], res[1]["raw"], rtol=1e-5, atol=1e-6)
+
