@@ -49,7 +49,11 @@ def parse_args():
     ap.add_argument("--config", default="step16", help="workload (tools/workloads.py); default = BASELINE.json configs[1]")
     ap.add_argument("--photons", type=int, default=0, help="photons per GPU per step (weak) / per step (strong); 0 = the workload's")
     ap.add_argument("--nlayers", type=int, default=16, help="step cloud: 16 = BASELINE.json label, 32 = reference generator (= --config step32)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="default: N = 1 -> the same thing; N > 1 -> strong (ONE batch of --photons photons per step sharded over the GPUs: the "
+                         "metric's case) as the headline, the weak figure measured after it and reported beside it")
+    ap.add_argument("--overlap", choices=("auto", "0", "1"), default="auto",
+                    help="two steps in flight (two handles / streams / tally buffers); auto = on for N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
     if a.gpus < 1:
@@ -184,6 +188,27 @@ def load_pmc(config):
     return best
 
 
+def load_calibration(config):
+    """Port-against-reference calibration (tools/cpu_calibration.py, run in the build container): the newest
+    profiles/*_cpu_calibration.json; the ratio of the nearest shape and the range over all cases."""
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if f.endswith("_cpu_calibration.json"):
+            try:
+                best = (f, json.load(open(os.path.join(pdir, f))))
+            except Exception:
+                continue
+    if best is None:
+        return None
+    f, j = best
+    nearest = {"step16": "step32", "landsat36": "landsat119", "radar64_nadir": "radar640_nadir", "landsat36_7dir": "landsat119_7dir"}.get(config, config)
+    rows = [c for c in j["cases"] if c["workload"] == nearest]
+    return {"source": "profiles/" + f, "what": j["what"], "host": j["host"], "nearest_case": rows[0] if rows else None,
+            "ratio_port_over_reference": (rows[0]["ratio_port_over_reference"] if rows else j["ratio_geomean"]),
+            "ratio_range": [j["ratio_min"], j["ratio_max"]], "note": j["note"]}
+
+
 def worker(a):
     rank = int(os.environ["RANK"])
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
@@ -233,41 +258,30 @@ def worker(a):
 
     # ---- problem: resident on the device before timing -------------------------------------------------
     name, w = W.get(a.config)
-    integ, d = W.make_integrator(w, device=local_rank)
     nd = W.n_dir(w)
-    absorbing = bool(np.any(d["ssa"][d["ext"] > 0] < 1.0))
-    per_step = a.photons or w["photons"]
-    if a.scaling == "strong":
-        first, mine = shard_photons(per_step, n_gpus, rank)
-        total_per_step = per_step
-    else:
-        first, mine = rank * per_step, per_step
-        total_per_step = per_step * n_gpus
-    lay = integ.layout()
-    tally = torch.zeros(lay.total, dtype=torch.float64, device="cuda")
-    stream = torch.cuda.current_stream()
     lib = B.load()
-    assert lib.i3rc_hip_bind_tally_buffer(integ._h, tally.data_ptr(), tally.numel() * 8) == 0
-    assert lib.i3rc_hip_set_stream(integ._h, stream.cuda_stream) == 0
-    # the phase-function tables are built and uploaded before the timed region (the reference builds them in its 1-photon
-    # warm-up, monteCarloDriver.f95:233-253); no kernel launch here, so that every photon_kernel dispatch a profiler sees
-    # is a full step
-    integ._ensure_tables()
+    # Steps in flight.  One (N = 1): zero, trace, (all-reduce), one after the other on torch's current stream.  Two (N > 1, or
+    # --overlap 1): two handles, each with a stream and a tally buffer of its own, take the steps in turn, so that the tail
+    # of step k -- its last photons keep a few wavefronts busy for a millisecond, a quarter of a 1.25e7-photon shard -- and
+    # its all-reduce overlap the trace of step k + 1.  Every step still zeroes, traces and reduces its own buffer.
+    overlap = (n_gpus > 1) if a.overlap == "auto" else (a.overlap == "1")
+    lanes = []
+    for k in range(2 if overlap else 1):
+        integ, d = W.make_integrator(w, device=local_rank)
+        lay = integ.layout()
+        tally = torch.zeros(lay.total, dtype=torch.float64, device="cuda")
+        stream = torch.cuda.Stream() if overlap else torch.cuda.current_stream()
+        assert lib.i3rc_hip_bind_tally_buffer(integ._h, tally.data_ptr(), tally.numel() * 8) == 0
+        assert lib.i3rc_hip_set_stream(integ._h, stream.cuda_stream) == 0
+        # the phase-function tables are built and uploaded before the timed region (the reference builds them in its 1-photon
+        # warm-up, monteCarloDriver.f95:233-253); no kernel launch here, so that every photon_kernel dispatch a profiler sees
+        # is a full step
+        integ._ensure_tables()
+        lanes.append(dict(integ=integ, tally=tally, stream=stream))
+    integ = lanes[0]["integ"]
+    absorbing = bool(np.any(d["ssa"][d["ext"] > 0] < 1.0))
     torch.cuda.synchronize()
-
     iseed = 10
-
-    def step(batch):
-        # computeRadiativeTransfer zeroes its tallies per call (:296-309)
-        tally.zero_()
-        integ.launch(M.new_RandomNumberSequence((iseed, batch)), M.new_PhotonStream(w["mu0"], 0.0, mine),
-                     firstPhoton=first, zero=False)
-        if rehearsal and dist is not None:
-            host = tally.cpu()
-            all_reduce_tallies(host, dist)
-            tally.copy_(host)
-        else:
-            all_reduce_tallies(tally, dist)  # the single exchange step: sum of tallies over GPUs (RCCL)
 
     def sync():
         torch.cuda.synchronize()
@@ -275,29 +289,77 @@ def worker(a):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(a.warmup):
-        step(1000 + k)
-    sync()
-    launches_before = int(integ.timed_launches())
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        step(1 + k)
-    sync()
-    elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, dist, device="cpu" if rehearsal else "cuda")
+    def measure(scaling, steps, warmup):
+        """`steps` timed steps of the workload's batch: weak = every rank its own --photons photons, strong = one batch of
+        --photons photons sharded over the ranks by photon range."""
+        per_step = a.photons or w["photons"]
+        if scaling == "strong":
+            first, mine = shard_photons(per_step, n_gpus, rank)
+            total_per_step = per_step
+        else:
+            first, mine = rank * per_step, per_step
+            total_per_step = per_step * n_gpus
 
-    # ---- kernel durations of the timed launches (HIP events recorded on the launch stream, read now) ------
-    n_launches = int(integ.timed_launches()) - launches_before   # a step is one launch unless a batch exceeds the launch limit
-    kernel_ms = integ.kernel_ms_history(min(n_launches, 64))
-    launches_per_step = n_launches / a.steps
+        def step(k, batch):
+            ln = lanes[k % len(lanes)]
+            with torch.cuda.stream(ln["stream"]):
+                ln["tally"].zero_()   # computeRadiativeTransfer zeroes its tallies per call (:296-309)
+                ln["integ"].launch(M.new_RandomNumberSequence((iseed, batch)), M.new_PhotonStream(w["mu0"], 0.0, mine),
+                                   firstPhoton=first, zero=False)
+                if rehearsal and dist is not None:
+                    host = ln["tally"].cpu()
+                    all_reduce_tallies(host, dist)
+                    ln["tally"].copy_(host)
+                else:
+                    all_reduce_tallies(ln["tally"], dist)  # the single exchange step: sum of tallies over GPUs (RCCL)
+            return ln
+
+        for k in range(warmup):
+            step(k, 1000 + k)
+        sync()
+        before = [int(ln["integ"].timed_launches()) for ln in lanes]
+        t0 = time.perf_counter()
+        last = None
+        for k in range(steps):
+            last = step(k, 1 + k)
+        sync()
+        elapsed = time.perf_counter() - t0
+        elapsed = max_over_ranks(elapsed, dist, device="cpu" if rehearsal else "cuda")
+        # kernel durations of the timed launches (HIP events recorded on the launch streams, read now)
+        kernel_ms, n_launches = [], 0
+        for ln, b0 in zip(lanes, before):
+            nl = int(ln["integ"].timed_launches()) - b0   # a step is one launch unless a batch exceeds the launch limit
+            n_launches += nl
+            if nl:
+                kernel_ms += [float(x) for x in ln["integ"].kernel_ms_history(min(nl, 64))]
+        return dict(scaling=scaling, elapsed=elapsed, steps=steps, mine=mine, per_step=per_step, total_per_step=total_per_step,
+                    kernel_ms=kernel_ms, launches_per_step=n_launches / steps, last=last)
+
+    # N = 1: weak and strong are the same run.  N > 1 without --scaling: the metric's case -- ONE batch of the workload's
+    # photons per step, sharded over the GPUs (strong) -- is the headline; the weak figure (every GPU the whole batch) is
+    # measured after it and reported beside it.
+    headline = a.scaling or ("strong" if n_gpus > 1 else "weak")
+    m = measure(headline, a.steps, a.warmup)
+    weak = None
+    if a.scaling is None and n_gpus > 1:
+        mw = measure("weak", a.steps, 1)
+        weak = {"value": float(mw["total_per_step"]) * mw["steps"] / mw["elapsed"], "unit": "photons/s", "ms_per_step": mw["elapsed"] / mw["steps"] * 1e3,
+                "photons_per_step": mw["total_per_step"], "photons_per_gpu_per_step": mw["mine"], "steps": mw["steps"],
+                "note": "weak scaling measured after the headline run: every GPU traces the workload's whole batch per step"}
+        m["last"] = None   # (the lanes now hold the weak run's tallies: the result check below uses what it left)
+        check = mw
+    else:
+        check = m
+    elapsed, mine, per_step, total_per_step = m["elapsed"], m["mine"], m["per_step"], m["total_per_step"]
+    kernel_ms, launches_per_step = m["kernel_ms"], m["launches_per_step"]
     # ---- results of the last step (already all-reduced across ranks) ------------------------------------
-    raw = tally.cpu().numpy()
+    raw = check["last"]["tally"].cpu().numpy()
     res = integ.finish(raw)
     counters = res["counters"]
     # the last step's tallies must be those of exactly one step: every photon leaves through the top, ends at the
     # surface / by roulette or is dropped by the tracer -- a wrong count or a lost / doubled tally shows here
-    if counters["photons"] != float(total_per_step):
-        sys.stderr.write(f"bench: inconsistent results (photons {counters['photons']:.0f}, expected {total_per_step})\n")
+    if counters["photons"] != float(check["total_per_step"]):
+        sys.stderr.write(f"bench: inconsistent results (photons {counters['photons']:.0f}, expected {check['total_per_step']})\n")
         return 4
     albedo = w.get("surface", 0.0)
     if albedo == 0.0 and not absorbing:
@@ -312,13 +374,15 @@ def worker(a):
         devices = gathered
 
     if rank == 0:
-        share = mine / float(total_per_step)   # this rank's share of the (all-reduced) work counters
-        local = {k: v * share for k, v in counters.items()}
+        share = check["mine"] / float(check["total_per_step"])   # this rank's share of the (all-reduced) work counters
+        local = {k: v * share / check["mine"] * mine for k, v in counters.items()}   # ... scaled to a headline step's photons
         avg_ms = float(np.mean(kernel_ms)) * launches_per_step     # kernel time per step on this rank
         kbpp, kskd = algorithmic_bytes_per_photon(local, nd, absorbing)        # what this kernel actually did
-        # Algorithmic bytes follow SURVEY.md 8(d): the formula evaluated with the work per photon of the REFERENCE'S
-        # ALGORITHM on this input, counted by the CPU restatement.  For flux-only workloads the kernel does exactly that
-        # work; with the local estimate's roulette it leaves out rays that are known to contribute nothing (kernel_work).
+        # roofline.achieved: SURVEY.md 8(d)'s byte formula evaluated with THE KERNEL'S OWN work counters.  With the local
+        # estimate's roulette the kernel leaves out rays that are known to contribute nothing, so it touches fewer bytes than
+        # the reference's loop would on the same input; that figure -- the formula with the work per photon of the REFERENCE'S
+        # ALGORITHM, counted by the CPU restatement -- is reported beside it as reference_equivalent.  Flux-only kernels do
+        # exactly the reference's work: there the two are the same.
         ref, ref_src = None, None
         if cpu_baseline and cpu_baseline.get("oracle_per_photon"):
             ref, ref_src = cpu_baseline["oracle_per_photon"], "CPU restatement (oracle) on this workload, counted in this run's cpu_baseline leg"
@@ -326,13 +390,16 @@ def worker(a):
             ref, ref_src = W.REFERENCE_WORK[name], "CPU-restatement-equivalent counters recorded in tools/workloads.py (REFERENCE_WORK)"
         if ref is None or nd == 0:
             ref, ref_src = kskd, "the kernel's own counters (flux only: identical to the reference's algorithm)"
-        bpp = 16 * ref["S"] + 20 * ref["K"] + (16 * ref["K"] if absorbing else 0) + 8 * ref["E"] + 24 * ref["K"] * nd
-        skd = dict(S=ref["S"], K=ref["K"], E=ref["E"], D=nd)
-        achieved = bpp * mine / (avg_ms * 1e-3) / 1e9
-        kernel_work = {"per_photon": kskd, "bytes_per_photon": kbpp, "GBps": kbpp * mine / (avg_ms * 1e-3) / 1e9,
-                       "frac": kbpp * mine / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        rbpp = 16 * ref["S"] + 20 * ref["K"] + (16 * ref["K"] if absorbing else 0) + 8 * ref["E"] + 24 * ref["K"] * nd
+        achieved = kbpp * mine / (avg_ms * 1e-3) / 1e9
+        ref_achieved = rbpp * mine / (avg_ms * 1e-3) / 1e9
+        reference_equivalent = {"achieved": ref_achieved, "frac": ref_achieved / HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_photon": rbpp,
+                                "per_photon": dict(S=ref["S"], K=ref["K"], E=ref["E"], D=nd), "per_photon_source": ref_src,
+                                "note": "what the REFERENCE'S loop would touch on this input in the kernel's time (it traces every local-estimate ray "
+                                        "before it plays the ray's roulette); the kernel's own bytes are roofline.achieved"}
+        kernel_work = {"per_photon": kskd, "bytes_per_photon": kbpp, "GBps": achieved, "frac": achieved / HBM_PEAK_GBS,
                        "rays_skipped_per_photon": local.get("raysSkipped", 0.0) / mine,
-                       "note": "the kernel's own counters: local-estimate rays whose roulette is lost before the trace are not traced"}
+                       "note": "the kernel's own counters (= roofline.achieved): local-estimate rays whose roulette is lost before the trace are not traced"}
         pmc = load_pmc(name)
         traffic = measured = issue = None
         if pmc:
@@ -352,6 +419,8 @@ def worker(a):
                                              "v_rcp / v_sqrt / v_log 8.2: the 2-cycle figure holds for the simplest class only, "
                                              "this kernel's mix is issued at its own pace",
                      "useful_lane_frac": rate / ISSUE_PEAK * pmc["lane_occupancy"]}
+        if cpu_baseline is not None:
+            cpu_baseline["calibration"] = load_calibration(name)
         total_photons = float(total_per_step) * a.steps
         value = total_photons / elapsed
         line = {
@@ -363,29 +432,34 @@ def worker(a):
             "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": a.scaling,
+            "scaling": headline,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{w['label']}; {mine:.4g} photons per GPU per step" +
-                                   (f" ({per_step:.4g} per step sharded over {n_gpus} GPUs)" if a.scaling == "strong" else ""),
+                                   (f" ({per_step:.4g} per step sharded over {n_gpus} GPUs)" if headline == "strong" else ""),
                        "name": name, "baseline_config_index": w["baseline_config"],
                        "photons_per_gpu_per_step": mine, "photons_per_step": total_per_step,
                        "parallelism": (f"photon batches sharded over {n_gpus} GPUs, one RCCL all-reduce of the float64 tally "
                                        f"buffer ({lay.total * 8} bytes) per step" if n_gpus > 1 else "single GPU"),
+                       "steps_in_flight": len(lanes),
+                       "overlap": ("two steps in flight: two handles, each with a stream and a tally buffer of its own, take the steps in turn -- "
+                                   "the tail and the all-reduce of step k overlap the trace of step k + 1" if overlap else
+                                   "none: zero, trace, all-reduce one after the other on one stream"),
                        "rng": "Philox4x32-10 per photon, key (iseed=10, batch)"},
             "world_size": dist.get_world_size() if dist is not None else 1,
             "backend": (dist.get_backend() if dist is not None else None),
             "devices": devices,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "achieved_is": "ALGORITHMIC bytes (SURVEY.md 8d formula x the S/K/E/D per photon of the reference's algorithm "
-                                        "on this input, see per_photon_source) / kernel time: a model of what the reference loop touches, "
-                                        "NOT bytes that crossed the HBM interface (measured_hbm_GBps) and not the kernel's own work (kernel_work)",
+                         "achieved_is": "ALGORITHMIC bytes (SURVEY.md 8d formula x the S/K/E/D per photon THIS KERNEL counted, see per_photon) / kernel "
+                                        "time: NOT bytes that crossed the HBM interface (measured_hbm_GBps); the same formula with the reference "
+                                        "algorithm's work per photon is reference_equivalent",
                          "measured_hbm_GBps": measured,
                          "measured_hbm_frac": (measured / HBM_PEAK_GBS if measured is not None else None),
                          "kernel": integ.kernel_name(), "kernel_ms_avg": avg_ms, "launches_per_step": launches_per_step,
-                         "algorithmic_bytes_per_photon": bpp, "per_photon": skd, "per_photon_source": ref_src,
+                         "algorithmic_bytes_per_photon": kbpp, "per_photon": kskd, "per_photon_source": "the kernel's own work counters (this run's last step)",
+                         "reference_equivalent": reference_equivalent,
                          "kernel_work": kernel_work,
                          "issue": issue,
                          "note": "working set is LDS/L2 resident: the path is vector-issue bound, not HBM bound -- see `issue` (DESIGN.md section 5)"},
@@ -393,13 +467,16 @@ def worker(a):
             "result_check": {"meanFluxUp": float(res["fluxUp"].mean()), "meanFluxDown": float(res["fluxDown"].mean()),
                              "dropped_fraction": counters["dropped"] / counters["photons"]},
         }
+        if weak is not None:
+            line["weak"] = weak
         if nd:
             line["result_check"]["meanIntensity"] = [float(x) for x in res["intensity"].mean(axis=(1, 2))]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    integ.finalize_Integrator()
+    for ln in lanes:
+        ln["integ"].finalize_Integrator()
     return 0
 
 
