@@ -97,6 +97,9 @@ def wait_for_ranks(procs, poll_s=0.2, grace_s=10.0):
             break
         time.sleep(poll_s)
     if failed:
+        t_fail = time.time()   # (ranks that fail for the same reason -- no GPU, a bad argument -- say so themselves within a moment)
+        while time.time() - t_fail < 3.0 and any(p.poll() is None for p in procs):
+            time.sleep(poll_s)
         for p in procs:
             if p.poll() is None:
                 p.terminate()

@@ -91,3 +91,78 @@ def test_bench_launcher_starts_n_ranks_and_reports_their_failure_without_a_gpu()
     assert r.returncode != 0
     assert r.stderr.count("bench.py needs a GPU") == 2, r.stderr
     assert "rank exit codes [3, 3]" in r.stderr
+
+
+# ---- eight ranks: a batch sharded by photon range, one all-reduce, the reference's normalisation -----------------------
+def _philox_vec(photon, key):
+    """Philox4x32-10 block (photon, 0, 0, 0) of every photon of an int64 array: words 0 and 1 are a photon's start
+    position (photon_kernel, part C), whichever rank traces it."""
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), 0x9E3779B9, 0xBB67AE85
+    mask = np.uint64(0xFFFFFFFF)
+    c0, c1 = (photon.astype(np.uint64) & mask), (photon.astype(np.uint64) >> np.uint64(32))
+    c2, c3 = np.zeros_like(c0), np.zeros_like(c0)
+    k0, k1 = key
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0)) & mask, p1 & mask, ((p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1)) & mask, p0 & mask
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    return c0, c1
+
+
+def _beer_lambert_shard(first, n, tau, key):
+    """The closed-form physics of a black (omega = 0) 1-D-column domain under an overhead sun, photon by photon from the
+    photon's OWN Philox stream: it starts over column floor(u0 nx) and either reaches the surface (fluxDown, counted when
+    u1 < exp(-tau)) or is absorbed on the way (fluxAbsorbed).  Packed like the tally buffer: up | down | absorbed | counters."""
+    ncol = len(tau)
+    idx = np.arange(first, first + n, dtype=np.int64)
+    w0, w1 = _philox_vec(idx, key)
+    u0 = (w0.astype(np.float64) / 4294967295.0).astype(np.float32)
+    u1 = (w1.astype(np.float64) / 4294967295.0).astype(np.float32)
+    col = np.minimum((u0 * np.float32(ncol)).astype(np.int64), ncol - 1)
+    through = u1 < np.exp(-tau[col])
+    t = np.zeros(3 * ncol + 16, np.float64)
+    np.add.at(t, ncol + col[through], 1.0)
+    np.add.at(t, 2 * ncol + col[~through], 1.0)
+    t[3 * ncol] = n
+    return t
+
+
+def _normalise(t, ncol):
+    """computeRadiativeTransfer :353-356 on a regular grid: tallies / (photons / columns)."""
+    return t[:3 * ncol].reshape(3, ncol) / (t[3 * ncol] / ncol)
+
+
+def _worker8(rank, world, port, n_total, tau, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, n = shard_photons(n_total, world, rank)
+    t = torch.from_numpy(_beer_lambert_shard(first, n, tau, (10, 1)))
+    all_reduce_tallies(t, dist)
+    if rank == world - 1:     # (any rank holds the sum: an all-reduce, not a reduce to rank 0)
+        np.save(out, t.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_shard_reduce_normalise(tmp_path):
+    """World size 8 (the node BASELINE.json's configs 3 and 4 are quoted on): one batch sharded over the ranks by
+    multigpu.shard_photons, each rank's photons traced from their own Philox streams, ONE all-reduce of the packed float64
+    buffer, the reference's normalisation -- equal to the unsharded batch in every bit, and to Beer-Lambert within 4 sigma."""
+    n_total, ncol = 400003, 16
+    tau = np.linspace(0.1, 3.0, ncol).astype(np.float32)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "reduced8.npy")
+    mp.spawn(_worker8, args=(8, port, n_total, tau, out), nprocs=8, join=True)
+    got = np.load(out)
+    want = _beer_lambert_shard(0, n_total, tau, (10, 1))
+    assert np.array_equal(got, want)
+    assert got[3 * ncol] == n_total
+    flux = _normalise(got, ncol)
+    assert np.all(flux[0] == 0.0)
+    per_col = n_total / ncol
+    assert np.all(np.abs(flux[1] - np.exp(-tau)) < 4 * np.sqrt(np.exp(-tau) * (1 - np.exp(-tau)) / per_col) + 4 / per_col)
+    assert np.allclose(flux[1] + flux[2], flux[1:].sum(axis=0))
+    assert abs((flux[1] + flux[2]).mean() - 1.0) < 1e-12
