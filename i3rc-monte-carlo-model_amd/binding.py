@@ -14,8 +14,8 @@ ip = C.POINTER(C.c_int32)
 lp = C.POINTER(C.c_int64)
 up = C.POINTER(C.c_uint32)
 
-MAX_COMPONENTS = 8
-MAX_DIRECTIONS = 20
+MAX_COMPONENTS = 255
+MAX_DIRECTIONS = 255
 NUM_COUNTERS = 16
 COUNTER_NAMES = ["photons", "dropped", "cellSteps", "scatterings", "surfaceHits", "exitsTop", "roulette",
                  "shadowSteps", "tracerCalls", "rngDraws", "raysSkipped"]

@@ -29,6 +29,9 @@ bool poison() { static const bool on = std::getenv("I3RC_POISON") != nullptr; re
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { if (p) (void)hipFree(p); }
   hipError_t upload(const void *src, size_t n) {
     hipError_t e = alloc(n);
@@ -60,9 +63,9 @@ struct i3rc_hip_integrator {
   DevBuf dExtBrick;              // totalExt in bricks of 32 cells (DevProblem::extBrick)
   bool compDirty = true;         // comp[] changed since its device copy (dComp) was made
   int bsx = 0, bsy = 0, bsz = 0, nbx = 0, nby = 0, nbz = 0;
-  DevBuf dInv[I3RC_MAX_COMPONENTS], dInvCos[I3RC_MAX_COMPONENTS], dFwd[I3RC_MAX_COMPONENTS], dFwdOrig[I3RC_MAX_COMPONENTS];
-  CompTables comp[I3RC_MAX_COMPONENTS] = {};
-  int nInvEntries[I3RC_MAX_COMPONENTS] = {}, nFwdEntries[I3RC_MAX_COMPONENTS] = {};
+  std::vector<DevBuf> dInv, dInvCos, dFwd, dFwdOrig;   // per component (sized by i3rc_hip_create)
+  std::vector<CompTables> comp;
+  std::vector<int> nInvEntries, nFwdEntries;
   DevBuf dComp;
   DevBuf dXs, dYs, dBrdf;
   int nxs = 0, nys = 0;
@@ -72,7 +75,7 @@ struct i3rc_hip_integrator {
   i3rc_params params{};
   float maxExt = 0.f;
   int xyRegular = 0, zRegular = 0;
-  int maxPfIndex[I3RC_MAX_COMPONENTS] = {};
+  std::vector<int> maxPfIndex;
   float uniformSsa = -1.f;   // one-component domains: the value every cell shares, else -1
   int uniformPf = 0;         // ... and the phase-function entry every cell shares, else 0
 
@@ -249,7 +252,7 @@ int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int n
   if (!out) { g_createError = "i3rc_hip_create: null handle pointer"; return 1; }
   *out = nullptr;
   if (nx < 1 || ny < 1 || nz < 1 || ncomp < 1 || ncomp > I3RC_MAX_COMPONENTS) {
-    g_createError = "i3rc_hip_create: bad dimensions (need nx,ny,nz >= 1 and 1 <= ncomp <= 8)";
+    g_createError = "i3rc_hip_create: bad dimensions (need nx,ny,nz >= 1 and 1 <= ncomp <= 255)";
     return 1;
   }
   if ((int64_t)nx * ny * nz > (int64_t)1 << 30 || (int64_t)nx * ny >= (int64_t)1 << 24 || nz >= 1 << 24) {
@@ -274,6 +277,8 @@ int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int n
   auto *h = new i3rc_hip_integrator();
   h->device = device;
   h->nx = nx; h->ny = ny; h->nz = nz; h->ncomp = ncomp;
+  h->dInv = std::vector<DevBuf>(ncomp); h->dInvCos = std::vector<DevBuf>(ncomp); h->dFwd = std::vector<DevBuf>(ncomp); h->dFwdOrig = std::vector<DevBuf>(ncomp);
+  h->comp.assign(ncomp, CompTables{}); h->nInvEntries.assign(ncomp, 0); h->nFwdEntries.assign(ncomp, 0); h->maxPfIndex.assign(ncomp, 0);
   auto bail = [&](const char *what, hipError_t er) {
     g_createError = std::string(what) + ": " + hipGetErrorString(er);
     delete h;
@@ -331,7 +336,7 @@ int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int n
   CCHK(h->dSsa.upload(ssa, sizeof(float) * ncell * ncomp));
   CCHK(h->dPf.upload(pfIndex, sizeof(int32_t) * ncell * ncomp));
   CCHK(h->workCounter.alloc(sizeof(unsigned long long)));
-  CCHK(h->dComp.alloc(sizeof(CompTables) * I3RC_MAX_COMPONENTS));
+  CCHK(h->dComp.alloc(sizeof(CompTables) * ncomp));
   CCHK(h->dDir.alloc(sizeof(float) * 3 * I3RC_MAX_DIRECTIONS));
   CCHK(hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking));
   h->stream = h->ownStream;
@@ -469,7 +474,7 @@ int i3rc_hip_set_surface(i3rc_hip_integrator *h, int nxs, int nys, const float *
 int i3rc_hip_set_directions(i3rc_hip_integrator *h, int nDir, const float *dirCos) {
   if (!h) return 1;
   drop_lookahead(h);
-  if (nDir < 0 || nDir > I3RC_MAX_DIRECTIONS) return h->fail("i3rc_hip_set_directions: 0 <= nDir <= 20 required");
+  if (nDir < 0 || nDir > I3RC_MAX_DIRECTIONS) return h->fail("i3rc_hip_set_directions: 0 <= nDir <= 255 required");
   if (nDir > 0 && !dirCos) return h->fail("i3rc_hip_set_directions: null directions");
   for (int d = 0; d < nDir; ++d)
     if (std::fabs(dirCos[3 * d + 2]) < FLT_MIN) return h->fail("specifyParameters: intensityMus can't be 0 (directly sideways)");  // :932-933
@@ -580,6 +585,10 @@ struct LaunchPlan {
 };
 
 constexpr size_t kLdsBudget = 64 * 1024;  // per workgroup: leaves room for >= 2 workgroups per CU
+// ... which what a launch MUST have in LDS -- the edge vectors, the directions, the ray queues -- may exceed, up to the 160 KB of a
+// compute unit (less the kernels' few static words): a 2-D domain of 20 000 columns runs with one workgroup per CU, slowly,
+// instead of being refused
+constexpr size_t kLdsHard = 158 * 1024;
 
 // Which kernel runs a launch (see photon_kernel): the common problem class -- regular grid,
 // ray tracing, one component, no BRDF grid, Directional source -- has specialised kernels.
@@ -626,7 +635,7 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false) {
     // the stream has drained (launches in flight read the old descriptors), not an asynchronous copy from the
     // pageable handle per launch
     if (hipStreamSynchronize(h->stream) != hipSuccess ||
-        hipMemcpy(h->dComp.p, h->comp, sizeof(CompTables) * I3RC_MAX_COMPONENTS, hipMemcpyHostToDevice) != hipSuccess)
+        hipMemcpy(h->dComp.p, h->comp.data(), sizeof(CompTables) * h->ncomp, hipMemcpyHostToDevice) != hipSuccess)
       return h->fail("copying the component table descriptors failed");
     h->compDirty = false;
   }
@@ -663,7 +672,7 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false) {
   if (h->nDir > 0)
     for (int c = 0; c < h->ncomp; ++c)
       if (h->maxPfIndex[c] >= 65536) return h->fail("radiance runs take at most 65535 phase-function table entries per component");
-  if (lds > kLdsBudget) return h->fail("domain edge vectors do not fit in LDS");
+  if (lds > kLdsHard) return h->fail("domain edge vectors do not fit in LDS (nx + ny + nz beyond about 39 000)");
   const size_t budget = kLdsBudget;
   P.ldsTallies = 0;
   // (a fused multi-batch launch tallies per batch, straight into global memory: no partial sums in LDS)
@@ -674,7 +683,7 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false) {
     if (!fused && h->nDir > 0 && nInt <= 16 * 1024 && lds + nInt <= kLdsBudget) { P.ldsIntensity = 1; lds += nInt; }
   }
   P.ldsGrid = 0;
-  if (lds + ncell * sizeof(float) <= budget) { P.ldsGrid = 1; lds += ncell * sizeof(float); }
+  if (lds + ncell * sizeof(float) <= budget) { P.ldsGrid = 1; lds += ncell * sizeof(float); }   // (never when the edges alone are beyond the budget)
   plan.ldsBytes = (lds + 15) & ~(size_t)15;
   plan.intensity = h->nDir > 0;
   return 0;
@@ -1247,15 +1256,14 @@ int i3rc_hip_trace_rays(i3rc_hip_integrator *h, int64_t n, const float *dir, flo
   HIPCHK(h, hipSetDevice(h->device));
   LaunchPlan plan;
   // tables are not needed for bare tracing: build the problem without the completeness checks
-  CompTables saved[I3RC_MAX_COMPONENTS];
-  std::memcpy(saved, h->comp, sizeof(saved));
+  const std::vector<CompTables> saved = h->comp;
   static const float dummy = 0.f;
   for (int c = 0; c < h->ncomp; ++c) if (!h->comp[c].inv) h->comp[c].inv = &dummy;
   const int savedDir = h->nDir;
   h->nDir = 0;
   const int rc = make_problem(h, plan);
   h->nDir = savedDir;
-  std::memcpy(h->comp, saved, sizeof(saved));
+  h->comp = saved;
   h->compDirty = true;
   if (rc) return 1;
   plan.P.ldsGrid = 0; plan.P.ldsTallies = 0;

@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
   lds_float *const qBase = L.queue + (threadIdx.x >> 6) * (kRecWords * P.rayQueueCap + kReadyWords * kReadyRays);
   lds_float *const rdBase = qBase + kRecWords * P.rayQueueCap;   // ready rays: word w of slot s at rdBase[w * kReadyRays + s]
   const unsigned qMask = (unsigned)P.rayQueueCap - 1u;
-  const unsigned qMagic = (65536u + (unsigned)P.nDir - 1u) / (unsigned)(P.nDir > 0 ? P.nDir : 1);   // t / nDir = (t * qMagic) >> 16 for t < 200
+  const unsigned qMagic = ((1u << 20) + (unsigned)P.nDir - 1u) / (unsigned)(P.nDir > 0 ? P.nDir : 1);   // t / nDir = (t * qMagic) >> 20 for t < nDir + 64 <= 319 (nDir <= 255)
   bool pendingShadow = false;
   float wI = 0.0f, inDx = 0.0f, inDy = 0.0f, inDz = 0.0f;   // of the event being pushed
   int evInfo = 0;
@@ -640,7 +640,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
             const lds_float *evRec = qBase;
             if (lane < n) {                                                  // next radiance direction (:1473-1510)
               const unsigned t = qHeadSub + (unsigned)lane;
-              const unsigned eOff = (t * qMagic) >> 16;
+              const unsigned eOff = (t * qMagic) >> 20;
               const int dIdx = (int)(t - eOff * (unsigned)Px.nDir);
               const lds_float *rec = qBase + ((qHeadEv + eOff) & qMask);
               const int cap = Px.rayQueueCap;
@@ -693,7 +693,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
             }
             {   // ring bookkeeping (wave-uniform)
               const unsigned t = qHeadSub + (unsigned)n;
-              const unsigned e = (t * qMagic) >> 16;
+              const unsigned e = (t * qMagic) >> 20;
               qHeadEv += e; qHeadSub = t - e * (unsigned)Px.nDir;
               const unsigned kept = (unsigned)__popcll(keepMask);
               rdTail += kept;

@@ -29,7 +29,7 @@ module i3rcHipInterface
   end type i3rc_tally_layout
 
   integer, parameter :: I3RC_CNT_PHOTONS = 0, I3RC_CNT_DROPPED = 1
-  integer, parameter :: I3RC_MAX_COMPONENTS = 8, I3RC_MAX_DIRECTIONS = 20
+  integer, parameter :: I3RC_MAX_COMPONENTS = 255, I3RC_MAX_DIRECTIONS = 255
 
   interface
     function i3rc_hip_create(h, device, nx, ny, nz, ncomp, xEdges, yEdges, zEdges, totalExt, cumExt, ssa, pfIndex) &

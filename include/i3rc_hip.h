@@ -28,8 +28,10 @@ extern "C" {
 
 typedef struct i3rc_hip_integrator i3rc_hip_integrator;
 
-#define I3RC_MAX_COMPONENTS 8
-#define I3RC_MAX_DIRECTIONS 20 /* Example-Drivers/monteCarloDriver.f95:63 maxNumRad */
+/* The reference limits neither (Code/opticalProperties.f95:133-230, monteCarloRadiativeTransfer.f95:1026-1045; its driver reads
+ * at most 20 directions, Example-Drivers/monteCarloDriver.f95:63 maxNumRad): here a ray record carries either in 8 bits. */
+#define I3RC_MAX_COMPONENTS 255
+#define I3RC_MAX_DIRECTIONS 255
 
 /* Algorithm switches and scalars: the private components of type(integrator)
  * (monteCarloRadiativeTransfer.f95:50-142) that specifyParameters (:830-1069) sets. */

@@ -117,7 +117,7 @@ def test_config4_landsat_seven_radiances_lambertian_surface_object(oracle):
 
 # ---- configs 2 and 4 at 1e6+ photons: the oracle's sample is produced by a child program on the host cores while the
 #      GPU traces its own (as the 1e8 step-cloud test does) -------------------------------------------------------------
-def _oracle_child(tmp_path, config, cores, per_core, photons):
+def _oracle_child(tmp_path, config, cores, per_core, photons, columns=False):
     import os
     import subprocess
     import sys
@@ -125,7 +125,7 @@ def _oracle_child(tmp_path, config, cores, per_core, photons):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / f"oracle_{config}.npz")
     child = subprocess.Popen([sys.executable, os.path.join(root, "tools", "cpu_baseline.py"), "--config", config, "--cores", str(cores),
-                              "--batches-per-core", str(per_core), "--photons", str(photons), "--save", out],
+                              "--batches-per-core", str(per_core), "--photons", str(photons), "--save", out] + (["--save-columns"] if columns else []),
                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     return child, out
 
@@ -183,9 +183,9 @@ def test_config4_landsat_seven_radiances_at_1e6_photons(tmp_path):
     import os
 
     cores = min(16, len(os.sched_getaffinity(0)))
-    per_core, n_ref = 4, 1_000_000 // (cores * 4)
-    child, out = _oracle_child(tmp_path, "landsat119_7dir", cores, per_core, n_ref)
-    gr = _gpu_batches("landsat119_7dir", 40, 25_000)                      # 1e6 photons on the GPU meanwhile
+    per_core, n_ref = 4, 2_000_000 // (cores * 4)
+    child, out = _oracle_child(tmp_path, "landsat119_7dir", cores, per_core, n_ref, columns=True)
+    gr = _gpu_batches("landsat119_7dir", 40, 200_000)                     # 8e6 photons on the GPU meanwhile
     so, se = child.communicate(timeout=900)
     assert child.returncode == 0, so + se
     z = np.load(out)
@@ -193,6 +193,74 @@ def test_config4_landsat_seven_radiances_at_1e6_photons(tmp_path):
         _assert_means_3sigma([r[key].mean(dtype=np.float64) for r in gr], z["means"][:, k], key)
     for d in range(7):                                                      # every direction on its own
         _assert_means_3sigma([r["intensity"][d].mean(dtype=np.float64) for r in gr], z["intensityMeans"][:, d], f"radiance {d}")
-    n_g, n_o = 25_000 * len(gr), n_ref * len(z["nBad"])
+    # per column: the 3-sigma statistic of config 2 over the 7 x 16384 radiance columns and the flux fields
+    from tests.test_gpu_parity import _assert_3sigma
+    # The fields, column by column.  Config 2's per-cell statistic (_assert_3sigma: excursions beyond 3 sigma counted against
+    # Student's t) assumes Gaussian batch means; here a column sees two photons per oracle batch and a local-estimate field is
+    # made of a few large contributions among many small ones: on numbers that agree the count of 3-sigma excursions is 2.5
+    # times what t allows.  So: (1) that statistic on BLOCKS of 4 x 4 columns (8 x 8 for the fluxes), batches pooled four /
+    # eight to a group, where the means are Gaussian; (2) per column, statistics that do not lean on the tails -- the mean
+    # of z^2 (1.14 for t with 16 degrees of freedom), and no structure in the difference field: it must not correlate with
+    # the field's gradient along x or y (a radiance tallied one column off would).
+    def pooled(rs, k, block):
+        def f(a, key):
+            a = a.astype(np.float64)
+            b = block if key == "intensity" else 2 * block
+            return a if block == 1 else a.reshape(a.shape[:-2] + (128 // b, b, 128 // b, b)).mean(axis=(-3, -1))
+        return [{key: np.mean([f(r[key], key) for r in rs[i:i + k]], axis=0) for key in ("fluxUp", "fluxDown", "intensity")}
+                for i in range(0, len(rs) - k + 1, k)]
+    orr = [dict(fluxUp=u, fluxDown=dn, intensity=i) for u, dn, i in zip(z["fluxUp"], z["fluxDown"], z["intensity"])]
+    gp, op = pooled(gr, 4, 4), pooled(orr, 8, 4)
+    assert len(gp) == 10 and len(op) == cores * per_core // 8 and gp[0]["intensity"].shape == (7, 32, 32) and gp[0]["fluxUp"].shape == (16, 16)
+    for key in ("intensity", "fluxUp", "fluxDown"):
+        _assert_3sigma(gp, op, key, floor=1e-7)
+    from tests.test_gpu_parity import _mean_se
+    g1, o1 = pooled(gr, 4, 1), pooled(orr, 8, 1)
+    mg, sg = _mean_se(g1, "intensity")
+    mo, so_ = _mean_se(o1, "intensity")
+    zz = (mg - mo) / np.sqrt(sg ** 2 + so_ ** 2 + 1e-14)
+    assert 0.8 < np.mean(zz ** 2) < 1.6, np.mean(zz ** 2)
+    for k in range(7):
+        diff, field = (mg[k] - mo[k]), 0.5 * (mg[k] + mo[k])
+        lim = 6.0 / np.sqrt(diff.size)
+        # (the gradient at a column is made of its NEIGHBOURS: independent of the column's own noise, which the field itself is not)
+        for what, other in (("x gradient", np.roll(field, 1, axis=1) - np.roll(field, -1, axis=1)),
+                            ("y gradient", np.roll(field, 1, axis=0) - np.roll(field, -1, axis=0))):
+            c = np.corrcoef(diff.ravel(), other.ravel())[0, 1]
+            assert abs(c) < lim, (k, what, c, lim)
+    n_g, n_o = 200_000 * len(gr), n_ref * len(z["nBad"])
     dg, do = sum(r["counters"]["dropped"] for r in gr) / n_g, z["nBad"].sum() / n_o
     assert abs(dg - do) < 3 * np.sqrt(do / n_g + do / n_o) + 1e-5, (dg, do)
+
+
+@pytest.mark.parametrize("config,nb,n", [("landsat_tiled", 10, 40_000), ("landsat_tiled_7dir", 10, 20_000)])
+def test_fields_beyond_16_MB_against_the_oracle(tmp_path, config, nb, n):
+    """The Landsat scene tiled 2 x 2 (256 x 256 x 119: 31 MB of extinction) runs the instantiation and the launch set-up of fields
+    beyond 16 MB -- bricks, four workgroups per CU, the XCD-aware photon order also for radiance runs: here against the
+    oracle on the same domain (4e5 / 2e5 photons a side), domain means of the fluxes and of every radiance direction, the
+    dropped-photon rate, the work per photon."""
+    import os
+
+    cores = min(16, len(os.sched_getaffinity(0)))
+    per_core = 2
+    n_ref = nb * n // (cores * per_core)
+    child, out = _oracle_child(tmp_path, config, cores, per_core, n_ref)
+    from tools import workloads as W
+
+    name, w = W.get(config)
+    g, d = W.make_integrator(w)
+    rs = [g.computeRadiativeTransfer(M.new_RandomNumberSequence((77, b)), M.new_PhotonStream(w["mu0"], 0.0, n)) for b in range(1, nb + 1)]
+    assert "GRID_BRICKS" in g.kernel_name()
+    g.finalize_Integrator()
+    so, se = child.communicate(timeout=900)
+    assert child.returncode == 0, so + se
+    z = np.load(out)
+    for k, key in enumerate(("fluxUp", "fluxDown")):
+        _assert_means_3sigma([r[key].mean(dtype=np.float64) for r in rs], z["means"][:, k], key)
+    for k in range(W.n_dir(w)):
+        _assert_means_3sigma([r["intensity"][k].mean(dtype=np.float64) for r in rs], z["intensityMeans"][:, k], f"radiance {k}")
+    n_g, n_o = n * nb, n_ref * len(z["nBad"])
+    dg, do = sum(r["counters"]["dropped"] for r in rs) / n_g, z["nBad"].sum() / n_o
+    assert abs(dg - do) < 3 * np.sqrt(do / n_g + do / n_o) + 2e-5, (dg, do)
+    kg = sum(r["counters"]["scatterings"] for r in rs) / n_g
+    assert abs(kg - z["scatterings"].sum() / n_o) < 0.02 * kg

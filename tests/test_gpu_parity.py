@@ -222,13 +222,13 @@ def _assert_3sigma(gpu, ref, key, floor=1e-9, frac_ok=None):
     assert abs(dg.mean() - dr.mean()) <= t, (key, dg.mean(), dr.mean(), t)
 
 
-def _parity(oracle, g, o, nb, n, mu0, az=0.0, keys=("fluxUp", "fluxDown"), floor=1e-9):
+def _parity(oracle, g, o, nb, n, mu0, az=0.0, keys=("fluxUp", "fluxDown"), floor=1e-9, iseed=10):
     """Two-stage 3-sigma test.  Stage 1: nb batches of n photons on both sides (seeds (10, b)).  A suite of ~60
     such assertions would raise a false alarm every few runs (P(|t| > 3) ~ 1 % at these batch counts), so a
     failure is re-examined once with an independent, twice as large sample (seeds (11, b)); a real bias fails both
     stages, a fluctuation passes the second with probability > 99 %.  Returns the batches that were accepted."""
     try:
-        gr, orr = _batches_gpu(g, nb, n, mu0, az), _batches_oracle(oracle, o, nb, n, mu0, az)
+        gr, orr = _batches_gpu(g, nb, n, mu0, az, iseed=iseed), _batches_oracle(oracle, o, nb, n, mu0, az, iseed=iseed)
         for key in keys:
             _assert_3sigma(gr, orr, key, floor=floor)
         return gr, orr
@@ -238,8 +238,8 @@ def _parity(oracle, g, o, nb, n, mu0, az=0.0, keys=("fluxUp", "fluxDown"), floor
         from tests.conftest import record_stage1_miss
         caller = next((f.function for f in inspect.stack()[1:] if f.function.startswith("test_")), "?")
         record_stage1_miss(caller, first.args)
-        gr = _batches_gpu(g, 2 * nb, n, mu0, az, iseed=11)
-        orr = _batches_oracle(oracle, o, 2 * nb, n, mu0, az, iseed=11)
+        gr = _batches_gpu(g, 2 * nb, n, mu0, az, iseed=iseed + 1)
+        orr = _batches_oracle(oracle, o, 2 * nb, n, mu0, az, iseed=iseed + 1)
         try:
             for key in keys:
                 _assert_3sigma(gr, orr, key, floor=floor)

@@ -30,7 +30,7 @@ REFERENCE_NOTES = {
 
 
 def _worker(args):
-    first_batch, n_batches, photons, config, nlayers, mu0 = args
+    first_batch, n_batches, photons, config, nlayers, mu0, columns = args
     import numpy as np
 
     from oracle import pyoracle as O
@@ -49,7 +49,7 @@ def _worker(args):
         ph = O.photons_directional(rng, mu0, 0.0, photons)
         r = integ.compute(rng, *ph)
         fu += float(r["fluxUp"].mean())
-        small = r["fluxUp"].size <= 5000     # per-column fields of small domains; domain means (float64) of all
+        small = columns or r["fluxUp"].size <= 5000     # per-column fields of small domains (or on request); domain means (float64) of all
         inten = r.get("intensity")
         cols.append(dict(fluxUp=r["fluxUp"].copy() if small else None, fluxDown=r["fluxDown"].copy() if small else None,
                          intensity=inten.copy() if (small and inten is not None) else None,
@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--photons", type=int, default=0, help="photons per batch (0 = the workload's bounded sample)")
     ap.add_argument("--nlayers", type=int, default=0, help="step cloud only: 16 = BASELINE.json label, 32 = reference generator")
     ap.add_argument("--mu0", type=float, default=None)
+    ap.add_argument("--save-columns", action="store_true", help="with --save: per-column fields whatever the size of the domain")
     ap.add_argument("--save", default="", help="write per-batch results to this .npz: domain means of every batch, per-column fields of small domains")
     a = ap.parse_args()
     from oracle import pyoracle as O
@@ -79,7 +80,7 @@ def main():
         name, w = W.get("step32")
     photons = a.photons or w["cpu_photons"]
     cores = a.cores or min(16, len(os.sched_getaffinity(0)))
-    jobs = [(1 + i * a.batches_per_core, a.batches_per_core, photons, name, a.nlayers, a.mu0) for i in range(cores)]
+    jobs = [(1 + i * a.batches_per_core, a.batches_per_core, photons, name, a.nlayers, a.mu0, a.save_columns) for i in range(cores)]
     t0 = time.perf_counter()
     with ProcessPoolExecutor(max_workers=cores) as ex:
         res = list(ex.map(_worker, jobs))
