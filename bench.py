@@ -52,8 +52,8 @@ def parse_args():
     ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
                     help="default: N = 1 -> the same thing; N > 1 -> strong (ONE batch of --photons photons per step sharded over the GPUs: the "
                          "metric's case) as the headline, the weak figure measured after it and reported beside it")
-    ap.add_argument("--overlap", choices=("auto", "0", "1"), default="auto",
-                    help="two steps in flight (two handles / streams / tally buffers); auto = on for N > 1")
+    ap.add_argument("--overlap", choices=("auto", "0", "1", "2"), default="auto",
+                    help="1: two steps in flight (two handles / streams / tally buffers), 2: three; auto = 1 for N > 1, else 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
     if a.gpus < 1:
@@ -267,9 +267,9 @@ def worker(a):
     # --overlap 1): two handles, each with a stream and a tally buffer of its own, take the steps in turn, so that the tail
     # of step k -- its last photons keep a few wavefronts busy for a millisecond, a quarter of a 1.25e7-photon shard -- and
     # its all-reduce overlap the trace of step k + 1.  Every step still zeroes, traces and reduces its own buffer.
-    overlap = (n_gpus > 1) if a.overlap == "auto" else (a.overlap == "1")
+    overlap = (n_gpus > 1) if a.overlap == "auto" else (a.overlap != "0")
     lanes = []
-    for k in range(2 if overlap else 1):
+    for k in range(1 if not overlap else (3 if a.overlap == "2" else 2)):
         integ, d = W.make_integrator(w, device=local_rank)
         lay = integ.layout()
         tally = torch.zeros(lay.total, dtype=torch.float64, device="cuda")
@@ -446,7 +446,7 @@ def worker(a):
                        "parallelism": (f"photon batches sharded over {n_gpus} GPUs, one RCCL all-reduce of the float64 tally "
                                        f"buffer ({lay.total * 8} bytes) per step" if n_gpus > 1 else "single GPU"),
                        "steps_in_flight": len(lanes),
-                       "overlap": ("two steps in flight: two handles, each with a stream and a tally buffer of its own, take the steps in turn -- "
+                       "overlap": (f"{len(lanes)} steps in flight: as many handles, each with a stream and a tally buffer of its own, take the steps in turn -- "
                                    "the tail and the all-reduce of step k overlap the trace of step k + 1" if overlap else
                                    "none: zero, trace, all-reduce one after the other on one stream"),
                        "rng": "Philox4x32-10 per photon, key (iseed=10, batch)"},

@@ -61,6 +61,8 @@ struct i3rc_hip_integrator {
   std::vector<float> xE, yE, zE;  // host copies (normalisation, checks)
   DevBuf dxE, dyE, dzE, dExt, dCum, dSsa, dPf;
   DevBuf dExtBrick;              // totalExt in bricks of 32 cells (DevProblem::extBrick)
+  DevBuf dClearMap;              // ... and its clear-air map (DevProblem::clearMap)
+  int clearShift = 0, clearNx = 1, clearWords = 1;
   bool compDirty = true;         // comp[] changed since its device copy (dComp) was made
   int bsx = 0, bsy = 0, bsz = 0, nbx = 0, nby = 0, nbz = 0;
   std::vector<DevBuf> dInv, dInvCos, dFwd, dFwdOrig;   // per component (sized by i3rc_hip_create)
@@ -331,6 +333,23 @@ int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int n
           brick[b * 32 + w] = totalExt[((size_t)k * ny + j) * nx + i];
         }
     CCHK(h->dExtBrick.upload(brick.data(), sizeof(float) * brick.size()));
+    // clear-air map: lowest / highest layer with any extinction per footprint of 2^s x 2^s columns, at most 1024 words
+    int sft = 0;
+    while ((size_t)(((nx - 1) >> sft) + 1) * (size_t)(((ny - 1) >> sft) + 1) > 1024) ++sft;
+    h->clearShift = sft; h->clearNx = ((nx - 1) >> sft) + 1;
+    const int cny = ((ny - 1) >> sft) + 1;
+    h->clearWords = h->clearNx * cny;
+    std::vector<uint32_t> lo((size_t)h->clearWords, 0xffffu), hi((size_t)h->clearWords, 0u), map((size_t)h->clearWords);
+    for (int k = 0; k < nz; ++k)
+      for (int j = 0; j < ny; ++j)
+        for (int i = 0; i < nx; ++i)
+          if (totalExt[((size_t)k * ny + j) * nx + i] != 0.0f) {   // (NaN or negative values count as "something there": they are read as before)
+            const size_t c = (size_t)(j >> sft) * h->clearNx + (size_t)(i >> sft);
+            lo[c] = std::min<uint32_t>(lo[c], (uint32_t)std::min(k + 1, 0xfffe));
+            hi[c] = std::max<uint32_t>(hi[c], (uint32_t)std::min(k + 1, 0xffff));
+          }
+    for (size_t c = 0; c < map.size(); ++c) map[c] = lo[c] | (hi[c] << 16);
+    CCHK(h->dClearMap.upload(map.data(), sizeof(uint32_t) * map.size()));
   }
   CCHK(h->dCum.upload(cumExt, sizeof(float) * ncell * ncomp));
   CCHK(h->dSsa.upload(ssa, sizeof(float) * ncell * ncomp));
@@ -628,6 +647,7 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false) {
   // bricks pay off once the field no longer fits in one XCD's 4 MB of L2
   P.extBrick = (ncell_bytes(h) > ((size_t)4 << 20)) ? (const float *)h->dExtBrick.p : nullptr;
   P.bsx = h->bsx; P.bsy = h->bsy; P.bsz = h->bsz; P.nbx = h->nbx; P.nbxy = h->nbx * h->nby;
+  P.clearMap = (const uint32_t *)h->dClearMap.p; P.clearShift = h->clearShift; P.clearNx = h->clearNx;
   P.totalExt = (const float *)h->dExt.p; P.cumExt = (const float *)h->dCum.p; P.ssa = (const float *)h->dSsa.p;
   P.pfIndex = (const int32_t *)h->dPf.p;
   if (h->compDirty) {
@@ -684,6 +704,7 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false) {
   }
   P.ldsGrid = 0;
   if (lds + ncell * sizeof(float) <= budget) { P.ldsGrid = 1; lds += ncell * sizeof(float); }   // (never when the edges alone are beyond the budget)
+  else if (P.extBrick && h->nDir == 0) lds += sizeof(uint32_t) * (size_t)h->clearWords;          // bricked field, flux kernels: its clear-air map
   plan.ldsBytes = (lds + 15) & ~(size_t)15;
   plan.intensity = h->nDir > 0;
   return 0;
@@ -740,6 +761,18 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
         {photon_kernel<Rng, true, false, GRID_LDS>, photon_kernel<Rng, true, false, GRID_GLOBAL>, photon_kernel<Rng, true, false, GRID_BRICKS>}};
     if (simple) kern = special[plan.intensity ? 1 : 0][place];
   }
+  // experiment (I3RC_TABLE_LDS=1): the inverse table's cosines in LDS, workgroups of 1024 threads (photon_kernel, TBL)
+  int threads = 256;
+  size_t ldsBytes = plan.ldsBytes;
+  if constexpr (!Rng::kReplay) {
+    static const bool tblOn = std::getenv("I3RC_TABLE_LDS") && std::atoi(std::getenv("I3RC_TABLE_LDS")) != 0;
+    if (tblOn && simple && !plan.intensity && place == GRID_LDS && plan.P.uniformPf >= 1 &&
+        plan.ldsBytes + sizeof(float) * (size_t)plan.P.comp0.nInv <= 79 * 1024) {
+      kern = photon_kernel<Rng, false, false, GRID_LDS, true>;
+      threads = 1024;
+      ldsBytes = (plan.ldsBytes + sizeof(float) * (size_t)plan.P.comp0.nInv + 15) & ~(size_t)15;
+    }
+  }
   const void *fn = (const void *)kern;
   {
     static const char *const placeName[3] = {"GRID_LDS", "GRID_GLOBAL", "GRID_BRICKS"};
@@ -747,11 +780,12 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
     std::snprintf(name, sizeof(name), "photon_kernel<%s, %s, %s, %s>", Rng::kReplay ? "ReplayStream" : "PhiloxStream",
                        plan.intensity ? "true" : "false", (simple ? "false" : "true"), placeName[place]);
     h->lastKernelName = name;
+    if (threads == 1024) h->lastKernelName = "photon_kernel<PhiloxStream, false, false, GRID_LDS, table in LDS>";
   }
   int perCU = h->blocksPerCU;
   if (perCU <= 0) {
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, plan.ldsBytes) != hipSuccess || occ < 1) occ = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, threads, ldsBytes) != hipSuccess || occ < 1) occ = 2;
     perCU = std::min(occ, 8);
     // a field beyond an XCD's L2 (bricks): every wave in flight widens the part of it that is in use; measured on the
     // 7.8 MB Landsat-119 field (tools/blocks_sweep.py): 4-5 workgroups per CU 6.17e8 photons/s, 6-8 5.83e8.  (The radiance
@@ -760,10 +794,10 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
     // 5 5.02e8, 6-8 4.6e8.
     if (place == GRID_BRICKS) perCU = std::min(perCU, ncell_bytes(h) > ((size_t)16 << 20) ? 4 : 5);
   }
-  if (plan.ldsBytes > 48 * 1024)
-    HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.ldsBytes));
+  if (ldsBytes > 48 * 1024)
+    HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
   long long blocks = (long long)h->numCU * perCU;
-  const long long need = (A.nPhotons + 255) / 256;
+  const long long need = (A.nPhotons + threads - 1) / threads;
   if (blocks > need) blocks = std::max(1ll, need);
   RunArgs B = A;   // photon indices are handed to waves in chunks (one returning atomic per chunk)
   // XCD-aware photon order.  A field beyond an XCD's L2 (bricks) is shared by eight L2s that each see all of it: when
@@ -802,7 +836,7 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
   // tuning knob): 128 loses a third (a returning atomic every other generation), 256...448 are equal, 1024 loses
   // 0.5 % on the step cloud and 2-5 % on the radar / Landsat cases to the imbalance at the end of a launch.
   static const long long chunkMax = std::getenv("I3RC_CHUNK_MAX") ? std::max(64ll, std::atoll(std::getenv("I3RC_CHUNK_MAX"))) : 256;
-  B.chunk = (int)std::min<long long>(chunkMax, std::max<long long>(64, A.nPhotons / (blocks * 4 * 8)));
+  B.chunk = (int)std::min<long long>(chunkMax, std::max<long long>(64, A.nPhotons / (blocks * (threads / 64) * 8)));
   HIPCHK(h, hipMemsetAsync(A.workCounter, 0, sizeof(unsigned long long), h->stream));
   const int slot = (int)(h->timedLaunches % i3rc_hip_integrator::kEventRing);
   if (timeIt) HIPCHK(h, hipEventRecord(h->evStart[slot], h->stream));
@@ -810,7 +844,7 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
     // thresholds the caller did not fix are adapted per wave (photon_kernel); negative = adaptive, starting value
     const int evThreshold = h->evThreshold > 0 ? h->evThreshold : -40;
     const int lightThreshold = h->lightThreshold > 0 ? h->lightThreshold : -24;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), plan.ldsBytes, h->stream, plan.P, B, evThreshold, lightThreshold);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads), ldsBytes, h->stream, plan.P, B, evThreshold, lightThreshold);
   }
   HIPCHK(h, hipGetLastError());
   if (timeIt) { HIPCHK(h, hipEventRecord(h->evStop[slot], h->stream)); h->timedLaunches++; }
@@ -1272,7 +1306,8 @@ int i3rc_hip_trace_rays(i3rc_hip_integrator *h, int64_t n, const float *dir, flo
   HIPCHK(h, dDir.upload(dir, sizeof(float) * 3 * n)); HIPCHK(h, dPos.upload(pos, sizeof(float) * 3 * n));
   HIPCHK(h, dIdx.upload(idx, sizeof(int32_t) * 3 * n)); HIPCHK(h, dTar.upload(target, sizeof(float) * n));
   HIPCHK(h, dTau.alloc(sizeof(float) * n)); HIPCHK(h, dSteps.alloc(sizeof(int32_t) * n));
-  const size_t lds = sizeof(float) * ((h->nx + 1) + (h->ny + 1) + (h->nz + 1));
+  const size_t lds = sizeof(float) * ((h->nx + 1) + (h->ny + 1) + (h->nz + 1)) + sizeof(uint32_t) * (size_t)h->clearWords;
+  if (lds > 64 * 1024) return h->fail("i3rc_hip_trace_rays: domain edge vectors do not fit in LDS");
   hipLaunchKernelGGL(trace_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, h->stream, plan.P, (long long)n,
                      (const float *)dDir.p, (float *)dPos.p, (int32_t *)dIdx.p, (const float *)dTar.p, (float *)dTau.p,
                      (int32_t *)dSteps.p);

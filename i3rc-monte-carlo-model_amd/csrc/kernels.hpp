@@ -191,6 +191,9 @@ struct RngInit<ReplayStream> {
 // bounds are wave-uniform and held in scalar registers (readfirstlane tells the compiler so).
 struct Reservoir {
   long long next, end;   // (XCD-aware order: positions in the sorted list; end < 0: every tile has run dry)
+  // (Shorter chunks towards the end of a launch -- what is left shared out over all waves, down to one photon per lane -- were
+  // tried in round 3: nothing at 1e8 photons, -1 % at 1.25e7, -6 % at 1e6.  A launch ends with its longest photon histories,
+  // not with the last chunks.)
   __device__ __forceinline__ void refill() {   // call in uniform control flow only
     const ColdArgs k = cold_args();
     unsigned long long *const counter = k->A.workCounter;
@@ -333,17 +336,22 @@ __global__ void __launch_bounds__(256) slab_fill_kernel(uint32_t seed0, uint32_t
 #ifndef I3RC_FLUX_WAVES
 #define I3RC_FLUX_WAVES 8
 #endif
-// (the fused multi-batch kernels carry five more vector registers per lane: the batch and the per-lane counts)
+// (the fused multi-batch kernels carry five more vector registers per lane -- the batch and the per-lane counts -- and want 66:
+// planned for seven waves per SIMD they keep them all; for eight, two go to scratch and nothing is gained: 2.97 against
+// 2.83 ... 3.06e9 photons/s on the step cloud, 1.22 against 1.08e9 on the radar field, within the noise elsewhere)
 #ifndef I3RC_FUSED_WAVES
-#define I3RC_FUSED_WAVES 8
+#define I3RC_FUSED_WAVES 7
 #endif
 // GENERAL = false is the specialisation for the common problem class -- regular grid, ray tracing, one component,
 // Lambertian albedo (no BRDF grid), Directional source, production RNG: the rare paths (grid searches, periodic
 // re-wrapping loops, max-cross-section moves, BRDF lookups, component selection) are compiled out, which shrinks the
 // loop's code and its scalar-register pressure.  GENERAL = true keeps every path behind run-time switches.
 // (radiance kernels keep two rays per lane live -- the photon's and a shadow ray's: 4 waves per SIMD give them 128 vector registers)
-template <class Rng, bool INTENSITY, bool GENERAL, int GRID>
-__global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_WAVES) : ((GENERAL || GRID == GRID_BRICKS) ? I3RC_MIN_WAVES : (Rng::kBatched ? I3RC_FUSED_WAVES : I3RC_FLUX_WAVES))) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
+// TBL (experiment of round 3, specialised flux kernel with the grid in LDS only): workgroups of 1024 threads, two per compute
+// unit, that also keep the 40 KB of the inverse table's cosines in LDS: the two dependent table reads of a scattering then
+// come from LDS instead of L2.
+template <class Rng, bool INTENSITY, bool GENERAL, int GRID, bool TBL = false>
+__global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_WAVES) : ((GENERAL || GRID == GRID_BRICKS) ? I3RC_MIN_WAVES : (Rng::kBatched ? I3RC_FUSED_WAVES : I3RC_FLUX_WAVES))) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   {
@@ -360,6 +368,8 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
     L.tInt = p;
     if (P.ldsIntensity) p += (P.ncomp + 1) * P.nDir * ncol;
     L.ext = p;
+    if (GRID == GRID_LDS) p += P.nx * P.ny * P.nz;
+    L.cosTab = p;
   }
   for (int i = threadIdx.x; i < 3 * P.nDir; i += blockDim.x) L.dirCos[i] = P.dirCos[i];
   // coalesced staging of the edge vectors (and the extinction grid when it fits)
@@ -372,8 +382,16 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
     const int ncell = P.nx * P.ny * P.nz;
     for (int i = threadIdx.x; i < ncell; i += blockDim.x) L.ext[i] = P.totalExt[i];
   }
+  if (GRID == GRID_BRICKS && !INTENSITY) {   // the clear-air map of a bricked field (DevProblem::clearMap): flux kernels, see cell_extinction
+    const int nWords = P.clearNx * (((P.ny - 1) >> P.clearShift) + 1);
+    for (int i = threadIdx.x; i < nWords; i += blockDim.x) L.ext[i] = __uint_as_float(P.clearMap[i]);
+  }
   if (P.ldsIntensity)
     for (int i = threadIdx.x; i < (P.ncomp + 1) * P.nDir * P.nx * P.ny; i += blockDim.x) L.tInt[i] = 0.0f;
+  if (TBL) {
+    const float *src = P.comp0.invCos + (size_t)(P.uniformPf - 1) * P.comp0.nInv;
+    for (int i = threadIdx.x; i < P.comp0.nInv; i += blockDim.x) L.cosTab[i] = src[i];
+  }
   __syncthreads();
 
   constexpr bool REPLAY = Rng::kReplay;        // per-photon fates are recorded by i3rc_hip_run_replay only
@@ -1099,8 +1117,9 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
               if (w <= kTiny) { if (REPLAY) fate = 2; st = ST_NEW; }
               else {
                 const CompTables ct = GENERAL ? load_tables(Pe.comp[comp - 1]) : load_tables(Pe.comp0);
-                const float cosS = scattering_cosine<REPLAY>(rng.first(), ct.invCos + (size_t)(pfi - 1) * ct.nInv, ct.nInv,
-                                                             refined_rcp((float)ct.nInv));
+                float cosS;
+                if constexpr (TBL) cosS = scattering_cosine<REPLAY>(rng.first(), (const lds_float *)L.cosTab, ct.nInv, refined_rcp((float)ct.nInv));
+                else cosS = scattering_cosine<REPLAY>(rng.first(), ct.invCos + (size_t)(pfi - 1) * ct.nInv, ct.nInv, refined_rcp((float)ct.nInv));
                 next_direct(rng, cosS, r.dx, r.dy, r.dz);                 // :684-687
                 st = ST_TRACE;
               }
@@ -1157,7 +1176,7 @@ __global__ void __launch_bounds__(256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_
       PROF_BEGIN();
       if (tracing) {
         if constexpr (BATCHED) accSteps++;
-        const StepResult s = trace_step<GRID>(P, L, r, true);
+        const StepResult s = trace_step<GRID, !INTENSITY>(P, L, r, true);
         // (an exit through the top, or onto a black surface, ends the photon: such lanes wait for the turnover quorum)
         if (s != STEP_CONTINUE)
           st = s == STEP_DONE ? ST_EVENT : (s == STEP_ERROR ? ST_DROPPED : ((r.iz >= 1 || blackSurface) ? ST_EXIT : ST_EVENT));
@@ -1228,7 +1247,9 @@ __global__ void __launch_bounds__(256) trace_rays_kernel(const DevProblem P, lon
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   L.xE = (lds_float *)smem; L.yE = L.xE + P.nx + 1; L.zE = L.yE + P.ny + 1;
-  L.tUp = L.tDown = L.tAbs = L.ext = L.dirCos = nullptr;
+  L.tUp = L.tDown = L.tAbs = L.dirCos = nullptr;
+  L.ext = L.zE + P.nz + 1;   // the clear-air map of the bricked field (this hook always reads the bricks)
+  for (int i = threadIdx.x; i < P.clearNx * (((P.ny - 1) >> P.clearShift) + 1); i += blockDim.x) L.ext[i] = __uint_as_float(P.clearMap[i]);
   for (int i = threadIdx.x; i <= P.nx; i += blockDim.x) L.xE[i] = P.xE[i];
   for (int i = threadIdx.x; i <= P.ny; i += blockDim.x) L.yE[i] = P.yE[i];
   for (int i = threadIdx.x; i <= P.nz; i += blockDim.x) L.zE[i] = P.zE[i];
@@ -1245,7 +1266,7 @@ __global__ void __launch_bounds__(256) trace_rays_kernel(const DevProblem P, lon
   r.target = target[i];
   int ns = 0;
   StepResult s;
-  do { ns++; s = trace_step<GRID_BRICKS>(P, L, r, hasTarget); } while (s == STEP_CONTINUE && ns < (1 << 24));
+  do { ns++; s = trace_step<GRID_BRICKS, true>(P, L, r, hasTarget); } while (s == STEP_CONTINUE && ns < (1 << 24));
   pos[3 * i] = r.x; pos[3 * i + 1] = r.y; pos[3 * i + 2] = r.z;
   idx[3 * i] = r.ix; idx[3 * i + 1] = r.iy; idx[3 * i + 2] = r.iz;
   tau[i] = r.acc;

@@ -43,6 +43,13 @@ struct DevProblem {
   // of two, 2^bsx x 2^bsy x 2^bsz cells; brick (X, Y, Z) starts at float 32 (X + nbx (Y + nby Z)).
   const float *extBrick;               // null: the grid is small enough to stay in L2 as it is (cheaper index)
   int bsx, bsy, bsz, nbx, nbxy;
+  // ... and with it the CLEAR-AIR MAP (bricked fields only): for every footprint of 2^clearShift x 2^clearShift columns the
+  // lowest and the highest layer that hold any extinction at all (one word: lo | hi << 16, 1-based; an empty footprint has
+  // lo > hi), at most 4 KB, staged in LDS.  A cell outside [lo, hi] has extinction 0 -- the value the field holds -- without
+  // a memory request: a third of the Landsat scene is clear air above the cloud tops, which every local-estimate ray
+  // crosses on its way out, and those steps' loads were most of the field's traffic beyond L2.
+  const uint32_t *clearMap;
+  int clearShift, clearNx;
   const float *cumExt, *ssa;          // [ncomp][nz][ny][nx]
   const int32_t *pfIndex;             // [ncomp][nz][ny][nx]
   const CompTables *comp;             // [ncomp] phase-function tables (device memory: indexed per lane)
@@ -106,9 +113,10 @@ typedef __attribute__((address_space(3))) float lds_float;
 struct Lds {
   lds_float *xE, *yE, *zE;    // edges
   lds_float *tUp, *tDown, *tAbs;  // privatised flux tallies (valid when ldsTallies)
-  lds_float *ext;             // totalExt copy (valid when ldsGrid)
+  lds_float *ext;             // totalExt copy (valid when ldsGrid); bricked fields: the clear-air map (DevProblem::clearMap) as words
   lds_float *dirCos;          // intensity directions
   lds_float *tInt;            // privatised intensityByComponent (valid when ldsIntensity)
+  lds_float *cosTab;          // the inverse table's cosines (one entry) where a kernel keeps them in LDS (photon_kernel, TBL)
   lds_float *queue;           // [waves][kRecWords][rayQueueCap]: every wave's ring of local-estimate events (see kernels.hpp)
 };
 __device__ __forceinline__ void lds_add(lds_float *p, float v) { atomicAdd((float *)p, v); }
@@ -268,9 +276,18 @@ __device__ __forceinline__ int brick_index(const PR &P, int ix, int iy, int iz) 
 // grid that lives in global memory and read zeros (found by the replay tests on the I3RC radar / Landsat fields;
 // tests/test_build_isa.py keeps the pattern out of the kernels).
 enum GridPlace { GRID_LDS = 0, GRID_GLOBAL = 1, GRID_BRICKS = 2 };
-template <int GRID, class PR>
+// CLEARMAP: consult the clear-air map of a bricked field first (DevProblem::clearMap).  The flux kernels do -- Landsat-119 6.6 ->
+// 7.2e8 photons/s, the scene tiled 2 x 2 5.5 -> 6.0e8 --; the radiance kernels do not: the look-up is an LDS read in front of
+// every load, and with five waves per SIMD and no register to carry it a step ahead it cost them 11 %.
+template <int GRID, bool CLEARMAP = false, class PR>
 __device__ __forceinline__ float cell_extinction(const PR &P, const Lds &L, int ix, int iy, int iz) {
   if (GRID == GRID_LDS) return L.ext[cell_index(P, ix, iy, iz)];   // ds_read
+  if (GRID == GRID_BRICKS && CLEARMAP) {
+    const uint32_t range = __float_as_uint(L.ext[__umul24((unsigned)(iy - 1) >> P.clearShift, (unsigned)P.clearNx) + ((unsigned)(ix - 1) >> P.clearShift)]);
+    const unsigned z = (unsigned)iz;
+    if (z < (range & 0xffffu) || z > (range >> 16)) return 0.0f;   // clear air: what the field holds there, without asking for it
+    return P.extBrick[brick_index(P, ix, iy, iz)];
+  }
   if (GRID == GRID_BRICKS) return P.extBrick[brick_index(P, ix, iy, iz)];
   return P.totalExt[cell_index(P, ix, iy, iz)];
 }
@@ -281,11 +298,11 @@ __device__ __forceinline__ float cell_extinction(const PR &P, const Lds &L, int 
 // escapes): on a 64-lane wavefront the lanes take the reference's if/else arms in every combination at every step,
 // so branches would execute both arms anyway and add exec-mask bookkeeping on top.  The arithmetic of each arm is
 // exactly the reference's (checked bit for bit against the oracle by the tracer tests).
-template <int GRID, class PR>
+template <int GRID, bool CLEARMAP = false, class PR>
 __device__ __forceinline__ StepResult trace_step(const PR &P, const Lds &L, Ray &r, bool hasTarget) {
   // the extinction of the current cell is requested first: its latency (LDS, or L2 / HBM for grids that do not fit
   // in LDS) is covered by the three face-distance divisions below
-  const float ext = cell_extinction<GRID>(P, L, r.ix, r.iy, r.iz);
+  const float ext = cell_extinction<GRID, CLEARMAP>(P, L, r.ix, r.iy, r.iz);
   const int cx = r.cx, cy = r.cy, cz = r.cz;
   const float ex = lds_read(r.ex + (r.ix << 2)), ey = lds_read(r.ey + (r.iy << 2)), ez = lds_read(r.ez + (r.iz << 2));
   float stx, sty, stz;
@@ -381,8 +398,8 @@ __device__ __forceinline__ void find_z(const PR &P, const Lds &L, float z, int &
 // interpolation weight `left` is < 1/n, cos((1-left) T(k) + left T(k+1)) and (1-left) cos T(k) + left cos T(k+1)
 // differ by < left * dT^2 / 2 ~ 1e-11, far below one float32 ulp: the same cosine without a 57-op cosf per event.
 // EXACT = false (production streams): (k - 1) / n by reciprocal -- `left` only weights the two neighbouring entries.
-template <bool EXACT = true>
-__device__ __forceinline__ float scattering_cosine(float r, const float *cosTab, int n, float rcpN) {
+template <bool EXACT = true, class Tab = const float *>
+__device__ __forceinline__ float scattering_cosine(float r, Tab cosTab, int n, float rcpN) {
   const int k = (int)(r * (float)n) + 1;
   if (k < n) {
     const float left = r - (EXACT ? exact_div((float)(k - 1), (float)n, rcpN) : (float)(k - 1) * rcpN);
