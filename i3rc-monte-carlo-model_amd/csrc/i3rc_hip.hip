@@ -894,11 +894,12 @@ int fused_replicas(const i3rc_hip_integrator *h) {
 }
 
 // Batches per group: device memory for the blocks (<= 1 GiB) and the pinned copy (<= 256 MiB) bound it; beyond that a
-// group wants some 1e8 photons (its tail, a millisecond, is covered by the next group anyway).
+// group wants some 2.5e8 photons: a group boundary costs about 2.4 ms even with the next group queued behind it (step
+// cloud, 300 batches of 1e6 photons: 15 groups 0.38, 6 groups 0.34, 3 groups 0.33, 1 group 0.31 ms per batch).
 int fused_group_size(const i3rc_hip_integrator *h, int nBatches, int64_t nPhotons) {
   const int64_t blockBytes = h->layout.total * 8, R = fused_replicas(h);
   int64_t g = std::min<int64_t>(((int64_t)1 << 30) / (blockBytes * R), ((int64_t)256 << 20) / blockBytes);
-  static const int64_t target = std::getenv("I3RC_FUSED_GROUP_PHOTONS") ? std::atoll(std::getenv("I3RC_FUSED_GROUP_PHOTONS")) : 100000000ll;
+  static const int64_t target = std::getenv("I3RC_FUSED_GROUP_PHOTONS") ? std::atoll(std::getenv("I3RC_FUSED_GROUP_PHOTONS")) : 250000000ll;
   g = std::min<int64_t>(g, (target + nPhotons - 1) / nPhotons);
   return (int)std::max<int64_t>(1, std::min<int64_t>(g, nBatches));
 }
@@ -1149,7 +1150,8 @@ int i3rc_hip_compute_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed
   };
   hipStream_t const callerStream = h->stream;
   double *const callerTally = h->tally;
-  auto start = [&](int k, uint32_t s1) -> int {   // zero, trace, copy back: asynchronous on the slot's stream
+  auto start = [&](int k, uint32_t s1, bool timed) -> int {   // zero, trace, copy back: asynchronous on the slot's stream (batches launched
+                                                               // ahead of the caller are not recorded in the ring of timed launches)
     if (ready_slot(h, k)) return 1;
     auto &sl = h->pipe[k];
     h->stream = sl.stream; h->tally = (double *)sl.tally.p;
@@ -1166,7 +1168,7 @@ int i3rc_hip_compute_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed
       RunArgs part = A;
       part.firstPhoton = done;
       part.nPhotons = std::min(perLaunch, nPhotons - done);
-      rc = launch<PhiloxStream>(h, plan, part, true);
+      rc = launch<PhiloxStream>(h, plan, part, timed);
     }
     if (!rc && (hipMemcpyAsync(sl.pinned, sl.tally.p, bytes, hipMemcpyDeviceToHost, sl.stream) != hipSuccess ||
                 hipEventRecord(sl.done, sl.stream) != hipSuccess))
@@ -1216,7 +1218,7 @@ int i3rc_hip_compute_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed
   } else {
     mine = free_slot();
     if (mine < 0) return h->fail("i3rc_hip_compute_batch: no free slot");
-    if (start(mine, seed1)) { drop_lookahead(h); return 1; }
+    if (start(mine, seed1, true)) { drop_lookahead(h); return 1; }
   }
   h->pipe[mine].batch = 0;   // (in use until its tallies have been handed over)
   // look ahead once the caller's loop shows: the same batch as last time with the next seed word (monteCarloDriver.f95:277)
@@ -1230,7 +1232,7 @@ int i3rc_hip_compute_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed
     while ((int)h->aheadQueue.size() < depth) {
       const uint32_t next = (h->aheadQueue.empty() ? seed1 : h->aheadQueue.back().seed1) + 1u;
       const int k = free_slot();
-      if (k < 0 || start(k, next)) break;   // (a failed look-ahead is not this batch's failure: the error text stays for the next call)
+      if (k < 0 || start(k, next, false)) break;   // (a failed look-ahead is not this batch's failure: the error text stays for the next call)
       h->aheadQueue.push_back({next, k});
     }
   }

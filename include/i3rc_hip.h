@@ -156,18 +156,25 @@ int i3rc_hip_launch_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1
 
 /* The batch loop of a driver as ONE call (Example-Drivers/monteCarloDriver.f95:283-326: per batch a random-number
  * sequence seeded (/iseed, batch/), a photon stream of numPhotonsPerBatch photons, computeRadiativeTransfer,
- * reportResults).  Batch k = 0 .. nBatches-1 is traced with the key (seed0, seed1 + k) into a tally buffer of its own;
+ * reportResults).  Batch k = 0 .. nBatches-1 is traced with the key (seed0, seed1 + k) into tallies of its own;
  * its raw tallies (layout of i3rc_hip_get_tally_layout, float64; normalise them with i3rc_hip_normalise) are written
  * to hostTallies + k * layout.total.  Every batch equals i3rc_hip_zero_tallies + i3rc_hip_launch_batch(seed0,
- * seed1 + k, 0, nPhotons) + i3rc_hip_fetch_tallies, photon for photon.
- * Up to inFlight batches (1..8; 0 = 6) are on the device at a time, each on a HIP stream of its own: a batch ends with
- * a long tail -- the few photons of a million that scatter a thousand times keep a handful of wavefronts busy for a
- * millisecond -- and the next batch's photons fill the machine meanwhile.  At the reference drivers' batch sizes
- * (1e5 ... 1e6 photons) that is 2-3 times the throughput of one call per batch.  (Streams share
- * GPU_MAX_HW_QUEUES hardware queues, default 4: with GPU_MAX_HW_QUEUES=8 in the environment of the process the gain is
- * another 10-15 %.)
- * Directional sources only (an explicit stream differs from batch to batch).  Synchronous: returns when all batches
- * are in hostTallies; the handle's own tally buffer and stream are not touched. */
+ * seed1 + k, 0, nPhotons) + i3rc_hip_fetch_tallies, photon for photon: the same integer work counters, tallies equal to
+ * the order of the float64 additions.
+ * A batch ends with a long tail -- the few photons of a million that scatter a thousand times keep a handful of
+ * wavefronts busy for a millisecond --, so batches of the reference drivers' size (1e5 ... 1e6 photons) must overlap:
+ *   - FUSED (flux problems of the common class: regular x / y grid, ray tracing, one component, no BRDF grid, no radiance
+ *     directions; two batches or more of at most 2e7 photons): a group of consecutive batches is ONE kernel launch
+ *     (photon_kernel<PhiloxBatchStream, ...>).  Every lane carries the batch of its photon in its Philox key, tallies
+ *     go to per-batch blocks in global memory (spread over replicas where a domain has few columns), work counters are
+ *     gathered per lane and handed over per batch: one batch's tail is filled by the next batch's photons inside the
+ *     launch.  Groups hold about 2.5e8 photons (bounded by 1 GiB of tally blocks), up to three groups are in flight.  Step
+ *     cloud, 1e6-photon batches: 0.33 ms per batch (3.0e9 photons/s) against 1.6 ms one call at a time.
+ *   - otherwise up to inFlight batches (1..8; 0 = 6) are on the device at a time, each a launch on a HIP stream of its
+ *     own with its own tally buffer (GPU_MAX_HW_QUEUES=8 in the environment gives these another 10-15 %).
+ * i3rc_hip_set_batch_fusion chooses between the two.  Directional sources only (an explicit stream differs from batch
+ * to batch).  Synchronous: returns when all batches are in hostTallies; the handle's own tally buffer and stream are
+ * not touched. */
 int i3rc_hip_run_batches(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int nBatches, int64_t nPhotons,
                          const i3rc_source *src, int inFlight, double *hostTallies);
 
@@ -176,12 +183,15 @@ int i3rc_hip_run_batches(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1,
  * that LOOKS AHEAD: the reference's drivers call computeRadiativeTransfer once per batch with
  * seed = (/iseed, batch/) (monteCarloDriver.f95:277, :287), and a call cannot return before the batch's last photon has
  * (the tail of a launch: see i3rc_hip_run_batches).  When a call is the same batch as the previous call with the next
- * seed word, the library takes that for such a loop and launches up to lookAhead (0..7) following batches (seed1 + 1,
- * seed1 + 2, ...) behind this one; the next call then finds its batch under way or done.  A call that is not the
- * expected batch (other seed, photon count, sun), and every change of the problem (tables, parameters, surface,
- * directions, tuning), waits for the batches launched ahead and forgets them: results never depend on the guess, a wrong
- * guess costs the device time of the discarded batches.  Unchanged reference driver, 1000 batches of 1e6 photons on the
- * step cloud: 2.0 s -> 1.2 s.  Directional sources only.  Synchronous. */
+ * seed word, the library takes that for such a loop and traces the following batches (seed1 + 1, seed1 + 2, ...) behind
+ * this one: on problems whose batches can share a grid in FUSED GROUPS of 8, 16, 32, 64 ... batches (up to three groups
+ * under way), else up to lookAhead (0..7; 0 = never look ahead) single batches; the next call then finds its batch under
+ * way or done.  A call that is not the expected batch (other seed, photon count, sun), and every change of the problem
+ * (tables, parameters, surface, directions, tuning), calls the work launched ahead off -- fused groups poll an abort word
+ * and end within one chunk per wavefront --, waits for it and forgets it: results never depend on the guess, a wrong
+ * guess (and the end of the loop) costs the device a few milliseconds.  So does i3rc_hip_destroy.  Launches made ahead are
+ * not recorded in i3rc_hip_kernel_ms_history.  Unchanged reference driver, 1000 batches of 1e6 photons on the step
+ * cloud, process start to result files: 2.2 s (one launch per call) -> 0.8 s.  Directional sources only.  Synchronous. */
 int i3rc_hip_compute_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int64_t nPhotons,
                            const i3rc_source *src, int lookAhead, double *hostTallies);
 
@@ -245,7 +255,7 @@ int i3rc_hip_set_launch_limit(i3rc_hip_integrator *h, int64_t photons);
  * problems the specialised flux kernels run, two batches or more of at most 2e7 photons), 0 = never (every batch a launch
  * of its own, several in flight), 1 = whenever the problem allows.  Environment: I3RC_FUSED=0 switches fusion off for the
  * process, I3RC_FUSED_CHUNK (photons a wavefront takes from one batch at a time, default 512) and
- * I3RC_FUSED_GROUP_PHOTONS (photons per fused launch, default 1e8) are tuning knobs. */
+ * I3RC_FUSED_GROUP_PHOTONS (photons per fused launch, default 2.5e8) are tuning knobs. */
 int i3rc_hip_set_batch_fusion(i3rc_hip_integrator *h, int mode);
 
 /* Test / tuning knob.  A launch normally (AUTO) runs the one-photon-per-lane kernel specialised for the common

@@ -9,7 +9,10 @@
  * netCDF-Fortran, which this image lacks, and the build rules forbid stand-in libraries, so no oracle/_ref binary
  * exists; the reference ships no tests, golden vectors or expected outputs.  What the restatement is pinned against:
  * (i) closed forms of the very loop -- Beer-Lambert transmission per column and layer at omega = 0, an empty domain
- * over a Lambertian surface, first-order scattering of a slab (tests/test_closed_form.py, independent of this code);
+ * over a Lambertian surface, first-order scattering of a slab (tests/test_closed_form.py, independent of this code) --
+ * and MULTIPLE scattering: fluxes and radiances of homogeneous slabs (optical depth 0.1 / 1 / 10, omega 1 / 0.9, surface albedo
+ * 0 / 0.5, planeParallel.nml among them) against an adding-doubling solver in float64 that shares nothing with this code
+ * (tests/plane_parallel_solver.py, tests/test_plane_parallel.py);
  * (ii) the product's independent Fortran implementation of the six photon-stream constructors, bit for bit
  * (tests/test_fortran_shell.py); (iii) the canonical MT19937 known answers and the reference-run numbers recorded at
  * survey time in SURVEY.md 6 / 8c and BASELINE.md 2 (RNG KATs for seed=(/10,1/), inverse and forward table spot values,

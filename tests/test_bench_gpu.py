@@ -46,10 +46,10 @@ def test_two_ranks_end_to_end_in_rehearsal_mode(scaling):
 
 def test_two_ranks_default_is_the_metrics_case_with_the_weak_figure_beside_it():
     # no --scaling: N > 1 reports ONE batch of --photons photons per step sharded over the ranks (strong) as the headline,
-    # two steps in flight, and the weak figure beside it
+    # three steps in flight, and the weak figure beside it
     n = 1000001
     j = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--photons", str(n)], env=dict(I3RC_BENCH_REHEARSAL="1"))
-    assert j["scaling"] == "strong" and j["config"]["photons_per_step"] == n and j["config"]["steps_in_flight"] == 2
+    assert j["scaling"] == "strong" and j["config"]["photons_per_step"] == n and j["config"]["steps_in_flight"] == 3
     assert j["weak"]["photons_per_step"] == 2 * n and j["weak"]["value"] > 1e6
     assert abs(j["result_check"]["meanFluxUp"] - 0.3253) < 3e-3
 
