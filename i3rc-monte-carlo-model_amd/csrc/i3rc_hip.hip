@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -24,6 +25,14 @@ thread_local std::string g_createError;
 // as pointers -- so that a read of memory nobody wrote shows in a fresh process and not only after other
 // allocations have left their contents behind.
 bool poison() { static const bool on = std::getenv("I3RC_POISON") != nullptr; return on; }
+
+// I3RC_TRACE=1 (debugging aid): a line on stderr for every fused group launched, served late or called off
+bool tracing() { static const bool on = std::getenv("I3RC_TRACE") != nullptr; return on; }
+double trace_ms() {
+  timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+  static const double t0 = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6 - t0;
+}
 
 
 struct DevBuf {
@@ -126,7 +135,9 @@ struct i3rc_hip_integrator {
   static constexpr int kFusedSlots = 3;
   FusedSlot fused[kFusedSlots];
   std::vector<int> aheadGroups;    // look-ahead: slots of the groups launched ahead, oldest first
-  int aheadGroupSize = 0;          // size of the next group to launch ahead (grows 8, 16, 32, 64)
+  int aheadGroupSize = 0;          // size of the next group to launch ahead (grows 8, 16, 32 ... 256)
+  bool aheadBounded = false;       // i3rc_hip_expect_batches: the caller has announced its loop -- nothing is launched beyond
+  uint32_t aheadEnd = 0;           // ... this seed word (exclusive)
   int fusion = -1;                 // -1: automatic, 0: never fuse, 1: fuse whatever the batch size (i3rc_hip_set_batch_fusion)
 
   // XCD-aware photon order (launch): the sorted photon numbers and the slab bookkeeping of a launch, per stream (launches
@@ -193,6 +204,8 @@ static int realloc_tally(i3rc_hip_integrator *h) {
 // Batches launched ahead by i3rc_hip_compute_batch read the handle's device arrays: whatever changes those (tables,
 // parameters, surface, directions, tuning) waits for them first and forgets them.
 static void drop_lookahead(i3rc_hip_integrator *h) {
+  if (tracing() && (!h->aheadGroups.empty() || !h->aheadQueue.empty()))
+    std::fprintf(stderr, "[i3rc %9.3f ms] look-ahead called off (%d fused groups, %d single batches)\n", trace_ms(), (int)h->aheadGroups.size(), (int)h->aheadQueue.size());
   for (const int k : h->aheadGroups) {   // fused groups launched ahead: called off (their waves take no further chunks), then awaited
     auto &g = h->fused[k];
     if (g.abortFlag) __atomic_store_n(g.abortFlag, 1, __ATOMIC_RELEASE);
@@ -204,6 +217,7 @@ static void drop_lookahead(i3rc_hip_integrator *h) {
   }
   h->aheadGroups.clear();
   h->aheadGroupSize = 0;
+  h->aheadBounded = false;
   for (const auto &a : h->aheadQueue) {
     (void)hipStreamSynchronize(h->pipe[a.slot].stream);
     h->pipe[a.slot].batch = -1;
@@ -402,15 +416,23 @@ int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int n
 int i3rc_hip_destroy(i3rc_hip_integrator *h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
+  // (first of all: whatever was launched ahead of the caller is called off -- destroying a stream waits for the device)
+  for (auto &g : h->fused) if (g.abortFlag) __atomic_store_n(g.abortFlag, 1, __ATOMIC_RELEASE);
+  if (tracing()) std::fprintf(stderr, "[i3rc %9.3f ms] destroy begins\n", trace_ms());
+  for (auto &g : h->fused) if (g.stream && g.count > 0) { (void)hipStreamSynchronize(g.stream); break; }
   if (h->ownStream) { (void)hipStreamSynchronize(h->ownStream); (void)hipStreamDestroy(h->ownStream); }
   for (auto &sl : h->pipe) {
     if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
     if (sl.done) (void)hipEventDestroy(sl.done);
     if (sl.pinned) (void)hipHostFree(sl.pinned);
   }
-  for (auto &g : h->fused) {
-    if (g.abortFlag) __atomic_store_n(g.abortFlag, 1, __ATOMIC_RELEASE);
-    if (g.stream) { (void)hipStreamSynchronize(g.stream); (void)hipStreamDestroy(g.stream); }
+  for (auto &g : h->fused) if (g.abortFlag) __atomic_store_n(g.abortFlag, 1, __ATOMIC_RELEASE);
+  if (tracing()) std::fprintf(stderr, "[i3rc %9.3f ms] destroy: abort words set\n", trace_ms());
+  for (int k = 0; k < i3rc_hip_integrator::kFusedSlots; ++k) {
+    auto &g = h->fused[k];
+    bool shared = false;   // (the slots normally share the first one's stream)
+    for (int j = 0; j < k; ++j) shared = shared || (g.stream && g.stream == h->fused[j].stream);
+    if (g.stream && !shared) { (void)hipStreamSynchronize(g.stream); if (tracing()) std::fprintf(stderr, "[i3rc %9.3f ms] destroy: fused stream drained\n", trace_ms()); (void)hipStreamDestroy(g.stream); }
     if (g.done) (void)hipEventDestroy(g.done);
     if (g.pinned) (void)hipHostFree(g.pinned);
     if (g.abortFlag) (void)hipHostFree(g.abortFlag);
@@ -904,9 +926,24 @@ int fused_group_size(const i3rc_hip_integrator *h, int nBatches, int64_t nPhoton
   return (int)std::max<int64_t>(1, std::min<int64_t>(g, nBatches));
 }
 
-int ready_fused_slot(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g, int count, int R) {
+// (`reserve`: batches the slot's buffers are made for at least -- a slot that had to grow later would hipFree / hipMalloc while
+// other groups are under way, and both wait for the device: a driver's look-ahead, whose groups grow 8, 16 ... 256, stood still
+// for a whole group each time)
+int ready_fused_slot(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g, int count, int R, int reserve) {
+  count = std::max(count, reserve);
   const size_t outBytes = (size_t)count * h->layout.total * sizeof(double);
-  if (!g.stream) HIPCHK(h, hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+  // All groups share ONE stream (the first slot's): a kernel trace of groups on streams of their own showed consecutive
+  // launches overlapping by 2 ms only -- the next kernel gets its first workgroup slots when the one before drains -- while
+  // every launch took 5 ms longer than it does alone: with work pending in a second hardware queue the persistent kernel's
+  // waves are time-sliced against it.  One queue exposes a launch's 1.4 ms tail per group and nothing else.
+  static const bool ownStreams = std::getenv("I3RC_FUSED_STREAMS") && std::atoi(std::getenv("I3RC_FUSED_STREAMS")) != 0;
+  if (!g.stream) {
+    if (ownStreams || &g == &h->fused[0]) HIPCHK(h, hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    else {
+      if (!h->fused[0].stream) HIPCHK(h, hipStreamCreateWithFlags(&h->fused[0].stream, hipStreamNonBlocking));
+      g.stream = h->fused[0].stream;
+    }
+  }
   if (!g.done) HIPCHK(h, hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
   if (!g.counter.p) HIPCHK(h, g.counter.alloc(sizeof(unsigned long long)));
   if (!g.abortFlag) HIPCHK(h, hipHostMalloc((void **)&g.abortFlag, sizeof(int), hipHostMallocCoherent | hipHostMallocMapped));
@@ -925,9 +962,9 @@ int ready_fused_slot(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g, 
 // One group: `count` batches with the keys (seed0, seed1 .. seed1 + count - 1), nPhotons photons each, traced by ONE grid;
 // zero, trace, sum the replicas, copy to the slot's pinned buffer -- all asynchronous on the slot's stream.
 int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g, uint32_t seed0, uint32_t seed1, int count,
-                       int64_t nPhotons, const i3rc_source *src, bool timeIt) {
+                       int64_t nPhotons, const i3rc_source *src, bool timeIt, int reserve = 0) {
   const int R = fused_replicas(h);
-  if (ready_fused_slot(h, g, count, R)) return 1;
+  if (ready_fused_slot(h, g, count, R, reserve)) return 1;
   hipStream_t const callerStream = h->stream;
   double *const callerTally = h->tally;
   h->stream = g.stream; h->tally = (double *)g.blocks.p;   // (make_problem reads these two)
@@ -1004,6 +1041,8 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
   HIPCHK(h, hipMemcpyAsync(g.pinned, result, outBytes, hipMemcpyDeviceToHost, g.stream));
   HIPCHK(h, hipEventRecord(g.done, g.stream));
   g.count = count; g.seed1 = seed1; g.next = 0;
+  if (tracing()) std::fprintf(stderr, "[i3rc %9.3f ms] fused group launched: seed words %u .. %u (%d batches of %lld photons, %d replicas, chunk %d)\n", trace_ms(),
+                              seed1, seed1 + (unsigned)count - 1u, count, (long long)nPhotons, R, A.chunk);
   return 0;
 }
 
@@ -1027,7 +1066,7 @@ int run_batches_fused(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, in
     auto &g = h->fused[k % i3rc_hip_integrator::kFusedSlots];
     if ((rc = collect(g))) break;
     const int count = std::min(G, nBatches - first);
-    rc = launch_fused_group(h, g, seed0, seed1 + (uint32_t)first, count, nPhotons, src, true);
+    rc = launch_fused_group(h, g, seed0, seed1 + (uint32_t)first, count, nPhotons, src, true, G);
     if (!rc) g.first = first;
   }
   for (int j = 0; j < i3rc_hip_integrator::kFusedSlots; ++j) {   // drain in launch order (also after a failure: nothing stays in flight)
@@ -1036,6 +1075,31 @@ int run_batches_fused(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, in
     else rc = collect(g);
   }
   return rc;
+}
+
+
+// Launches fused groups ahead of the caller until three are under way: the batches after the last group launched (or from
+// `nextIfNone`), 8, 16, 32 ... 256 batches a group -- small groups first, so that the caller's first batches are there soon.
+// A loop the caller has announced (i3rc_hip_expect_batches) is never overshot.
+void top_up_groups(i3rc_hip_integrator *h, uint32_t seed0, uint32_t nextIfNone, int64_t nPhotons, const i3rc_source *src) {
+  while ((int)h->aheadGroups.size() < i3rc_hip_integrator::kFusedSlots) {
+    int k = -1;
+    for (int j = 0; j < i3rc_hip_integrator::kFusedSlots; ++j) if (h->fused[j].count == 0) { k = j; break; }
+    if (k < 0) break;
+    uint32_t next = nextIfNone;
+    if (!h->aheadGroups.empty()) { const auto &last = h->fused[h->aheadGroups.back()]; next = last.seed1 + (uint32_t)last.count; }
+    int want = h->aheadGroupSize <= 0 ? 8 : std::min(256, 2 * h->aheadGroupSize);
+    if (h->aheadBounded) {
+      const int64_t left = (int64_t)h->aheadEnd - (int64_t)next;
+      if (left <= 0) break;
+      want = (int)std::min<int64_t>(want, left);
+    }
+    const int size = fused_group_size(h, want, nPhotons);
+    const int reserve = h->aheadBounded ? (int)std::min<int64_t>(fused_group_size(h, 256, nPhotons), (int64_t)h->aheadEnd - (int64_t)next + 0) : fused_group_size(h, 256, nPhotons);
+    if (launch_fused_group(h, h->fused[k], seed0, next, size, nPhotons, src, false, std::max(reserve, size))) { h->fused[k].count = 0; break; }   // (not the caller's failure)
+    h->aheadGroupSize = std::max(h->aheadGroupSize, want);
+    h->aheadGroups.push_back(k);
+  }
 }
 
 }  // namespace
@@ -1179,32 +1243,23 @@ int i3rc_hip_compute_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed
   };
   i3rc_hip_integrator::BatchSignature sig;
   sig.seed0 = seed0; sig.n = nPhotons; sig.mu = src->solarMu; sig.az = src->solarAzimuth; sig.set = true;
-  // Problems whose batches can share a grid (fusable) are looked ahead in GROUPS: 8, 16, 32, 64 ... batches per fused
-  // launch, up to three groups under way, the caller served from the oldest.  Such launches are not timed (the ring of
+  // Problems whose batches can share a grid (fusable) are looked ahead in GROUPS: 8, 16, 32 ... 256 batches per fused
+  // launch, up to three groups under way (one after the other on the device), the caller served from the oldest.  Such launches are not timed (the ring of
   // i3rc_hip_kernel_ms_history holds launches the caller asked for), and a group that is not wanted after all is called
   // off through its abort word: its waves stop at their next visit of the work counter.
   const bool fuse = depth > 0 && fusable(h, nPhotons) && (h->fusion == 1 || nPhotons <= 20000000);
-  auto top_up = [&]() {
-    while ((int)h->aheadGroups.size() < i3rc_hip_integrator::kFusedSlots) {
-      int k = -1;
-      for (int j = 0; j < i3rc_hip_integrator::kFusedSlots; ++j) if (h->fused[j].count == 0) { k = j; break; }
-      if (k < 0) break;
-      uint32_t next = seed1 + 1u;
-      if (!h->aheadGroups.empty()) { const auto &last = h->fused[h->aheadGroups.back()]; next = last.seed1 + (uint32_t)last.count; }
-      h->aheadGroupSize = h->aheadGroupSize <= 0 ? 8 : std::min(64, 2 * h->aheadGroupSize);
-      const int size = fused_group_size(h, h->aheadGroupSize, nPhotons);
-      if (launch_fused_group(h, h->fused[k], seed0, next, size, nPhotons, src, false)) { h->fused[k].count = 0; break; }   // (not this batch's failure)
-      h->aheadGroups.push_back(k);
-    }
-  };
+  auto top_up = [&]() { top_up_groups(h, seed0, seed1 + 1u, nPhotons, src); };
   if (!h->aheadGroups.empty()) {
     auto &g = h->fused[h->aheadGroups.front()];
     if (fuse && h->aheadSig == sig && g.seed1 + (uint32_t)g.next == seed1) {
+      const double tw = tracing() ? trace_ms() : 0.0;
       if (hipEventSynchronize(g.done) != hipSuccess) { drop_lookahead(h); return h->fail("i3rc_hip_compute_batch: waiting for the batch failed"); }
+      if (tracing() && trace_ms() - tw > 0.5) std::fprintf(stderr, "[i3rc %9.3f ms] batch %u waited %.3f ms for its group\n", trace_ms(), seed1, trace_ms() - tw);
       std::memcpy(hostTallies, g.pinned + (size_t)g.next * (size_t)h->layout.total, bytes);
       if (++g.next == g.count) { g.count = 0; h->aheadGroups.erase(h->aheadGroups.begin()); }
       h->lastSig = sig; h->lastSeed1 = seed1;
       top_up();
+      if (h->aheadBounded && h->aheadGroups.empty()) h->aheadBounded = false;   // the announced loop is through: from here on the usual guessing
       return 0;
     }
     drop_lookahead(h);
@@ -1240,6 +1295,33 @@ int i3rc_hip_compute_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed
   if (hipEventSynchronize(sl.done) != hipSuccess) { drop_lookahead(h); sl.batch = -1; return h->fail("i3rc_hip_compute_batch: waiting for the batch failed"); }
   std::memcpy(hostTallies, sl.pinned, bytes);
   sl.batch = -1;
+  return 0;
+}
+
+// Announces a driver's loop to i3rc_hip_compute_batch: see include/i3rc_hip.h
+int i3rc_hip_expect_batches(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int nBatches, int64_t nPhotons, const i3rc_source *src,
+                            int *accepted) {
+  if (!h) return 1;
+  if (accepted) *accepted = 0;
+  if (!src || nBatches < 1) return h->fail("i3rc_hip_expect_batches: bad arguments");
+  if (src->kind != 0) return h->fail("i3rc_hip_expect_batches: Directional photon streams only");
+  if (nPhotons <= 0) return h->fail("setIllumination: must ask for non-negative number of photons.");
+  HIPCHK(h, hipSetDevice(h->device));
+  drop_lookahead(h);
+  if (!(fusable(h, nPhotons) && (h->fusion == 1 || (nBatches >= 2 && nPhotons <= 20000000)))) return 0;   // (the caller goes on as it would have)
+  {   // the problem must be complete before anything is launched (as i3rc_hip_compute_batch would find out)
+    LaunchPlan plan;
+    if (make_problem(h, plan, true)) return 1;
+  }
+  i3rc_hip_integrator::BatchSignature sig;
+  sig.seed0 = seed0; sig.n = nPhotons; sig.mu = src->solarMu; sig.az = src->solarAzimuth; sig.set = true;
+  h->aheadSig = sig;
+  h->lastSig = sig; h->lastSeed1 = seed1 - 1u;
+  h->aheadBounded = true; h->aheadEnd = seed1 + (uint32_t)nBatches;
+  h->aheadGroupSize = 16;   // (the first group: 32 batches)
+  top_up_groups(h, seed0, seed1, nPhotons, src);
+  if (h->aheadGroups.empty()) { h->aheadBounded = false; return 1; }   // (launch_fused_group has left the reason)
+  if (accepted) *accepted = 1;
   return 0;
 }
 

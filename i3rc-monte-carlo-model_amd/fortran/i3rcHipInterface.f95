@@ -128,6 +128,17 @@ module i3rcHipInterface
       real(c_double), intent(out)   :: hostTallies(*)        ! nBatches * layout%total
       integer(c_int)                :: rc
     end function
+    function i3rc_hip_expect_batches(h, seed0, seed1, nBatches, nPhotons, src, accepted) &
+             bind(C, name = "i3rc_hip_expect_batches") result(rc)
+      import
+      type(c_ptr), value            :: h
+      integer(c_int32_t), value     :: seed0, seed1          ! the caller will ask for the batches (seed0, seed1) ... (seed0, seed1 + nBatches - 1)
+      integer(c_int), value         :: nBatches
+      integer(c_int64_t), value     :: nPhotons
+      type(i3rc_source), intent(in) :: src
+      integer(c_int), intent(out)   :: accepted              ! 1: traced ahead in fused groups; 0: nothing done
+      integer(c_int)                :: rc
+    end function
     function i3rc_hip_fetch_tallies(h, host) bind(C, name = "i3rc_hip_fetch_tallies") result(rc)
       import
       type(c_ptr), value          :: h

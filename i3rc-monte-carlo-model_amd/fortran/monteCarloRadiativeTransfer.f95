@@ -58,6 +58,9 @@ module monteCarloRadiativeTransfer
     double precision :: photonsProcessed = 0.d0, photonsDropped = 0.d0
     ! raw tallies of the batches of the last computeRadiativeTransferBatches (one column per batch)
     real(c_double), dimension(:, :), pointer :: batchTallies => null()
+    ! ... of which the first batchesFetched have arrived (a streamed loop: see computeRadiativeTransferBatches), and the loop itself
+    integer :: batchesFetched = 0, batchSeed0 = 0, batchFirst = 0, batchPhotons = 0
+    real    :: batchMu = 0., batchAzimuth = 0.
   end type integrator
 
   public :: integrator
@@ -554,7 +557,8 @@ contains
   !   traces it (same photons), but several batches share the device at a time (i3rc_hip_run_batches): a batch of 1e5 ... 1e6
   !   photons ends with a long tail -- a few photons with a thousand scatterings -- that the next batch's photons cover.
   !   selectBatchResults(integrator, k, status), k = 1 ... numBatches, then makes batch firstBatch + k - 1 the one
-  !   reportResults reports.  The raw tallies of all batches of the call stay with the integrator until the next call.
+  !   reportResults reports (call it before reportResults: a streamed loop has no results before).  The raw tallies of the
+  !   batches taken over so far stay with the integrator until the next call; asking for batch k takes over all up to k.
   ! ------------------------------------------------------------------------------------------------
   subroutine computeRadiativeTransferBatches(thisIntegrator, iseed, firstBatch, numBatches, solarMu, solarAzimuth, &
                                              numberOfPhotons, status, batchesInFlight)
@@ -566,6 +570,7 @@ contains
     type(i3rc_source)       :: source
     type(i3rc_tally_layout) :: layout
     integer :: inFlight
+    integer(c_int) :: accepted
 
     if(.not. isReady_Integrator(thisIntegrator)) then
       call setStateToFailure(status, "computeRadiativeTransfer: problem not completely specified.")
@@ -584,13 +589,35 @@ contains
                         "computeRadiativeTransfer", status)) return
     if(associated(thisIntegrator%batchTallies)) deallocate(thisIntegrator%batchTallies)
     allocate(thisIntegrator%batchTallies(layout%total, numBatches))
-    if(.not. deviceCall(thisIntegrator, i3rc_hip_run_batches(thisIntegrator%device, int(iseed, c_int32_t),              &
-                        int(firstBatch, c_int32_t), int(numBatches, c_int), int(numberOfPhotons, c_int64_t), source,   &
-                        int(inFlight, c_int), thisIntegrator%batchTallies), "computeRadiativeTransfer", status)) then
-      deallocate(thisIntegrator%batchTallies)
-      return
+    thisIntegrator%batchesFetched = 0
+    thisIntegrator%batchSeed0 = iseed;   thisIntegrator%batchFirst = firstBatch; thisIntegrator%batchPhotons = numberOfPhotons
+    thisIntegrator%batchMu    = solarMu; thisIntegrator%batchAzimuth = solarAzimuth
+    ! Flux problems of the common class are STREAMED: the library is told the loop (i3rc_hip_expect_batches) and starts tracing
+    ! it at once, group of batches by group (each group one kernel launch); selectBatchResults(k) takes the batches over as
+    ! they are asked for, so that the caller works on batch k while the following ones are traced -- and this call returns
+    ! without waiting.  Other problems (radiances, BRDF grids, several components) are traced here and now, several batches
+    ! on the device at a time (i3rc_hip_run_batches).
+    accepted = 0
+    if(inFlight /= 1) then
+      if(.not. deviceCall(thisIntegrator, i3rc_hip_expect_batches(thisIntegrator%device, int(iseed, c_int32_t),           &
+                          int(firstBatch, c_int32_t), int(numBatches, c_int), int(numberOfPhotons, c_int64_t), source,   &
+                          accepted), "computeRadiativeTransfer", status)) then
+        deallocate(thisIntegrator%batchTallies)
+        return
+      end if
     end if
-    call selectBatchResults(thisIntegrator, numBatches, status)   ! (as after a loop of computeRadiativeTransfer calls: the last batch)
+    if(accepted == 0) then
+      if(.not. deviceCall(thisIntegrator, i3rc_hip_run_batches(thisIntegrator%device, int(iseed, c_int32_t),              &
+                          int(firstBatch, c_int32_t), int(numBatches, c_int), int(numberOfPhotons, c_int64_t), source,   &
+                          int(inFlight, c_int), thisIntegrator%batchTallies), "computeRadiativeTransfer", status)) then
+        deallocate(thisIntegrator%batchTallies)
+        return
+      end if
+      thisIntegrator%batchesFetched = numBatches
+      call selectBatchResults(thisIntegrator, numBatches, status)   ! (as after a loop of computeRadiativeTransfer calls: the last batch)
+    else
+      call setStateToSuccess(status)
+    end if
   end subroutine computeRadiativeTransferBatches
 
   subroutine selectBatchResults(thisIntegrator, batch, status)
@@ -598,6 +625,7 @@ contains
     integer,            intent(in   ) :: batch
     type(ErrorMessage), intent(inout) :: status
     type(i3rc_tally_layout) :: layout
+    type(i3rc_source)       :: source
     if(.not. associated(thisIntegrator%batchTallies)) then
       call setStateToFailure(status, "selectBatchResults: no batches have been computed.")
       return
@@ -607,6 +635,15 @@ contains
       return
     end if
     if(.not. deviceCall(thisIntegrator, i3rc_hip_get_tally_layout(thisIntegrator%device, layout), "selectBatchResults", status)) return
+    ! a streamed loop: take over the batches up to this one (in the loop's order: the library traces them ahead of us)
+    source%kind = 0; source%solarMu = thisIntegrator%batchMu; source%solarAzimuth = thisIntegrator%batchAzimuth
+    do while(thisIntegrator%batchesFetched < batch)
+      if(.not. deviceCall(thisIntegrator, i3rc_hip_compute_batch(thisIntegrator%device, int(thisIntegrator%batchSeed0, c_int32_t),       &
+                          int(thisIntegrator%batchFirst + thisIntegrator%batchesFetched, c_int32_t),                                   &
+                          int(thisIntegrator%batchPhotons, c_int64_t), source, 3_c_int,                                                 &
+                          thisIntegrator%batchTallies(:, thisIntegrator%batchesFetched + 1)), "selectBatchResults", status)) return
+      thisIntegrator%batchesFetched = thisIntegrator%batchesFetched + 1
+    end do
     if(.not. unpackTallies(thisIntegrator, thisIntegrator%batchTallies(:, batch), layout, "selectBatchResults", status)) return
     if(thisIntegrator%photonsProcessed > 0.d0) then
       call setStateToCompleteSuccess(status, "computeRadiativeTransfer: finished with photons")

@@ -184,7 +184,7 @@ int i3rc_hip_run_batches(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1,
  * seed = (/iseed, batch/) (monteCarloDriver.f95:277, :287), and a call cannot return before the batch's last photon has
  * (the tail of a launch: see i3rc_hip_run_batches).  When a call is the same batch as the previous call with the next
  * seed word, the library takes that for such a loop and traces the following batches (seed1 + 1, seed1 + 2, ...) behind
- * this one: on problems whose batches can share a grid in FUSED GROUPS of 8, 16, 32, 64 ... batches (up to three groups
+ * this one: on problems whose batches can share a grid in FUSED GROUPS of 8, 16, 32 ... 256 batches (up to three groups
  * under way), else up to lookAhead (0..7; 0 = never look ahead) single batches; the next call then finds its batch under
  * way or done.  A call that is not the expected batch (other seed, photon count, sun), and every change of the problem
  * (tables, parameters, surface, directions, tuning), calls the work launched ahead off -- fused groups poll an abort word
@@ -194,6 +194,18 @@ int i3rc_hip_run_batches(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1,
  * cloud, process start to result files: 2.2 s (one launch per call) -> 0.8 s.  Directional sources only.  Synchronous. */
 int i3rc_hip_compute_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int64_t nPhotons,
                            const i3rc_source *src, int lookAhead, double *hostTallies);
+
+/* Announces a driver's batch loop to the look-ahead of i3rc_hip_compute_batch: the caller is going to ask for the batches
+ * with the seed words seed1, seed1 + 1 ... seed1 + nBatches - 1 (nPhotons photons each, this sun), one
+ * i3rc_hip_compute_batch call per batch, in this order.  On problems whose batches can share a grid (see
+ * i3rc_hip_run_batches) the library starts tracing them at once, in fused groups of 32, 64, 128, 256 ... batches, three groups
+ * under way at a time and none beyond the announced loop; *accepted is 1.  The calls then find their batches done or under
+ * way while the caller works on the ones it has: the shell's computeRadiativeTransferBatches / selectBatchResults stream
+ * a driver's loop this way.  On other problems nothing happens and *accepted is 0: i3rc_hip_run_batches (or the calls'
+ * own look-ahead) serves those.  A call for any other batch, and every change of the problem, calls the announced work
+ * off, as for any look-ahead.  Asynchronous. */
+int i3rc_hip_expect_batches(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int nBatches, int64_t nPhotons,
+                            const i3rc_source *src, int *accepted);
 
 /* Test hook: same kernel, but every uniform deviate is read from `randoms` (float32, e.g. the reference's
  * MT19937 stream): photon i consumes randoms[drawStart[i]], randoms[drawStart[i]+1], ... in the reference's

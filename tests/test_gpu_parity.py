@@ -694,3 +694,43 @@ def test_phase_function_entries_beyond_32767():
     assert res[0]["counters"] == res[1]["counters"]
     assert np.allclose(res[0]["raw"], res[1]["raw"], rtol=1e-5, atol=1e-6)
 
+
+
+def test_an_announced_loop_is_streamed_and_never_overshot():
+    """i3rc_hip_expect_batches tells the library a driver's loop in advance (the shell's computeRadiativeTransferBatches does): the
+    batches are traced at once in fused groups and handed over by i3rc_hip_compute_batch one by one -- each equal to the plain
+    call of the same batch --; leaving the announced order in mid-loop (another seed) calls the rest off and still gives the
+    right batch; a radiance problem is not accepted (its batches go through i3rc_hip_run_batches)."""
+    import ctypes as C
+    from i3rc_monte_carlo_model_amd import binding as B
+    lib = B.load()
+    d = cases.step_cloud(ssa=0.97, nlayers=8)
+    plain, stream = make_gpu(d, hg_table(), surfaceAlbedo=0.2), make_gpu(d, hg_table(), surfaceAlbedo=0.2)
+    plain.set_batch_fusion(0)
+    stream._ensure_tables()
+    n, nb = 9000, 45
+    s = B.Source(); s.kind, s.solarMu, s.solarAzimuth = 0, 0.7, 40.0
+    acc = C.c_int(-1)
+    assert lib.i3rc_hip_expect_batches(stream._h, 21, 5, nb, n, C.byref(s), C.byref(acc)) == 0 and acc.value == 1
+    raw = np.zeros(stream.layout().total, np.float64)
+
+    def check(seed1):
+        assert lib.i3rc_hip_compute_batch(stream._h, 21, seed1, n, C.byref(s), 3, raw.ctypes.data_as(B.dp)) == 0, lib.i3rc_hip_last_error(stream._h)
+        got = stream.finish(raw.copy())
+        want = plain.computeRadiativeTransfer(M.new_RandomNumberSequence((21, seed1)), M.new_PhotonStream(0.7, 40.0, n))
+        assert got["counters"] == want["counters"], seed1
+        assert np.allclose(got["raw"], want["raw"], rtol=1e-5, atol=1e-6)
+
+    for b in range(nb):
+        check(5 + b)
+    check(5 + nb)                       # beyond the announced loop: an ordinary call again
+    assert lib.i3rc_hip_expect_batches(stream._h, 21, 100, 40, n, C.byref(s), C.byref(acc)) == 0 and acc.value == 1
+    for b in range(7):
+        check(100 + b)
+    check(300)                          # out of order: the announced rest is called off
+    check(301); check(302)
+    # a radiance problem is left to i3rc_hip_run_batches
+    stream.specifyParameters(intensityMus=[1.0], intensityPhis=[0.0])
+    stream._ensure_tables()
+    assert lib.i3rc_hip_expect_batches(stream._h, 21, 5, nb, n, C.byref(s), C.byref(acc)) == 0 and acc.value == 0
+    plain.finalize_Integrator(); stream.finalize_Integrator()
