@@ -347,9 +347,9 @@ __global__ void __launch_bounds__(256) slab_fill_kernel(uint32_t seed0, uint32_t
 // re-wrapping loops, max-cross-section moves, BRDF lookups, component selection) are compiled out, which shrinks the
 // loop's code and its scalar-register pressure.  GENERAL = true keeps every path behind run-time switches.
 // (radiance kernels keep two rays per lane live -- the photon's and a shadow ray's: 4 waves per SIMD give them 128 vector registers)
-// TBL (experiment of round 3, specialised flux kernel with the grid in LDS only): workgroups of 1024 threads, two per compute
-// unit, that also keep the 40 KB of the inverse table's cosines in LDS: the two dependent table reads of a scattering then
-// come from LDS instead of L2.
+// TBL (round 3, specialised flux kernel with the grid in LDS only): workgroups of 1024 threads, two per compute unit, that also
+// keep the 40 KB of the inverse table's cosines in LDS: the two dependent table reads of a scattering then come from LDS
+// instead of L2 (+1.6 % on the step cloud; the launch chooses it: i3rc_hip.hip).
 template <class Rng, bool INTENSITY, bool GENERAL, int GRID, bool TBL = false>
 __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_WAVES) : ((GENERAL || GRID == GRID_BRICKS) ? I3RC_MIN_WAVES : (Rng::kBatched ? I3RC_FUSED_WAVES : I3RC_FLUX_WAVES))) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -26,7 +26,7 @@ def test_gpus_1_goes_through_the_spawn_path():
     j = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--photons", "2000000", "--no-cpu-baseline"])
     assert j["n_gpus"] == 1 and j["world_size"] == 1 and "spawned 1 rank" in j["launch"]
     assert j["config"]["photons_per_step"] == 2000000 and j["value"] > 1e7
-    assert j["roofline"]["kernel"] == "photon_kernel<PhiloxStream, false, false, GRID_LDS>"
+    assert j["roofline"]["kernel"] == "photon_kernel<PhiloxStream, false, false, GRID_LDS, table in LDS>"
     assert abs(j["result_check"]["meanFluxUp"] - 0.3253) < 2e-3
     assert len(j["devices"]) == 1
 

@@ -502,16 +502,18 @@ def test_kernels_agree_on_random_regular_domains():
     # surface albedo, sun position -- identical work counters, tallies equal up to float32 summation order
     rng = np.random.default_rng(2024)
     dropped_all = 0
+    seen_kernels = set()
     for case in range(16):
         d, albedo, mu0, az = _random_regular_case(rng, case)
         nx, ny, nz = len(d["xe"]) - 1, len(d["ye"]) - 1, len(d["ze"]) - 1
         g = make_gpu(d, hg_table(), surfaceAlbedo=albedo)
         n = 20000
         out = {}
-        for kernel in ("lane", "general"):
+        for kernel in ("lane", "general", "auto"):   # (auto: small domains take the instantiation that keeps the inverse table in LDS)
             g.set_tuning(0, 0, kernel=kernel)
             out[kernel] = g.computeRadiativeTransfer(M.new_RandomNumberSequence((77, case)), M.new_PhotonStream(mu0, az, n))
-        for other in ("general",):
+            seen_kernels.add(g.kernel_name())
+        for other in ("general", "auto"):
             assert out["lane"]["counters"] == out[other]["counters"], (case, other, nx, ny, nz)
             assert np.allclose(out["lane"]["raw"], out[other]["raw"], rtol=3e-5, atol=2e-5), (case, other, nx, ny, nz)
         c = out["lane"]["counters"]
@@ -520,6 +522,7 @@ def test_kernels_agree_on_random_regular_domains():
         # oracle too: the start height z0 + (1 - spacing(1)) (zMax - z0) rounds to zMax itself there; reference behaviour)
         dropped_all += c["dropped"] == n
     assert dropped_all == 2
+    assert any("table in LDS" in k for k in seen_kernels), seen_kernels
 
 
 def test_pipelined_batches_equal_one_call_per_batch():

@@ -10,7 +10,7 @@ if [ "$1" = collect ]; then
   TAG=$2; O=$R/gpurun_out/$TAG
   for w in step16 radar64_nadir landsat36 landsat119_7dir; do
     [ -f $O/bench_$w.json ] && cp $O/bench_$w.json $R/profiles/${TAG}_${w}_bench.json
-    f=$(ls $O/stats_$w/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $R/profiles/${TAG}_${w}_kernel_stats.csv
+    f=$(ls -t $O/stats_$w/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $R/profiles/${TAG}_${w}_kernel_stats.csv
     [ -f $O/pmc_$w/summary.txt ] && cp $O/pmc_$w/summary.txt $R/profiles/${TAG}_${w}_pmc_summary.txt
   done
   [ -f $O/issue_rate.txt ] && cp $O/issue_rate.txt $R/profiles/${TAG}_issue_rate_microbench.txt
@@ -22,12 +22,12 @@ fi
 TAG=$1; O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 declare -A N=( [step16]=50000000 [radar64_nadir]=50000000 [landsat36]=100000000 [landsat119_7dir]=20000000 )
 # counters first, so that the bench lines below quote THIS build's instruction mix and traffic (bench.py reads the newest profiles/*_pmc.json)
-for w in step16 radar64_nadir landsat36 landsat119_7dir; do
+for w in ${WORKLOADS:-step16 radar64_nadir landsat36 landsat119_7dir}; do
   $R/tools/pmc_profile.sh $TAG/pmc_$w $w ${N[$w]} > $O/pmc_$w.log 2>&1 || echo "pmc $w failed"
   echo "$w counters done"
 done
 python3 $R/tools/pmc_to_json.py --collect $R/profiles/${TAG}_pmc.json $O/pmc_*/summary.txt > /dev/null && cp $R/profiles/${TAG}_pmc.json $O/pmc.json
-for w in step16 radar64_nadir landsat36 landsat119_7dir; do
+for w in ${WORKLOADS:-step16 radar64_nadir landsat36 landsat119_7dir}; do
   # the profiled program is the rank itself (RANK set: bench.py's main() runs worker() at once), never bench.py's launcher --
   # a launcher hop after `--` would be traced only through the inherited preload, after the profiler library has touched the GPU
   ( export RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533
@@ -35,6 +35,7 @@ for w in step16 radar64_nadir landsat36 landsat119_7dir; do
   python3 $R/bench.py --config $w > $O/bench_$w.json 2> $O/bench_$w.err || echo "bench $w failed"
   echo "$w done: $(python3 -c "import json;j=json.load(open('$O/bench_$w.json'));print('%.3e photons/s'%j['value'], j['roofline']['kernel'])")"
 done
+[ -n "$SKIP_EXTRAS" ] && { echo "profile round $TAG done (workloads only)"; exit 0; }
 [ -x $R/tools/microbench/issue_rate ] && $R/tools/microbench/issue_rate 5 > $O/issue_rate.txt 2>&1
 [ -x $R/tools/microbench/atomic_rate ] && $R/tools/microbench/atomic_rate > $O/atomic_rate.txt 2>&1
 # the batch loop: one call per batch, batches in flight, fused launches (tools/call_overhead.py, tools/fused_timing.py), the drivers end to end
