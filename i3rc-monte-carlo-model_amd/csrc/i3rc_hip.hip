@@ -783,17 +783,22 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
         {photon_kernel<Rng, true, false, GRID_LDS>, photon_kernel<Rng, true, false, GRID_GLOBAL>, photon_kernel<Rng, true, false, GRID_BRICKS>}};
     if (simple) kern = special[plan.intensity ? 1 : 0][place];
   }
-  // Small domains (extinction grid in LDS) whose cells share one phase-function entry keep the inverse table's cosines in LDS
-  // too, in workgroups of 1024 threads, two per compute unit (photon_kernel, TBL): the two dependent table reads of a
-  // scattering come from LDS instead of L2.  Step cloud 29.75 -> 29.29 ms per 1e8 photons (+1.6 %, 32 layers +1.5 %).
+  // Flux problems of the common class with ONE phase-function entry keep the inverse table's cosines (40 KB) in LDS, in
+  // workgroups of 1024 threads, two per compute unit (photon_kernel, TBL): the two dependent table reads of a scattering come
+  // from LDS instead of L2 -- or, where the extinction field fills the L2 (Landsat-36: 2.4 MB of 4), instead of the fabric.
+  // Step cloud 29.75 -> 29.29 ms per 1e8 photons (+1.6 %), radar 640 +2 %, Landsat-36 87.0 -> 71.0 ms (+22 %).
   // I3RC_TABLE_LDS=0 switches it off.
   int threads = 256;
   size_t ldsBytes = plan.ldsBytes;
   if constexpr (!Rng::kReplay) {
     static const bool tblOn = !(std::getenv("I3RC_TABLE_LDS") && std::atoi(std::getenv("I3RC_TABLE_LDS")) == 0);
-    if (tblOn && simple && !plan.intensity && place == GRID_LDS && plan.P.uniformPf >= 1 && h->kernelVariant == I3RC_KERNEL_AUTO &&
+    // (grid places as a bit mask: LDS and global memory.  Bricked fields: Landsat-119 -2.5 %, the scene tiled 2 x 2 +10 %: left out)
+    static const int tblPlaces = std::getenv("I3RC_TABLE_LDS_PLACES") ? std::atoi(std::getenv("I3RC_TABLE_LDS_PLACES")) : 3;
+    if (tblOn && simple && !plan.intensity && ((tblPlaces >> place) & 1) && (plan.P.uniformPf >= 1 || h->nInvEntries[0] == 1) && h->kernelVariant == I3RC_KERNEL_AUTO &&
         plan.ldsBytes + sizeof(float) * (size_t)plan.P.comp0.nInv <= 79 * 1024) {
-      kern = photon_kernel<Rng, false, false, GRID_LDS, true>;
+      static const Kernel tbl[3] = {photon_kernel<Rng, false, false, GRID_LDS, true>, photon_kernel<Rng, false, false, GRID_GLOBAL, true>,
+                                    photon_kernel<Rng, false, false, GRID_BRICKS, true>};
+      kern = tbl[place];
       threads = 1024;
       ldsBytes = (plan.ldsBytes + sizeof(float) * (size_t)plan.P.comp0.nInv + 15) & ~(size_t)15;
     }
@@ -805,7 +810,7 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
     std::snprintf(name, sizeof(name), "photon_kernel<%s, %s, %s, %s>", Rng::kReplay ? "ReplayStream" : "PhiloxStream",
                        plan.intensity ? "true" : "false", (simple ? "false" : "true"), placeName[place]);
     h->lastKernelName = name;
-    if (threads == 1024) h->lastKernelName = "photon_kernel<PhiloxStream, false, false, GRID_LDS, table in LDS>";
+    if (threads == 1024) { std::snprintf(name, sizeof(name), "photon_kernel<PhiloxStream, false, false, %s, table in LDS>", placeName[place]); h->lastKernelName = name; }
   }
   int perCU = h->blocksPerCU;
   if (perCU <= 0) {

@@ -347,9 +347,9 @@ __global__ void __launch_bounds__(256) slab_fill_kernel(uint32_t seed0, uint32_t
 // re-wrapping loops, max-cross-section moves, BRDF lookups, component selection) are compiled out, which shrinks the
 // loop's code and its scalar-register pressure.  GENERAL = true keeps every path behind run-time switches.
 // (radiance kernels keep two rays per lane live -- the photon's and a shadow ray's: 4 waves per SIMD give them 128 vector registers)
-// TBL (round 3, specialised flux kernel with the grid in LDS only): workgroups of 1024 threads, two per compute unit, that also
-// keep the 40 KB of the inverse table's cosines in LDS: the two dependent table reads of a scattering then come from LDS
-// instead of L2 (+1.6 % on the step cloud; the launch chooses it: i3rc_hip.hip).
+// TBL (round 3, specialised flux kernels): workgroups of 1024 threads, two per compute unit, that also keep the 40 KB of the
+// inverse table's cosines (one entry) in LDS: the two dependent table reads of a scattering then come from LDS instead of
+// L2 or beyond (+1.6 % on the step cloud, +22 % on Landsat-36; the launch chooses it: i3rc_hip.hip).
 template <class Rng, bool INTENSITY, bool GENERAL, int GRID, bool TBL = false>
 __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_WAVES) : ((GENERAL || GRID == GRID_BRICKS) ? I3RC_MIN_WAVES : (Rng::kBatched ? I3RC_FUSED_WAVES : I3RC_FLUX_WAVES))) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -369,6 +369,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
     if (P.ldsIntensity) p += (P.ncomp + 1) * P.nDir * ncol;
     L.ext = p;
     if (GRID == GRID_LDS) p += P.nx * P.ny * P.nz;
+    if (GRID == GRID_BRICKS && !INTENSITY) p += P.clearNx * (((P.ny - 1) >> P.clearShift) + 1);   // (the clear-air map lives at L.ext)
     L.cosTab = p;
   }
   for (int i = threadIdx.x; i < 3 * P.nDir; i += blockDim.x) L.dirCos[i] = P.dirCos[i];
@@ -389,7 +390,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
   if (P.ldsIntensity)
     for (int i = threadIdx.x; i < (P.ncomp + 1) * P.nDir * P.nx * P.ny; i += blockDim.x) L.tInt[i] = 0.0f;
   if (TBL) {
-    const float *src = P.comp0.invCos + (size_t)(P.uniformPf - 1) * P.comp0.nInv;
+    const float *src = P.comp0.invCos + (size_t)(P.uniformPf >= 1 ? P.uniformPf - 1 : 0) * P.comp0.nInv;   // (else the table has one entry)
     for (int i = threadIdx.x; i < P.comp0.nInv; i += blockDim.x) L.cosTab[i] = src[i];
   }
   __syncthreads();
@@ -427,7 +428,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
   float fateW = 0.0f;
   // XCD-aware photon order: kernels on fields beyond an XCD's L2 (bricks), when the host has sorted the launch's photons
   constexpr bool SLABS = GRID == GRID_BRICKS && !Rng::kReplay;
-  __shared__ int slabsTried[4];            // per wave (see Reservoir::refill_slabs)
+  __shared__ int slabsTried[16];           // per wave (see Reservoir::refill_slabs; 16 waves in the 1024-thread instantiations)
   Reservoir res;
   if constexpr (BATCHED) res.refill_batched();
   else if (SLABS && A.slabIds != nullptr) {

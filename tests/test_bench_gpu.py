@@ -66,7 +66,7 @@ def test_steps_in_flight_on_one_gpu():
 
 
 @pytest.mark.parametrize("config,kernel", [("radar64_nadir", "photon_kernel<PhiloxStream, true, false, GRID_GLOBAL>"),
-                                           ("landsat36", "photon_kernel<PhiloxStream, false, false, GRID_GLOBAL>"),
+                                           ("landsat36", "photon_kernel<PhiloxStream, false, false, GRID_GLOBAL, table in LDS>"),
                                            ("landsat119_7dir", "photon_kernel<PhiloxStream, true, false, GRID_BRICKS>")])
 def test_other_baseline_workloads(config, kernel):
     n = {"radar64_nadir": 2000000, "landsat36": 4000000, "landsat119_7dir": 300000}[config]
