@@ -1000,24 +1000,40 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
   static const Kernel kernels[3] = {photon_kernel<PhiloxBatchStream, false, false, GRID_LDS>, photon_kernel<PhiloxBatchStream, false, false, GRID_GLOBAL>,
                                     photon_kernel<PhiloxBatchStream, false, false, GRID_BRICKS>};
   const int place = plan.P.ldsGrid ? GRID_LDS : (plan.P.extBrick ? GRID_BRICKS : GRID_GLOBAL);
-  const void *fn = (const void *)kernels[place];
+  // (the inverse table's cosines in LDS, workgroups of 1024 threads: as in launch(); these instantiations are planned for eight
+  // waves per SIMD -- two workgroups per compute unit -- and pay for it with two vector registers in scratch)
+  Kernel kern = kernels[place];
+  int threads = 256;
+  size_t ldsBytes = plan.ldsBytes;
+  {
+    static const bool tblOn = !(std::getenv("I3RC_TABLE_LDS") && std::atoi(std::getenv("I3RC_TABLE_LDS")) == 0);
+    static const int tblPlaces = std::getenv("I3RC_FUSED_TABLE_LDS_PLACES") ? std::atoi(std::getenv("I3RC_FUSED_TABLE_LDS_PLACES")) : 3;   // (measured: Landsat-36 +13 %, radar 640 +12 %, step cloud +1.5 ... 3 % in the kernels' own time)
+    if (tblOn && ((tblPlaces >> place) & 1) && place != GRID_BRICKS && (plan.P.uniformPf >= 1 || h->nInvEntries[0] == 1) &&
+        plan.ldsBytes + sizeof(float) * (size_t)plan.P.comp0.nInv <= 79 * 1024) {
+      static const Kernel tbl[2] = {photon_kernel<PhiloxBatchStream, false, false, GRID_LDS, true>, photon_kernel<PhiloxBatchStream, false, false, GRID_GLOBAL, true>};
+      kern = tbl[place];
+      threads = 1024;
+      ldsBytes = (plan.ldsBytes + sizeof(float) * (size_t)plan.P.comp0.nInv + 15) & ~(size_t)15;
+    }
+  }
+  const void *fn = (const void *)kern;
   {
     static const char *const placeName[3] = {"GRID_LDS", "GRID_GLOBAL", "GRID_BRICKS"};
     static thread_local char name[96];
-    std::snprintf(name, sizeof(name), "photon_kernel<PhiloxBatchStream, false, false, %s>", placeName[place]);
+    std::snprintf(name, sizeof(name), "photon_kernel<PhiloxBatchStream, false, false, %s%s>", placeName[place], threads == 1024 ? ", table in LDS" : "");
     h->lastKernelName = name;
   }
   int perCU = h->blocksPerCU;
   if (perCU <= 0) {
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, plan.ldsBytes) != hipSuccess || occ < 1) occ = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, threads, ldsBytes) != hipSuccess || occ < 1) occ = 2;
     perCU = std::min(occ, 8);
     if (place == GRID_BRICKS) perCU = std::min(perCU, ncell_bytes(h) > ((size_t)16 << 20) ? 4 : 5);   // (as in launch())
   }
-  if (plan.ldsBytes > 48 * 1024)
-    HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.ldsBytes));
+  if (ldsBytes > 48 * 1024)
+    HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
   long long blocks = (long long)h->numCU * perCU;
-  const long long need = ((long long)count * nPhotons + 255) / 256;
+  const long long need = ((long long)count * nPhotons + threads - 1) / threads;
   if (blocks > need) blocks = std::max(1ll, need);
   const size_t outBytes = (size_t)count * h->layout.total * sizeof(double);
   *g.abortFlag = 0;
@@ -1028,7 +1044,7 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
   if (timeIt) HIPCHK(h, hipEventRecord(h->evStart[slot], g.stream));
   {
     const int evThreshold = h->evThreshold > 0 ? h->evThreshold : -40;
-    hipLaunchKernelGGL(kernels[place], dim3((unsigned)blocks), dim3(256), plan.ldsBytes, g.stream, plan.P, A, evThreshold, -24);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads), ldsBytes, g.stream, plan.P, A, evThreshold, -24);
   }
   HIPCHK(h, hipGetLastError());
   if (timeIt) { HIPCHK(h, hipEventRecord(h->evStop[slot], g.stream)); h->timedLaunches++; }

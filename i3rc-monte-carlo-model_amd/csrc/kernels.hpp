@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(256) slab_fill_kernel(uint32_t seed0, uint32_t
 // inverse table's cosines (one entry) in LDS: the two dependent table reads of a scattering then come from LDS instead of
 // L2 or beyond (+1.6 % on the step cloud, +22 % on Landsat-36; the launch chooses it: i3rc_hip.hip).
 template <class Rng, bool INTENSITY, bool GENERAL, int GRID, bool TBL = false>
-__global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_WAVES) : ((GENERAL || GRID == GRID_BRICKS) ? I3RC_MIN_WAVES : (Rng::kBatched ? I3RC_FUSED_WAVES : I3RC_FLUX_WAVES))) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
+__global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_WAVES) : ((GENERAL || GRID == GRID_BRICKS) ? I3RC_MIN_WAVES : ((Rng::kBatched && !TBL) ? I3RC_FUSED_WAVES : I3RC_FLUX_WAVES))) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   {

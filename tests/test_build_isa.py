@@ -69,14 +69,19 @@ def test_production_kernels_keep_their_state_in_registers():
     rows = [r for r in everything if r["name"].startswith("photon_kernel<PhiloxStream") and "table in LDS" not in r["name"]]
     assert len(rows) == 12, [r["name"] for r in rows]
     fused = [r for r in everything if r["name"].startswith("photon_kernel<PhiloxBatchStream")]   # the fused multi-batch flux kernels
-    assert len(fused) == 3, [r["name"] for r in fused]
+    assert len(fused) == 5, [r["name"] for r in fused]
     for r in rows + fused:
+        if r in fused and "table in LDS" in r["name"]:
+            # the fused kernels want 66 vector registers; their table-in-LDS instantiations (1024 threads, two workgroups per CU: eight
+            # waves per SIMD, 64 registers) keep two of them in scratch -- measured faster all the same (kernels.hpp, i3rc_hip.hip)
+            assert r["VGPRs Spill"] <= 2 and r["ScratchSize [bytes/lane]"] <= 16, (r["name"], r["VGPRs Spill"], r["ScratchSize [bytes/lane]"])
+            continue
         assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, (r["name"], r["VGPRs Spill"], r["ScratchSize [bytes/lane]"])
         if ", false, GRID" in r["name"]:                       # specialised (GENERAL = false)
             limit = 16
             # (the bricked flux kernel reads its clear-air map through two more scalar values: a couple of spills)
             if r["name"].startswith("photon_kernel<PhiloxStream, false"): limit = 4 if "GRID_BRICKS" in r["name"] else 12
-            if r["name"].startswith("photon_kernel<PhiloxBatchStream"): limit = 4
+            if r["name"].startswith("photon_kernel<PhiloxBatchStream"): limit = 12 if "table in LDS" in r["name"] else 4
             assert r["SGPRs Spill"] <= limit, (r["name"], r["SGPRs Spill"])
     # the replay build (test infrastructure on the device) must not use scratch either
     for r in everything:
