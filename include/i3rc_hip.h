@@ -169,7 +169,7 @@ int i3rc_hip_launch_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1
  *     go to per-batch blocks in global memory (spread over replicas where a domain has few columns), work counters are
  *     gathered per lane and handed over per batch: one batch's tail is filled by the next batch's photons inside the
  *     launch.  Groups hold about 2.5e8 photons (bounded by 1 GiB of tally blocks), up to three groups are in flight.  Step
- *     cloud, 1e6-photon batches: 0.33 ms per batch (3.0e9 photons/s) against 1.6 ms one call at a time.
+ *     cloud, 1e6-photon batches: 0.34 ms per batch (2.9e9 photons/s) against 1.6 ms one call at a time.
  *   - otherwise up to inFlight batches (1..8; 0 = 6) are on the device at a time, each a launch on a HIP stream of its
  *     own with its own tally buffer (GPU_MAX_HW_QUEUES=8 in the environment gives these another 10-15 %).
  * i3rc_hip_set_batch_fusion chooses between the two.  Directional sources only (an explicit stream differs from batch
