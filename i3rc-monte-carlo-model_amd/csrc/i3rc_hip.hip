@@ -911,8 +911,10 @@ __global__ void __launch_bounds__(256) reduce_counters_kernel(const double *coun
 bool fusable(const i3rc_hip_integrator *h, int64_t nPhotons) {
   static const bool envOff = std::getenv("I3RC_FUSED") && std::atoi(std::getenv("I3RC_FUSED")) == 0;
   if (envOff || h->fusion == 0) return false;
+  // (a batch's tally block beyond 256 MiB -- 3e7 cells -- would make a slot's pinned copy and its blocks unreasonably large: such
+  // domains keep one launch per batch, whose tail is a small part of a launch that long anyway)
   return common_class(h, 0) && h->nDir == 0 && h->kernelVariant != I3RC_KERNEL_GENERAL && nPhotons < ((int64_t)1 << 31) &&
-         h->layout.total < ((int64_t)1 << 31);
+         h->layout.total * (int64_t)sizeof(double) <= ((int64_t)256 << 20);
 }
 
 // Replicas of a batch's tally block: enough that the hot words of a small domain (fluxUp / fluxDown of nx * ny columns) are
