@@ -394,14 +394,22 @@ int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int n
     for (size_t i = 0; i < ncell; ++i) m = std::max(m, pfIndex[(size_t)c * ncell + i]);
     h->maxPfIndex[c] = m;
   }
-  if (ncomp == 1) {   // values every cell shares travel in the kernel arguments (specialised kernel)
-    bool sameSsa = true, samePf = pfIndex[0] >= 1;
-    for (size_t i = 1; i < ncell && (sameSsa || samePf); ++i) {
-      sameSsa = sameSsa && ssa[i] == ssa[0];
-      samePf = samePf && pfIndex[i] == pfIndex[0];
+  if (ncomp == 1) {
+    // Values that every cell WITH EXTINCTION shares travel in the kernel arguments (specialised kernels: ray tracing, where a
+    // photon can only be scattered in a cell of positive extinction -- the tracer never stops in any other --, so what the
+    // clear cells hold is never read: the I3RC cloud fields have omega = 0 and phase-function entry 0 there).  Without this
+    // every scattering reads two more words from two more arrays of the field's size, which on the Landsat fields
+    // do not fit in L2 beside it.
+    bool sameSsa = true, samePf = true, any = false;
+    float ssa0 = 1.f; int32_t pf0 = 1;
+    for (size_t i = 0; i < ncell && (sameSsa || samePf); ++i) {
+      if (totalExt[i] == 0.0f) continue;
+      if (!any) { any = true; ssa0 = ssa[i]; pf0 = pfIndex[i]; continue; }
+      sameSsa = sameSsa && ssa[i] == ssa0;
+      samePf = samePf && pfIndex[i] == pf0;
     }
-    h->uniformSsa = (sameSsa && ssa[0] >= 0.f) ? ssa[0] : -1.f;
-    h->uniformPf = samePf ? pfIndex[0] : 0;
+    h->uniformSsa = (sameSsa && ssa0 >= 0.f) ? ssa0 : -1.f;
+    h->uniformPf = (samePf && pf0 >= 1) ? pf0 : 0;
   }
   // defaults of type(integrator) :54-129
   h->params.surfaceAlbedo = 0.f; h->params.useSurfaceBDRF = 0; h->params.useRayTracing = 1; h->params.useRussianRoulette = 1;
