@@ -296,6 +296,8 @@ def worker(a):
         """`steps` timed steps of the workload's batch: weak = every rank its own --photons photons, strong = one batch of
         --photons photons sharded over the ranks by photon range."""
         per_step = a.photons or w["photons"]
+        if scaling == "strong" and n_gpus > 1 and not a.photons:
+            per_step = w.get("photons_node", per_step)   # configs 3 / 4: the batch BASELINE.json quotes for the whole node (1e9 photons)
         if scaling == "strong":
             first, mine = shard_photons(per_step, n_gpus, rank)
             total_per_step = per_step

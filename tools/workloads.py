@@ -13,7 +13,8 @@ NADIR = dict(intensityMus=[1.0], intensityPhis=[0.0])
 RRI = dict(useRussianRouletteForIntensity=True, zetaMin=0.3)   # the driver's defaults (monteCarloDriver.f95:75-76)
 
 # name -> description of one workload.  `photons` = photons per GPU per step at the size BASELINE.json quotes
-# (configs 3 / 4: 1e9 photons over 8 GPUs = 1.25e8 per GPU); `cpu_photons` = photons per CPU-baseline batch so that the
+# (configs 3 / 4: 1e9 photons over 8 GPUs = 1.25e8 per GPU; `photons_node` = the whole batch, what `bench.py --gpus N` shards in its
+# default (strong) mode); `cpu_photons` = photons per CPU-baseline batch so that the
 # bounded CPU sample is about 10-30 s on 16 cores.
 WORKLOADS = {
     "step16": dict(label="i3rcStepCloud 32x1x16 (HG g=0.85 64 moments, omega=1, mu0=1, albedo 0), flux up/down",
@@ -33,16 +34,16 @@ WORKLOADS = {
                            photons=100_000_000, cpu_photons=40_000),
     "landsat36": dict(label="i3rcLandsatCloud 128x128x36 (labelled synthetic, HG g=0.85 299 moments, mu0=1), flux",
                       baseline_config=3, domain=("landsat_cloud", dict(nlayers=36)), moments=299, mu0=1.0, params={},
-                      photons=125_000_000, cpu_photons=60_000),
+                      photons=125_000_000, photons_node=1_000_000_000, cpu_photons=60_000),
     "landsat119": dict(label="i3rcLandsatCloud 128x128x119 (reference-exact field, mu0=1), flux", baseline_config=3,
-                       domain=("landsat_cloud", {}), moments=299, mu0=1.0, params={}, photons=125_000_000, cpu_photons=40_000),
+                       domain=("landsat_cloud", {}), moments=299, mu0=1.0, params={}, photons=125_000_000, photons_node=1_000_000_000, cpu_photons=40_000),
     "landsat119_7dir": dict(label="i3rcLandsatCloud 128x128x119 + 7 radiance directions + Lambertian surface 0.2 "
                                   "(surfaceProperties object), mu0=0.5, roulette zetaMin 0.3",
                             baseline_config=4, domain=("landsat_cloud", {}), moments=299, mu0=0.5,
-                            params=dict(**DIRS7, **RRI), surface=0.2, photons=125_000_000, cpu_photons=6_000),
+                            params=dict(**DIRS7, **RRI), surface=0.2, photons=125_000_000, photons_node=1_000_000_000, cpu_photons=6_000),
     "landsat36_7dir": dict(label="i3rcLandsatCloud 128x128x36 + 7 radiance directions + Lambertian surface 0.2, mu0=0.5",
                            baseline_config=4, domain=("landsat_cloud", dict(nlayers=36)), moments=299, mu0=0.5,
-                           params=dict(**DIRS7, **RRI), surface=0.2, photons=125_000_000, cpu_photons=8_000),
+                           params=dict(**DIRS7, **RRI), surface=0.2, photons=125_000_000, photons_node=1_000_000_000, cpu_photons=8_000),
     # beyond BASELINE.json: a field of production size (31 MB of extinction: 8 times an XCD's L2), the Landsat scene tiled 2 x 2
     "landsat_tiled": dict(label="Landsat scene tiled 2x2: 256x256x119 (31 MB field), mu0=1, flux", baseline_config=3,
                           domain=("landsat_tiled", {}), moments=299, mu0=1.0, params={}, photons=125_000_000, cpu_photons=40_000),
