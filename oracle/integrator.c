@@ -318,6 +318,7 @@ int64_t orc_compute_rt(const orc_problem *p, orc_mt *rng, int64_t n,
   }
   float x0 = cx.x0, xMax = XE(p->nx + 1), y0 = cx.y0, yMax = YE(p->ny + 1), z0 = cx.z0, zMax = ZE(p->nz + 1);
   float *contrib = NULL; int *ixF = NULL, *iyF = NULL;
+  float *cum = malloc(sizeof(float) * ((size_t)p->ncomp + 1));   /* (/0, cumulativeExt(ix,iy,iz,:)/) of the event's cell, :637 */
   if (p->nDir > 0) {
     contrib = malloc(sizeof(float) * p->nDir); ixF = malloc(sizeof(int) * p->nDir); iyF = malloc(sizeof(int) * p->nDir);
   }
@@ -417,7 +418,6 @@ int64_t orc_compute_rt(const orc_problem *p, orc_mt *rng, int64_t n,
             if (zPos - ZE(iz) <= 0.0f && dir[2] > 0.0f) { zPos = zPos - orc_spacing(zPos); iz = iz - 1; }
           }
           /* component :637-638: findIndex(r, (/0, cumExt(ix,iy,iz,:)/)) */
-          float cum[64];
           cum[0] = 0.0f;
           for (int k = 1; k <= p->ncomp; k++) cum[k] = p->cumExt[CELLC(ix, iy, iz, k)];
           int comp = orc_find_index(orc_mt_real(rng), cum, p->ncomp + 1, 0);
@@ -452,7 +452,7 @@ int64_t orc_compute_rt(const orc_problem *p, orc_mt *rng, int64_t n,
   }
   if (t->drawStart) t->drawStart[n] = rng->draws - draws0;
   t->nPhotons += nPhotons;
-  free(contrib); free(ixF); free(iyF);
+  free(contrib); free(ixF); free(iyF); free(cum);
   return nPhotons;
 }
 

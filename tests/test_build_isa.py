@@ -66,8 +66,9 @@ def test_production_kernels_keep_their_state_in_registers():
     from tools.kernel_resources import resources
 
     everything = resources()
-    rows = [r for r in everything if r["name"].startswith("photon_kernel<PhiloxStream") and "table in LDS" not in r["name"]]
-    assert len(rows) == 12, [r["name"] for r in rows]
+    # every PhiloxStream instantiation, the table-in-LDS ones among them: BENCH's headline (step cloud) and Landsat-36 run those
+    rows = [r for r in everything if r["name"].startswith("photon_kernel<PhiloxStream")]
+    assert len(rows) == 15 and sum("table in LDS" in r["name"] for r in rows) == 3, [r["name"] for r in rows]
     fused = [r for r in everything if r["name"].startswith("photon_kernel<PhiloxBatchStream")]   # the fused multi-batch flux kernels
     assert len(fused) == 5, [r["name"] for r in fused]
     for r in rows + fused:
@@ -81,6 +82,8 @@ def test_production_kernels_keep_their_state_in_registers():
             limit = 16
             # (the bricked flux kernel reads its clear-air map through two more scalar values: a couple of spills)
             if r["name"].startswith("photon_kernel<PhiloxStream, false"): limit = 4 if "GRID_BRICKS" in r["name"] else 12
+            # (1024-thread workgroups with the inverse table's cosines in LDS: the table's LDS address and length are two more scalar values)
+            if r["name"].startswith("photon_kernel<PhiloxStream, false") and "table in LDS" in r["name"] and "GRID_BRICKS" not in r["name"]: limit = 14
             if r["name"].startswith("photon_kernel<PhiloxBatchStream"): limit = 12 if "table in LDS" in r["name"] else 4
             assert r["SGPRs Spill"] <= limit, (r["name"], r["SGPRs Spill"])
     # the replay build (test infrastructure on the device) must not use scratch either

@@ -237,3 +237,24 @@ def test_cpu_baseline_tool_reports_work_counters_and_saves_batches(tmp_path):
     z = np.load(out)
     assert z["means"].shape[0] == 4 and z["intensityMeans"].shape[0] == 4 and int(z["photonsPerBatch"]) == 500
     assert float(z["cellSteps"].sum()) / 2000 == pytest.approx(w["S"])
+
+
+def test_many_components_share_one_draw_each(oracle):
+    """Component selection (:637-638) with more components than the restatement's former fixed buffer of 64 took (the product
+    takes 255): a domain with 99 empty components behind its cloud is the one-component domain -- the same deviates are drawn
+    in the same order and every scattering picks component 1 -- so every counter and tally agrees to the last bit."""
+    d = cases.step_cloud(ssa=0.9, nlayers=8)
+    inv = oracle.inverse_table_legendre(cases.hg_coefficients(0.85, 64), 10001)
+    nc = 100
+    zero = np.zeros_like(d["ext"])
+    one = oracle.Integrator(d["xe"], d["ye"], d["ze"], d["ext"], d["ssa"], np.maximum(d["pf"], 1), [inv])
+    many = oracle.Integrator(d["xe"], d["ye"], d["ze"], np.stack([d["ext"]] + [zero] * (nc - 1)), np.stack([d["ssa"]] + [zero] * (nc - 1)),
+                             np.stack([np.maximum(d["pf"], 1)] * nc), [inv] * nc)
+    res = []
+    for integ in (one, many):
+        rng = oracle.RandomNumberSequence([10, 3])
+        res.append(integ.compute(rng, *oracle.photons_directional(rng, 1.0, 0.0, 20000)))
+    a, b = res
+    assert a["scatterings"] == b["scatterings"] > 1e5 and a["cellSteps"] == b["cellSteps"] and a["nBad"] == b["nBad"]
+    for k in ("fluxUp", "fluxDown", "fluxAbsorbed"):
+        assert np.array_equal(a[k], b[k]), k
