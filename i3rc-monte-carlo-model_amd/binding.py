@@ -25,7 +25,7 @@ SYMBOLS = [
     "i3rc_hip_create", "i3rc_hip_destroy", "i3rc_hip_last_error", "i3rc_hip_set_inverse_table",
     "i3rc_hip_set_forward_tables", "i3rc_hip_set_params", "i3rc_hip_set_surface", "i3rc_hip_set_directions",
     "i3rc_hip_get_tally_layout", "i3rc_hip_bind_tally_buffer", "i3rc_hip_set_stream", "i3rc_hip_use_own_stream", "i3rc_hip_zero_tallies",
-    "i3rc_hip_launch_batch", "i3rc_hip_run_batches", "i3rc_hip_compute_batch", "i3rc_hip_expect_batches", "i3rc_hip_run_replay", "i3rc_hip_trace_rays", "i3rc_hip_synchronize",
+    "i3rc_hip_launch_batch", "i3rc_hip_run_batches", "i3rc_hip_run_batches_moments", "i3rc_hip_get_moments_layout", "i3rc_hip_compute_batch", "i3rc_hip_expect_batches", "i3rc_hip_run_replay", "i3rc_hip_trace_rays", "i3rc_hip_synchronize",
     "i3rc_hip_fetch_tallies", "i3rc_hip_normalise", "i3rc_hip_last_kernel_ms", "i3rc_hip_kernel_ms_history", "i3rc_hip_set_tuning", "i3rc_hip_force_general_kernel", "i3rc_hip_select_kernel", "i3rc_hip_set_light_threshold", "i3rc_hip_set_launch_limit",
     "i3rc_hip_set_batch_fusion", "i3rc_hip_last_kernel_name", "i3rc_hip_timed_launch_count", "i3rc_hip_philox_blocks", "i3rc_hip_arith_check", "i3rc_hip_device_count", "i3rc_hip_version",
 ]
@@ -49,6 +49,11 @@ class TallyLayout(C.Structure):
     _fields_ = [("fluxUp", C.c_int64), ("fluxDown", C.c_int64), ("fluxAbsorbed", C.c_int64),
                 ("volumeAbsorption", C.c_int64), ("intensityByComponent", C.c_int64), ("intensityExcess", C.c_int64),
                 ("counters", C.c_int64), ("total", C.c_int64)]
+
+
+class MomentsLayout(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("fluxUp", "fluxDown", "fluxAbsorbed", "volumeAbsorption", "intensity", "absorbedProfile",
+                                         "meanFluxUp", "meanFluxDown", "meanFluxAbsorbed", "meanIntensity", "total")]
 
 
 class I3RCError(RuntimeError):
@@ -90,6 +95,9 @@ def load():
     L.i3rc_hip_launch_batch.argtypes = [H, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.POINTER(Source)]
     if hasattr(L, "i3rc_hip_run_batches"):   # (absent from older builds loaded for A/B timing)
         L.i3rc_hip_run_batches.argtypes = [H, C.c_uint32, C.c_uint32, C.c_int, C.c_int64, C.POINTER(Source), C.c_int, dp]
+    if hasattr(L, "i3rc_hip_run_batches_moments"):
+        L.i3rc_hip_run_batches_moments.argtypes = [H, C.c_uint32, C.c_uint32, C.c_int, C.c_int64, C.POINTER(Source), dp, dp, dp]
+        L.i3rc_hip_get_moments_layout.argtypes = [H, C.POINTER(MomentsLayout)]
     if hasattr(L, "i3rc_hip_expect_batches"):
         L.i3rc_hip_expect_batches.argtypes = [H, C.c_uint32, C.c_uint32, C.c_int, C.c_int64, C.POINTER(Source), C.POINTER(C.c_int)]
     if hasattr(L, "i3rc_hip_compute_batch"):

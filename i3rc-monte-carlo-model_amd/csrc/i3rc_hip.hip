@@ -99,7 +99,7 @@ struct i3rc_hip_integrator {
   // i3rc_hip_run_batches: batches in flight, each with a stream, a tally buffer, a work counter and a pinned host copy of its own
   struct PipeSlot {
     hipStream_t stream = nullptr;
-    DevBuf tally, counter;
+    DevBuf tally, counter, excess;   // (excess: see accumulate_moments)
     double *pinned = nullptr;
     hipEvent_t done = nullptr;
     int batch = -1;            // batch whose tallies are on their way into `pinned`
@@ -125,7 +125,7 @@ struct i3rc_hip_integrator {
   struct FusedSlot {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
-    DevBuf blocks, compact, counter, counterBlocks;
+    DevBuf blocks, compact, counter, counterBlocks, excess;
     double *pinned = nullptr; size_t pinnedBytes = 0;
     int *abortFlag = nullptr;      // host-coherent word the kernel polls (RunArgs::abortFlag)
     int first = 0, count = 0;      // batches first .. first + count - 1 of the call (count = 0: free)
@@ -139,6 +139,9 @@ struct i3rc_hip_integrator {
   bool aheadBounded = false;       // i3rc_hip_expect_batches: the caller has announced its loop -- nothing is launched beyond
   uint32_t aheadEnd = 0;           // ... this seed word (exclusive)
   int fusion = -1;                 // -1: automatic, 0: never fuse, 1: fuse whatever the batch size (i3rc_hip_set_batch_fusion)
+  bool fusedAheadFailed = false;
+  // i3rc_hip_run_batches_moments: sums and sums of squares over a loop's batches, accumulated on the device
+  DevBuf momSum, momSq, momCounters, momArea, momDz;   // a fused group could not be launched ahead (memory): look ahead with single batches until the layout changes
 
   // XCD-aware photon order (launch): the sorted photon numbers and the slab bookkeeping of a launch, per stream (launches
   // on different streams -- i3rc_hip_run_batches -- are in flight together)
@@ -237,6 +240,7 @@ static int reset_slots_if_layout_changed(i3rc_hip_integrator *h) {
     sl.batch = -1;
   }
   h->pipeTotal = h->layout.total;
+  h->fusedAheadFailed = false;
   return 0;
 }
 static int ready_slot(i3rc_hip_integrator *h, int k) {
@@ -605,7 +609,7 @@ int i3rc_hip_set_launch_limit(i3rc_hip_integrator *h, int64_t photons) {
 int i3rc_hip_select_kernel(i3rc_hip_integrator *h, int variant) {
   if (!h) return 1;
   drop_lookahead(h);
-  if (variant < I3RC_KERNEL_AUTO || variant > I3RC_KERNEL_LANE) return h->fail("i3rc_hip_select_kernel: unknown variant");
+  if (variant < I3RC_KERNEL_AUTO || variant > I3RC_KERNEL_RING) return h->fail("i3rc_hip_select_kernel: unknown variant");
   h->kernelVariant = variant;
   return 0;
 }
@@ -615,6 +619,7 @@ int i3rc_hip_set_batch_fusion(i3rc_hip_integrator *h, int mode) {
   drop_lookahead(h);
   if (mode < -1 || mode > 1) return h->fail("i3rc_hip_set_batch_fusion: mode is -1 (automatic), 0 (never) or 1 (whenever possible)");
   h->fusion = mode;
+  h->fusedAheadFailed = false;
   return 0;
 }
 
@@ -657,6 +662,13 @@ bool common_class(const i3rc_hip_integrator *h, int srcKind) {
   return h->xyRegular && traced(h) && !gridSurface && h->ncomp == 1 && srcKind == 0;
 }
 
+// One radiance direction (nadir views: BASELINE.json's radar case): the radiance kernels without an event ring (photon_kernel,
+// DIRECT).  I3RC_DIRECT=0 keeps the ring for them too.
+bool direct_rays(const i3rc_hip_integrator *h) {
+  static const bool on = !(std::getenv("I3RC_DIRECT") && std::atoi(std::getenv("I3RC_DIRECT")) == 0);
+  return on && h->nDir == 1 && h->kernelVariant != I3RC_KERNEL_RING;
+}
+
 size_t ncell_bytes(const i3rc_hip_integrator *h) { return sizeof(float) * (size_t)h->nx * h->ny * h->nz; }
 
 int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false) {
@@ -675,7 +687,8 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false) {
   P.deltaX = h->xE[1] - h->xE[0]; P.deltaY = h->yE[1] - h->yE[0]; P.deltaZ = h->zE[1] - h->zE[0];
   P.xE = (const float *)h->dxE.p; P.yE = (const float *)h->dyE.p; P.zE = (const float *)h->dzE.p;
   // bricks pay off once the field no longer fits in one XCD's 4 MB of L2
-  P.extBrick = (ncell_bytes(h) > ((size_t)4 << 20)) ? (const float *)h->dExtBrick.p : nullptr;
+  // (the clear-air map of a bricked field holds layer numbers in 16 bits: domains of more layers than that keep the linear field)
+  P.extBrick = (ncell_bytes(h) > ((size_t)4 << 20) && h->nz <= 65534) ? (const float *)h->dExtBrick.p : nullptr;
   P.bsx = h->bsx; P.bsy = h->bsy; P.bsz = h->bsz; P.nbx = h->nbx; P.nbxy = h->nbx * h->nby;
   P.clearMap = (const uint32_t *)h->dClearMap.p; P.clearShift = h->clearShift; P.clearNx = h->clearNx;
   P.totalExt = (const float *)h->dExt.p; P.cumExt = (const float *)h->dCum.p; P.ssa = (const float *)h->dSsa.p;
@@ -717,8 +730,9 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false) {
   size_t lds = sizeof(float) * ((h->nx + 1) + (h->ny + 1) + (h->nz + 1) + 3 * (size_t)h->nDir);
   // radiance runs: every wave's ring of local-estimate events (one record serves the nDir rays of an event) and its
   // buffer of ready-made rays (photon_kernel, ray mode)
-  P.rayQueueCap = h->nDir > 0 ? 64 : 0;   // (an event phase pushes at most 64 records; the rays go on to the ready buffer)
-  if (h->nDir > 0) lds += sizeof(float) * 4 * (kRecWords * (size_t)P.rayQueueCap + kReadyWords * kReadyRays);
+  // (one direction: no ring, a ready store of two wavefronts -- photon_kernel, DIRECT)
+  P.rayQueueCap = h->nDir > 0 && !direct_rays(h) ? 64 : 0;   // (an event phase pushes at most 64 records; the rays go on to the ready buffer)
+  if (h->nDir > 0) lds += sizeof(float) * 4 * (kRecWords * (size_t)P.rayQueueCap + kReadyWords * (size_t)(direct_rays(h) ? kDirectReady : kReadyRays));
   if (h->nDir > 0)
     for (int c = 0; c < h->ncomp; ++c)
       if (h->maxPfIndex[c] >= 65536) return h->fail("radiance runs take at most 65535 phase-function table entries per component");
@@ -790,6 +804,12 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
         {photon_kernel<Rng, false, false, GRID_LDS>, photon_kernel<Rng, false, false, GRID_GLOBAL>, photon_kernel<Rng, false, false, GRID_BRICKS>},
         {photon_kernel<Rng, true, false, GRID_LDS>, photon_kernel<Rng, true, false, GRID_GLOBAL>, photon_kernel<Rng, true, false, GRID_BRICKS>}};
     if (simple) kern = special[plan.intensity ? 1 : 0][place];
+    if (plan.intensity && direct_rays(h)) {   // (the replay build keeps the nested local estimate: no queue at all)
+      static const Kernel direct[2][3] = {
+          {photon_kernel<Rng, true, true, GRID_LDS, false, true>, photon_kernel<Rng, true, true, GRID_GLOBAL, false, true>, photon_kernel<Rng, true, true, GRID_BRICKS, false, true>},
+          {photon_kernel<Rng, true, false, GRID_LDS, false, true>, photon_kernel<Rng, true, false, GRID_GLOBAL, false, true>, photon_kernel<Rng, true, false, GRID_BRICKS, false, true>}};
+      kern = direct[simple ? 1 : 0][place];
+    }
   }
   // Flux problems of the common class with ONE phase-function entry keep the inverse table's cosines (40 KB) in LDS, in
   // workgroups of 1024 threads, two per compute unit (photon_kernel, TBL): the two dependent table reads of a scattering come
@@ -819,6 +839,10 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
                        plan.intensity ? "true" : "false", (simple ? "false" : "true"), placeName[place]);
     h->lastKernelName = name;
     if (threads == 1024) { std::snprintf(name, sizeof(name), "photon_kernel<PhiloxStream, false, false, %s, table in LDS>", placeName[place]); h->lastKernelName = name; }
+    if (!Rng::kReplay && plan.intensity && direct_rays(h)) {
+      std::snprintf(name, sizeof(name), "photon_kernel<PhiloxStream, true, %s, %s, one direction>", (simple ? "false" : "true"), placeName[place]);
+      h->lastKernelName = name;
+    }
   }
   int perCU = h->blocksPerCU;
   if (perCU <= 0) {
@@ -914,14 +938,116 @@ __global__ void __launch_bounds__(256) reduce_counters_kernel(const double *coun
   out[(size_t)b * stride + oCnt + k] = v;
 }
 
-// Can the batches of a driver's loop share one grid?  The specialised flux kernels only (so far): the common problem class
-// without radiance directions, production streams.
+// ---- batch moments on the device (i3rc_hip_run_batches_moments) ---------------------------------------------------------
+// A driver only ever wants the first two moments over its batches of what reportResults hands out (monteCarloDriver.f95:
+// 300-321, reduced at :333-352): per batch the raw block is normalised exactly as i3rc_hip_normalise does it (:353-395, float64,
+// rounded to the reference's real(4)) and x, x^2 are added up per element -- the per-batch blocks never leave the device.
+struct MomentsDev {
+  // the raw tally block (offsets as in DevProblem) ...
+  int oUp, oDown, oAbs, oVol, oInt, oExc, oCnt;
+  int nx, ny, nz, ncomp, nDir, xyRegular, limitContrib;
+  const double *areaFrac;   // [ncol] irregular grids: column area / domain area (:358-366)
+  const double *dz;         // [nz] layer depths (:378-381)
+  // ... and the moments block (i3rc_moments_layout)
+  long long mUp, mDown, mAbs, mVol, mInt, mProfile, mMeanUp, mMeanDown, mMeanAbs, mMeanInt;
+};
+__device__ __forceinline__ double photons_per_column(const MomentsDev &M, const double *raw, int col) {
+  const double nPhot = raw[M.oCnt + I3RC_CNT_PHOTONS];
+  return M.xyRegular ? nPhot / (double)(M.nx * M.ny) : M.areaFrac[col] * nPhot;
+}
+// the radiance of column `col` in direction d as reportResults gives it: components summed, the excess of limited contributions
+// redistributed in proportion (:327-347; excessSums[(j * nDir + d)] = the sum over the columns of component j's field)
+__device__ __forceinline__ float normalised_intensity(const MomentsDev &M, const double *raw, const double *excessSums, int d, int col) {
+  const size_t ncol = (size_t)M.nx * M.ny;
+  double tot = 0.0;
+  for (int j = 0; j <= M.ncomp; ++j) tot += raw[M.oInt + ((size_t)j * M.nDir + d) * ncol + col];
+  if (M.limitContrib)
+    for (int j = 0; j <= M.ncomp; ++j) {
+      const double ex = raw[M.oExc + (size_t)j * M.nDir + d];
+      if (ex > 0.0) tot += (raw[M.oInt + ((size_t)j * M.nDir + d) * ncol + col] / excessSums[j * M.nDir + d]) * ex;
+    }
+  return (float)(tot / photons_per_column(M, raw, col));
+}
+// one normalised field value of a batch; e counts through fluxUp | fluxDown | fluxAbsorbed | volumeAbsorption | intensity
+__device__ __forceinline__ float normalised_value(const MomentsDev &M, const double *raw, const double *excessSums, long long e) {
+  const long long ncol = (long long)M.nx * M.ny, ncell = ncol * M.nz;
+  if (e < 3 * ncol) {
+    const int which = (int)(e / ncol), col = (int)(e - which * ncol);
+    const int o = which == 0 ? M.oUp : (which == 1 ? M.oDown : M.oAbs);
+    return (float)(raw[o + col] / photons_per_column(M, raw, col));
+  }
+  e -= 3 * ncol;
+  if (e < ncell) {
+    const int kz = (int)(e / ncol), col = (int)(e - kz * ncol);
+    return (float)(raw[M.oVol + e] / (photons_per_column(M, raw, col) * M.dz[kz]));
+  }
+  e -= ncell;
+  const int d = (int)(e / ncol);
+  return normalised_intensity(M, raw, excessSums, d, (int)(e - d * ncol));
+}
+// excessSums[b][(j * nDir + d)] = sum over the columns of intensityByComponent(:, :, d, j) of batch b (one workgroup each)
+__global__ void __launch_bounds__(256) moments_excess_kernel(MomentsDev M, const double *blocks, long long stride, double *excessSums) {
+  const int per = (M.ncomp + 1) * M.nDir, b = blockIdx.x / per, jd = blockIdx.x - b * per;
+  const size_t ncol = (size_t)M.nx * M.ny;
+  const double *f = blocks + (size_t)b * stride + M.oInt + (size_t)jd * ncol;
+  double v = 0.0;
+  for (size_t k = threadIdx.x; k < ncol; k += 256) v += f[k];
+  __shared__ double part[4];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) excessSums[(size_t)b * per + jd] = part[0] + part[1] + part[2] + part[3];
+}
+// fields: one thread per element, the group's batches one after the other
+__global__ void __launch_bounds__(256) moments_fields_kernel(MomentsDev M, const double *blocks, int count, long long stride, const double *excessSums,
+                                                             long long nFields, double *sum, double *sumSq) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= nFields) return;
+  const int per = (M.ncomp + 1) * M.nDir;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < count; ++b) {
+    const double x = (double)normalised_value(M, blocks + (size_t)b * stride, excessSums + (size_t)b * per, e);
+    s1 += x; s2 += x * x;
+  }
+  // (fields lie in the moments block in the order e counts them: fluxUp | fluxDown | fluxAbsorbed | volumeAbsorption | intensity)
+  unsafeAtomicAdd(sum + M.mUp + e, s1);
+  unsafeAtomicAdd(sumSq + M.mUp + e, s2);
+}
+// domain means (:739-742), the absorption profile (:780) and the mean radiances: one workgroup per (batch, quantity)
+__global__ void __launch_bounds__(256) moments_means_kernel(MomentsDev M, const double *blocks, long long stride, const double *excessSums,
+                                                            double *sum, double *sumSq, double *counterTotals) {
+  const int nq = 3 + M.nz + M.nDir, b = blockIdx.x / nq, q = blockIdx.x - b * nq;
+  const double *raw = blocks + (size_t)b * stride;
+  const int per = (M.ncomp + 1) * M.nDir;
+  const long long ncol = (long long)M.nx * M.ny;
+  long long first, at;   // first field element of the quantity (normalised_value's numbering) and its place in the moments block
+  if (q < 3) { first = q * ncol; at = q == 0 ? M.mMeanUp : (q == 1 ? M.mMeanDown : M.mMeanAbs); }
+  else if (q < 3 + M.nz) { first = 3 * ncol + (long long)(q - 3) * ncol; at = M.mProfile + (q - 3); }
+  else { first = 3 * ncol + ncol * M.nz + (long long)(q - 3 - M.nz) * ncol; at = M.mMeanInt + (q - 3 - M.nz); }
+  double v = 0.0;
+  for (long long k = threadIdx.x; k < ncol; k += 256) v += (double)normalised_value(M, raw, excessSums + (size_t)b * per, first + k);
+  __shared__ double part[4];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double x = (double)(float)((part[0] + part[1] + part[2] + part[3]) / (double)ncol);
+    unsafeAtomicAdd(sum + at, x);
+    unsafeAtomicAdd(sumSq + at, x * x);
+  }
+  if (q == 0 && threadIdx.x < I3RC_NUM_COUNTERS) unsafeAtomicAdd(counterTotals + threadIdx.x, raw[M.oCnt + threadIdx.x]);
+}
+
+// Can the batches of a driver's loop share one grid?  The specialised kernels -- the common problem class, production streams --,
+// with or (round 4) without radiance directions: a local-estimate ray carries its batch in its info word (photon_kernel).
 bool fusable(const i3rc_hip_integrator *h, int64_t nPhotons) {
   static const bool envOff = std::getenv("I3RC_FUSED") && std::atoi(std::getenv("I3RC_FUSED")) == 0;
   if (envOff || h->fusion == 0) return false;
   // (a batch's tally block beyond 256 MiB -- 3e7 cells -- would make a slot's pinned copy and its blocks unreasonably large: such
   // domains keep one launch per batch, whose tail is a small part of a launch that long anyway)
-  return common_class(h, 0) && h->nDir == 0 && h->kernelVariant != I3RC_KERNEL_GENERAL && nPhotons < ((int64_t)1 << 31) &&
+  static const bool radianceOff = std::getenv("I3RC_FUSED_RADIANCE") && std::atoi(std::getenv("I3RC_FUSED_RADIANCE")) == 0;
+  if (h->nDir > 0 && radianceOff) return false;
+  return common_class(h, 0) && h->kernelVariant != I3RC_KERNEL_GENERAL && nPhotons < ((int64_t)1 << 31) &&
          h->layout.total * (int64_t)sizeof(double) <= ((int64_t)256 << 20);
 }
 
@@ -936,9 +1062,10 @@ int fused_replicas(const i3rc_hip_integrator *h) {
 // Batches per group: device memory for the blocks (<= 1 GiB) and the pinned copy (<= 256 MiB) bound it; beyond that a
 // group wants some 2.5e8 photons: a group boundary costs about 2.4 ms even with the next group queued behind it (step
 // cloud, 300 batches of 1e6 photons: 15 groups 0.38, 6 groups 0.34, 3 groups 0.33, 1 group 0.31 ms per batch).
-int fused_group_size(const i3rc_hip_integrator *h, int nBatches, int64_t nPhotons) {
+int fused_group_size(const i3rc_hip_integrator *h, int nBatches, int64_t nPhotons, bool moments = false) {
   const int64_t blockBytes = h->layout.total * 8, R = fused_replicas(h);
-  int64_t g = std::min<int64_t>(((int64_t)1 << 30) / (blockBytes * R), ((int64_t)256 << 20) / blockBytes);
+  int64_t g = ((int64_t)1 << 30) / (blockBytes * R);
+  if (!moments) g = std::min<int64_t>(g, ((int64_t)256 << 20) / blockBytes);   // (moments mode: no pinned copy of the blocks)
   static const int64_t target = std::getenv("I3RC_FUSED_GROUP_PHOTONS") ? std::atoll(std::getenv("I3RC_FUSED_GROUP_PHOTONS")) : 250000000ll;
   g = std::min<int64_t>(g, (target + nPhotons - 1) / nPhotons);
   return (int)std::max<int64_t>(1, std::min<int64_t>(g, nBatches));
@@ -947,7 +1074,7 @@ int fused_group_size(const i3rc_hip_integrator *h, int nBatches, int64_t nPhoton
 // (`reserve`: batches the slot's buffers are made for at least -- a slot that had to grow later would hipFree / hipMalloc while
 // other groups are under way, and both wait for the device: a driver's look-ahead, whose groups grow 8, 16 ... 256, stood still
 // for a whole group each time)
-int ready_fused_slot(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g, int count, int R, int reserve) {
+int ready_fused_slot(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g, int count, int R, int reserve, bool toHost) {
   count = std::max(count, reserve);
   const size_t outBytes = (size_t)count * h->layout.total * sizeof(double);
   // All groups share ONE stream (the first slot's): a kernel trace of groups on streams of their own showed consecutive
@@ -965,7 +1092,7 @@ int ready_fused_slot(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g, 
   if (!g.done) HIPCHK(h, hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
   if (!g.counter.p) HIPCHK(h, g.counter.alloc(sizeof(unsigned long long)));
   if (!g.abortFlag) HIPCHK(h, hipHostMalloc((void **)&g.abortFlag, sizeof(int), hipHostMallocCoherent | hipHostMallocMapped));
-  if (g.pinnedBytes < outBytes) {
+  if (toHost && g.pinnedBytes < outBytes) {
     if (g.pinned) { HIPCHK(h, hipHostFree(g.pinned)); g.pinned = nullptr; g.pinnedBytes = 0; }
     HIPCHK(h, hipHostMalloc((void **)&g.pinned, outBytes, hipHostMallocDefault));
     g.pinnedBytes = outBytes;
@@ -979,10 +1106,13 @@ int ready_fused_slot(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g, 
 
 // One group: `count` batches with the keys (seed0, seed1 .. seed1 + count - 1), nPhotons photons each, traced by ONE grid;
 // zero, trace, sum the replicas, copy to the slot's pinned buffer -- all asynchronous on the slot's stream.
+int accumulate_moments(i3rc_hip_integrator *h, hipStream_t stream, const double *blocks, int count, DevBuf &excess);
+
+// (moments: the group's blocks stay on the device -- normalised and added to the handle's moment sums there, see accumulate_moments)
 int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g, uint32_t seed0, uint32_t seed1, int count,
-                       int64_t nPhotons, const i3rc_source *src, bool timeIt, int reserve = 0) {
+                       int64_t nPhotons, const i3rc_source *src, bool timeIt, int reserve = 0, bool moments = false) {
   const int R = fused_replicas(h);
-  if (ready_fused_slot(h, g, count, R, reserve)) return 1;
+  if (ready_fused_slot(h, g, count, R, reserve, !moments)) return 1;
   hipStream_t const callerStream = h->stream;
   double *const callerTally = h->tally;
   h->stream = g.stream; h->tally = (double *)g.blocks.p;   // (make_problem reads these two)
@@ -1015,7 +1145,13 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
   Kernel kern = kernels[place];
   int threads = 256;
   size_t ldsBytes = plan.ldsBytes;
-  {
+  if (plan.intensity) {   // radiance problems: through the event ring, or (one direction) without it -- as in launch()
+    static const Kernel ring[3] = {photon_kernel<PhiloxBatchStream, true, false, GRID_LDS>, photon_kernel<PhiloxBatchStream, true, false, GRID_GLOBAL>,
+                                   photon_kernel<PhiloxBatchStream, true, false, GRID_BRICKS>};
+    static const Kernel direct[3] = {photon_kernel<PhiloxBatchStream, true, false, GRID_LDS, false, true>, photon_kernel<PhiloxBatchStream, true, false, GRID_GLOBAL, false, true>,
+                                     photon_kernel<PhiloxBatchStream, true, false, GRID_BRICKS, false, true>};
+    kern = direct_rays(h) ? direct[place] : ring[place];
+  } else {
     static const bool tblOn = !(std::getenv("I3RC_TABLE_LDS") && std::atoi(std::getenv("I3RC_TABLE_LDS")) == 0);
     static const int tblPlaces = std::getenv("I3RC_FUSED_TABLE_LDS_PLACES") ? std::atoi(std::getenv("I3RC_FUSED_TABLE_LDS_PLACES")) : 3;   // (measured: Landsat-36 +13 %, radar 640 +12 %, step cloud +1.5 ... 3 % in the kernels' own time)
     if (tblOn && ((tblPlaces >> place) & 1) && place != GRID_BRICKS && (plan.P.uniformPf >= 1 || h->nInvEntries[0] == 1) &&
@@ -1030,7 +1166,8 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
   {
     static const char *const placeName[3] = {"GRID_LDS", "GRID_GLOBAL", "GRID_BRICKS"};
     static thread_local char name[96];
-    std::snprintf(name, sizeof(name), "photon_kernel<PhiloxBatchStream, false, false, %s%s>", placeName[place], threads == 1024 ? ", table in LDS" : "");
+    std::snprintf(name, sizeof(name), "photon_kernel<PhiloxBatchStream, %s, false, %s%s>", plan.intensity ? "true" : "false", placeName[place],
+                  threads == 1024 ? ", table in LDS" : (plan.intensity && direct_rays(h) ? ", one direction" : ""));
     h->lastKernelName = name;
   }
   int perCU = h->blocksPerCU;
@@ -1054,7 +1191,8 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
   if (timeIt) HIPCHK(h, hipEventRecord(h->evStart[slot], g.stream));
   {
     const int evThreshold = h->evThreshold > 0 ? h->evThreshold : -40;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads), ldsBytes, g.stream, plan.P, A, evThreshold, -24);
+    const int lightThreshold = h->lightThreshold > 0 ? h->lightThreshold : -24;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads), ldsBytes, g.stream, plan.P, A, evThreshold, lightThreshold);
   }
   HIPCHK(h, hipGetLastError());
   if (timeIt) { HIPCHK(h, hipEventRecord(h->evStop[slot], g.stream)); h->timedLaunches++; }
@@ -1072,7 +1210,8 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
                        const_cast<double *>(result), (long long)count, (long long)h->layout.total, (int)h->layout.counters);
     HIPCHK(h, hipGetLastError());
   }
-  HIPCHK(h, hipMemcpyAsync(g.pinned, result, outBytes, hipMemcpyDeviceToHost, g.stream));
+  if (moments) { if (accumulate_moments(h, g.stream, result, count, g.excess)) return 1; }
+  else HIPCHK(h, hipMemcpyAsync(g.pinned, result, outBytes, hipMemcpyDeviceToHost, g.stream));
   HIPCHK(h, hipEventRecord(g.done, g.stream));
   g.count = count; g.seed1 = seed1; g.next = 0;
   if (tracing()) std::fprintf(stderr, "[i3rc %9.3f ms] fused group launched: seed words %u .. %u (%d batches of %lld photons, %d replicas, chunk %d)\n", trace_ms(),
@@ -1080,9 +1219,76 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
   return 0;
 }
 
+void moments_layout(const i3rc_hip_integrator *h, i3rc_moments_layout &L) {
+  const int64_t ncol = (int64_t)h->nx * h->ny, ncell = ncol * h->nz;
+  int64_t o = 0;
+  L.fluxUp = o; o += ncol; L.fluxDown = o; o += ncol; L.fluxAbsorbed = o; o += ncol;
+  L.volumeAbsorption = o; o += ncell;
+  L.intensity = o; o += (int64_t)h->nDir * ncol;
+  L.absorbedProfile = o; o += h->nz;
+  L.meanFluxUp = o++; L.meanFluxDown = o++; L.meanFluxAbsorbed = o++;
+  L.meanIntensity = o; o += h->nDir;
+  L.total = o;
+}
+
+// makes the handle's moment sums ready (zeroed) for a loop of batches
+int begin_moments(i3rc_hip_integrator *h) {
+  i3rc_moments_layout L;
+  moments_layout(h, L);
+  const size_t bytes = (size_t)L.total * sizeof(double);
+  if (h->momSum.bytes != bytes) { HIPCHK(h, h->momSum.alloc(bytes)); HIPCHK(h, h->momSq.alloc(bytes)); }
+  if (!h->momCounters.p) HIPCHK(h, h->momCounters.alloc(I3RC_NUM_COUNTERS * sizeof(double)));
+  if (!h->momDz.p) {
+    std::vector<double> dz((size_t)h->nz), area((size_t)h->nx * h->ny);
+    for (int k = 0; k < h->nz; ++k) dz[k] = (double)h->zE[k + 1] - h->zE[k];
+    const double ax = (double)h->xE.back() - h->xE.front(), ay = (double)h->yE.back() - h->yE.front();
+    for (int j = 0; j < h->ny; ++j)
+      for (int i = 0; i < h->nx; ++i)
+        area[(size_t)j * h->nx + i] = (((double)h->yE[j + 1] - h->yE[j]) * ((double)h->xE[i + 1] - h->xE[i])) / (ax * ay);   // (as i3rc_hip_normalise)
+    HIPCHK(h, h->momDz.upload(dz.data(), dz.size() * sizeof(double)));
+    HIPCHK(h, h->momArea.upload(area.data(), area.size() * sizeof(double)));
+  }
+  HIPCHK(h, hipMemset(h->momSum.p, 0, bytes));
+  HIPCHK(h, hipMemset(h->momSq.p, 0, bytes));
+  HIPCHK(h, hipMemset(h->momCounters.p, 0, I3RC_NUM_COUNTERS * sizeof(double)));
+  return 0;
+}
+
+// `count` raw tally blocks on the device (the handle's layout, counters filled in) -> normalised, x and x^2 added to the
+// handle's moment sums; asynchronous on `stream` (blocks from several streams may be added at the same time: float64 atomics)
+int accumulate_moments(i3rc_hip_integrator *h, hipStream_t stream, const double *blocks, int count, DevBuf &excess) {
+  i3rc_moments_layout L;
+  moments_layout(h, L);
+  MomentsDev M;
+  M.oUp = (int)h->layout.fluxUp; M.oDown = (int)h->layout.fluxDown; M.oAbs = (int)h->layout.fluxAbsorbed;
+  M.oVol = (int)h->layout.volumeAbsorption; M.oInt = (int)h->layout.intensityByComponent; M.oExc = (int)h->layout.intensityExcess;
+  M.oCnt = (int)h->layout.counters;
+  M.nx = h->nx; M.ny = h->ny; M.nz = h->nz; M.ncomp = h->ncomp; M.nDir = h->nDir; M.xyRegular = h->xyRegular;
+  M.limitContrib = h->nDir > 0 && h->params.limitIntensityContributions;
+  M.areaFrac = (const double *)h->momArea.p; M.dz = (const double *)h->momDz.p;
+  M.mUp = L.fluxUp; M.mDown = L.fluxDown; M.mAbs = L.fluxAbsorbed; M.mVol = L.volumeAbsorption; M.mInt = L.intensity;
+  M.mProfile = L.absorbedProfile; M.mMeanUp = L.meanFluxUp; M.mMeanDown = L.meanFluxDown; M.mMeanAbs = L.meanFluxAbsorbed; M.mMeanInt = L.meanIntensity;
+  const long long stride = h->layout.total;
+  const int per = (h->ncomp + 1) * h->nDir;
+  if (M.limitContrib) {
+    const size_t need = (size_t)count * per * sizeof(double);
+    if (excess.bytes < need) HIPCHK(h, excess.alloc(need));
+    hipLaunchKernelGGL(moments_excess_kernel, dim3((unsigned)(count * per)), dim3(256), 0, stream, M, blocks, stride, (double *)excess.p);
+  }
+  const long long nFields = L.absorbedProfile;   // (fluxUp ... intensity: everything in front of the profile)
+  hipLaunchKernelGGL(moments_fields_kernel, dim3((unsigned)((nFields + 255) / 256)), dim3(256), 0, stream, M, blocks, count, stride,
+                     (const double *)excess.p, nFields, (double *)h->momSum.p, (double *)h->momSq.p);
+  hipLaunchKernelGGL(moments_means_kernel, dim3((unsigned)(count * (3 + h->nz + h->nDir))), dim3(256), 0, stream, M, blocks, stride,
+                     (const double *)excess.p, (double *)h->momSum.p, (double *)h->momSq.p, (double *)h->momCounters.p);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+// (hostTallies == nullptr: moments mode -- nothing comes back per batch, see i3rc_hip_run_batches_moments)
 int run_batches_fused(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int nBatches, int64_t nPhotons, const i3rc_source *src,
                       double *hostTallies) {
-  const int G = fused_group_size(h, nBatches, nPhotons);
+  const bool moments = hostTallies == nullptr;
+  const int G = fused_group_size(h, nBatches, nPhotons, moments);
   const size_t blockBytes = (size_t)h->layout.total * sizeof(double);
   drop_lookahead(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));   // whatever the caller had in flight on the handle's stream comes first
@@ -1091,7 +1297,7 @@ int run_batches_fused(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, in
   auto collect = [&](i3rc_hip_integrator::FusedSlot &g) -> int {
     if (g.count == 0) return 0;
     HIPCHK(h, hipEventSynchronize(g.done));
-    std::memcpy(hostTallies + (size_t)g.first * (size_t)h->layout.total, g.pinned, (size_t)g.count * blockBytes);
+    if (!moments) std::memcpy(hostTallies + (size_t)g.first * (size_t)h->layout.total, g.pinned, (size_t)g.count * blockBytes);
     g.count = 0;
     return 0;
   };
@@ -1100,7 +1306,7 @@ int run_batches_fused(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, in
     auto &g = h->fused[k % i3rc_hip_integrator::kFusedSlots];
     if ((rc = collect(g))) break;
     const int count = std::min(G, nBatches - first);
-    rc = launch_fused_group(h, g, seed0, seed1 + (uint32_t)first, count, nPhotons, src, true, G);
+    rc = launch_fused_group(h, g, seed0, seed1 + (uint32_t)first, count, nPhotons, src, true, G, moments);
     if (!rc) g.first = first;
   }
   for (int j = 0; j < i3rc_hip_integrator::kFusedSlots; ++j) {   // drain in launch order (also after a failure: nothing stays in flight)
@@ -1128,9 +1334,23 @@ void top_up_groups(i3rc_hip_integrator *h, uint32_t seed0, uint32_t nextIfNone, 
       if (left <= 0) break;
       want = (int)std::min<int64_t>(want, left);
     }
-    const int size = fused_group_size(h, want, nPhotons);
-    const int reserve = h->aheadBounded ? (int)std::min<int64_t>(fused_group_size(h, 256, nPhotons), (int64_t)h->aheadEnd - (int64_t)next + 0) : fused_group_size(h, 256, nPhotons);
-    if (launch_fused_group(h, h->fused[k], seed0, next, size, nPhotons, src, false, std::max(reserve, size))) { h->fused[k].count = 0; break; }   // (not the caller's failure)
+    int size = fused_group_size(h, want, nPhotons);
+    // What a slot is made for.  An ANNOUNCED loop: its largest group at once (a slot that grows later waits for the device twice).
+    // A loop that is only guessed at (an unchanged driver's calls): at most 96 MiB of pinned memory per slot -- a Landsat-sized
+    // field would otherwise hold 3 x (256 MiB pinned + 256 MiB of device memory) per handle for a loop of any length --, and its
+    // groups stay within that, so that such a slot never grows either.
+    int reserve;
+    if (h->aheadBounded) reserve = (int)std::min<int64_t>(fused_group_size(h, 256, nPhotons), (int64_t)h->aheadEnd - (int64_t)next);
+    else {
+      const int64_t blockBytes = h->layout.total * (int64_t)sizeof(double);
+      reserve = (int)std::max<int64_t>(1, std::min<int64_t>(fused_group_size(h, 256, nPhotons), ((int64_t)96 << 20) / blockBytes));
+      size = std::min(size, reserve);
+    }
+    if (launch_fused_group(h, h->fused[k], seed0, next, size, nPhotons, src, false, std::max(reserve, size))) {   // (not the caller's failure)
+      h->fused[k].count = 0;
+      h->fusedAheadFailed = true;   // (remembered: the caller's loop goes on with single batches launched ahead, see i3rc_hip_compute_batch)
+      break;
+    }
     h->aheadGroupSize = std::max(h->aheadGroupSize, want);
     h->aheadGroups.push_back(k);
   }
@@ -1231,6 +1451,66 @@ int i3rc_hip_run_batches(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1,
   return rc;
 }
 
+int i3rc_hip_get_moments_layout(const i3rc_hip_integrator *h, i3rc_moments_layout *layout) {
+  if (!h || !layout) return 1;
+  moments_layout(h, *layout);
+  return 0;
+}
+
+// A driver's batch loop with its statistics gathered on the device: see include/i3rc_hip.h
+int i3rc_hip_run_batches_moments(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int nBatches, int64_t nPhotons,
+                                 const i3rc_source *src, double *sum, double *sumSquares, double *counters) {
+  if (!h) return 1;
+  if (!src || !sum || !sumSquares || nBatches < 1) return h->fail("i3rc_hip_run_batches_moments: bad arguments");
+  if (src->kind != 0) return h->fail("i3rc_hip_run_batches_moments: Directional photon streams only (explicit streams differ from batch to batch)");
+  if (nPhotons <= 0) return h->fail("setIllumination: must ask for non-negative number of photons.");
+  HIPCHK(h, hipSetDevice(h->device));
+  drop_lookahead(h);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (begin_moments(h)) return 1;
+  int rc = 0;
+  if (fusable(h, nPhotons) && (h->fusion == 1 || (nBatches >= 2 && nPhotons <= 20000000)))
+    rc = run_batches_fused(h, seed0, seed1, nBatches, nPhotons, src, nullptr);
+  else {
+    // other problems (the general kernels; long batches): one launch per batch, several in flight as in i3rc_hip_run_batches, each
+    // batch's block normalised and added up on its slot's stream behind its launch
+    const int K = std::min(nBatches, 6);
+    if (reset_slots_if_layout_changed(h)) return 1;
+    for (int k = 0; k < K; ++k) { if (ready_slot(h, k)) return 1; h->pipe[k].batch = -1; }
+    hipStream_t const callerStream = h->stream;
+    double *const callerTally = h->tally;
+    const size_t bytes = (size_t)h->layout.total * sizeof(double);
+    const int64_t perLaunch = h->launchLimit > 0 ? h->launchLimit : (int64_t)h->numCU << 22;
+    for (int b = 0; b < nBatches && !rc; ++b) {
+      auto &sl = h->pipe[b % K];
+      h->stream = sl.stream; h->tally = (double *)sl.tally.p;
+      LaunchPlan plan;
+      RunArgs A;
+      std::memset(&A, 0, sizeof(A));
+      A.seed0 = seed0; A.seed1 = seed1 + (uint32_t)b; A.firstPhoton = 0; A.nPhotons = nPhotons;
+      A.workCounter = (unsigned long long *)sl.counter.p;
+      rc = make_problem(h, plan) || upload_source(h, src, nPhotons, A);
+      if (!rc && hipMemsetAsync(sl.tally.p, 0, bytes, sl.stream) != hipSuccess) rc = h->fail("i3rc_hip_run_batches_moments: clearing a tally buffer failed");
+      for (int64_t done = 0; done < nPhotons && !rc; done += perLaunch) {
+        RunArgs part = A;
+        part.firstPhoton = done;
+        part.nPhotons = std::min(perLaunch, nPhotons - done);
+        rc = launch<PhiloxStream>(h, plan, part, true);
+      }
+      if (!rc) rc = accumulate_moments(h, sl.stream, (const double *)sl.tally.p, 1, sl.excess);
+    }
+    for (int k = 0; k < K; ++k) if (h->pipe[k].stream && hipStreamSynchronize(h->pipe[k].stream) != hipSuccess && !rc) rc = h->fail("i3rc_hip_run_batches_moments: waiting for the batches failed");
+    h->stream = callerStream; h->tally = callerTally;
+  }
+  if (rc) return 1;
+  i3rc_moments_layout L;
+  moments_layout(h, L);
+  HIPCHK(h, hipMemcpy(sum, h->momSum.p, (size_t)L.total * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(sumSquares, h->momSq.p, (size_t)L.total * sizeof(double), hipMemcpyDeviceToHost));
+  if (counters) HIPCHK(h, hipMemcpy(counters, h->momCounters.p, I3RC_NUM_COUNTERS * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
 // computeRadiativeTransfer for one batch of a driver's loop, looking ahead: see include/i3rc_hip.h
 int i3rc_hip_compute_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int64_t nPhotons, const i3rc_source *src,
                            int lookAhead, double *hostTallies) {
@@ -1282,7 +1562,8 @@ int i3rc_hip_compute_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed
   // i3rc_hip_kernel_ms_history holds launches the caller asked for), and a group that is not wanted after all is called
   // off through its abort word: its waves stop at their next visit of the work counter.
   const bool fuse = depth > 0 && fusable(h, nPhotons) && (h->fusion == 1 || nPhotons <= 20000000);
-  auto top_up = [&]() { top_up_groups(h, seed0, seed1 + 1u, nPhotons, src); };
+  // (a group that could not be launched -- memory -- is not tried again at every call: groups under way are still handed out)
+  auto top_up = [&]() { if (!h->fusedAheadFailed) top_up_groups(h, seed0, seed1 + 1u, nPhotons, src); };
   if (!h->aheadGroups.empty()) {
     auto &g = h->fused[h->aheadGroups.front()];
     if (fuse && h->aheadSig == sig && g.seed1 + (uint32_t)g.next == seed1) {
@@ -1316,7 +1597,8 @@ int i3rc_hip_compute_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed
   if (fuse && inLoop) {
     h->aheadSig = sig;
     top_up();
-  } else if (depth > 0 && (inLoop || !h->aheadQueue.empty())) {
+  }
+  if (!(fuse && inLoop && !h->aheadGroups.empty()) && depth > 0 && (inLoop || !h->aheadQueue.empty())) {   // (also when no fused group could be launched)
     h->aheadSig = sig;
     while ((int)h->aheadQueue.size() < depth) {
       const uint32_t next = (h->aheadQueue.empty() ? seed1 : h->aheadQueue.back().seed1) + 1u;
@@ -1354,7 +1636,9 @@ int i3rc_hip_expect_batches(i3rc_hip_integrator *h, uint32_t seed0, uint32_t see
   h->aheadBounded = true; h->aheadEnd = seed1 + (uint32_t)nBatches;
   h->aheadGroupSize = 16;   // (the first group: 32 batches)
   top_up_groups(h, seed0, seed1, nPhotons, src);
-  if (h->aheadGroups.empty()) { h->aheadBounded = false; return 1; }   // (launch_fused_group has left the reason)
+  // (the first group could not be launched -- the slot's pinned or device reserve, say: launch_fused_group has left the reason in
+  // i3rc_hip_last_error --: not accepted, and the caller goes on with i3rc_hip_run_batches, as the header promises)
+  if (h->aheadGroups.empty()) { drop_lookahead(h); return 0; }
   if (accepted) *accepted = 1;
   return 0;
 }
@@ -1426,7 +1710,8 @@ int i3rc_hip_trace_rays(i3rc_hip_integrator *h, int64_t n, const float *dir, flo
   HIPCHK(h, dTau.alloc(sizeof(float) * n)); HIPCHK(h, dSteps.alloc(sizeof(int32_t) * n));
   const size_t lds = sizeof(float) * ((h->nx + 1) + (h->ny + 1) + (h->nz + 1)) + sizeof(uint32_t) * (size_t)h->clearWords;
   if (lds > 64 * 1024) return h->fail("i3rc_hip_trace_rays: domain edge vectors do not fit in LDS");
-  hipLaunchKernelGGL(trace_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, h->stream, plan.P, (long long)n,
+  // (more than 65534 layers: the clear-air map's 16-bit layer numbers do not reach the top -- the hook reads the bricks without it)
+  hipLaunchKernelGGL(h->nz <= 65534 ? trace_rays_kernel<true> : trace_rays_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, h->stream, plan.P, (long long)n,
                      (const float *)dDir.p, (float *)dPos.p, (int32_t *)dIdx.p, (const float *)dTar.p, (float *)dTau.p,
                      (int32_t *)dSteps.p);
   HIPCHK(h, hipGetLastError());

@@ -210,7 +210,7 @@ struct Reservoir {
   // Fused multi-batch launch: the work counter hands out chunk numbers; a chunk lies within one batch (RunArgs).  `batch` is
   // the batch of the photons in hand (wave-uniform); end < 0 once the launch's chunks have run out or the host has called
   // the launch off (a look-ahead that is not wanted any more ends within one chunk per wave).
-  unsigned batch;
+  unsigned batch = 0u;
   __device__ __forceinline__ void refill_batched() {   // call in uniform control flow only
     const ColdArgs k = cold_args();
     unsigned long long *const counter = k->A.workCounter;
@@ -350,7 +350,11 @@ __global__ void __launch_bounds__(256) slab_fill_kernel(uint32_t seed0, uint32_t
 // TBL (round 3, specialised flux kernels): workgroups of 1024 threads, two per compute unit, that also keep the 40 KB of the
 // inverse table's cosines (one entry) in LDS: the two dependent table reads of a scattering then come from LDS instead of
 // L2 or beyond (+1.6 % on the step cloud, +22 % on Landsat-36; the launch chooses it: i3rc_hip.hip).
-template <class Rng, bool INTENSITY, bool GENERAL, int GRID, bool TBL = false>
+// DIRECT (round 4, radiance kernels, ONE radiance direction): no event ring.  With one direction an event is one ray, and with the
+// roulette most rays end where they are made: the event phase itself turns its event into a ready ray (the EXPAND arithmetic, at
+// the event phase's lane count -- what EXPAND had with a ring that an event phase half fills), only the survivors go to LDS, and
+// the LDS the ring took pays for a ready store of two wavefronts: rays are traced when a wavefront of SURVIVORS has gathered.
+template <class Rng, bool INTENSITY, bool GENERAL, int GRID, bool TBL = false, bool DIRECT = false>
 __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_WAVES) : ((GENERAL || GRID == GRID_BRICKS) ? I3RC_MIN_WAVES : ((Rng::kBatched && !TBL) ? I3RC_FUSED_WAVES : I3RC_FLUX_WAVES))) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
@@ -364,7 +368,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
     if (P.ldsTallies) p += 3 * ncol;
     L.dirCos = p; p += 3 * P.nDir;
     L.queue = p;
-    if (INTENSITY && !Rng::kReplay) p += 4 * (kRecWords * P.rayQueueCap + kReadyWords * kReadyRays);
+    if (INTENSITY && !Rng::kReplay) p += 4 * (kRecWords * P.rayQueueCap + kReadyWords * (DIRECT ? kDirectReady : kReadyRays));
     L.tInt = p;
     if (P.ldsIntensity) p += (P.ncomp + 1) * P.nDir * ncol;
     L.ext = p;
@@ -397,7 +401,11 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
 
   constexpr bool REPLAY = Rng::kReplay;        // per-photon fates are recorded by i3rc_hip_run_replay only
   constexpr bool BATCHED = Rng::kBatched;      // fused multi-batch launch: every lane knows its photon's batch (rng.batch)
-  static_assert(!BATCHED || (!INTENSITY && !GENERAL), "fused multi-batch launches: specialised flux kernels");
+  static_assert(!BATCHED || !GENERAL, "fused multi-batch launches: specialised kernels");
+  // Work counters of a fused launch.  Flux kernels: exact per batch, gathered per lane (below).  Radiance kernels have no
+  // vector register to spare for that: their counters stay per WAVE and are handed to the batch whose photons the wave was
+  // given last -- photons and dropped photons (what the normalisation needs) are exact per batch, the others over the group.
+  constexpr bool LANE_COUNTS = BATCHED && !INTENSITY;
   constexpr bool NEED_PID = REPLAY || GENERAL; // explicit photon sources are indexed by photon number
   const size_t ncell = (size_t)P.nx * P.ny * P.nz;
   const bool rayTracing = GENERAL ? (P.useRayTracing != 0) : true;
@@ -546,12 +554,25 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
 #define I3RC_EXPAND_BATCH 64   /* = the ready buffer: expand when it is empty, a whole wavefront at a time */
 #endif
   constexpr int kExpandBatch = I3RC_EXPAND_BATCH;   // an expand phase runs when the ready buffer has room for this many rays
+  // DIRECT: rays are traced once this many survivors are ready (an event phase adds at most 64 to fewer than that: the store
+  // of 128 never overflows), and the wave goes back to its photons when nothing is left to hand out and fewer than
+  // kDirectLeave rays are still under way (those few go back to the store: with rays of one or two voxel steps, a wave that
+  // left with a wavefront's worth under way -- the ring mode's rule -- would write back and take up again most of its rays)
+#ifndef I3RC_DIRECT_ENTER
+#define I3RC_DIRECT_ENTER 64
+#endif
+#ifndef I3RC_DIRECT_LEAVE
+#define I3RC_DIRECT_LEAVE 24
+#endif
+  constexpr int kDirectEnter = I3RC_DIRECT_ENTER, kDirectLeave = I3RC_DIRECT_LEAVE;
+  static_assert(!DIRECT || (kDirectReady >= kDirectEnter + 64 && (kDirectReady & (kDirectReady - 1)) == 0), "the ready store must take an event phase's rays on top of the entry level");
   constexpr int kLowWater = I3RC_LOW_WATER, kStepAhead = I3RC_STEP_AHEAD, kPhotonStepAhead = I3RC_PHOTON_STEP_AHEAD;
   bool wantSlots = false, photonsLeft = true;         // wave-uniform
   unsigned qTail = 0u, qHeadEv = 0u, qHeadSub = 0u;   // events pushed / events expanded completely / rays expanded of event qHeadEv
   unsigned rdHead = 0u, rdTail = 0u;                  // ready rays taken / made
-  lds_float *const qBase = L.queue + (threadIdx.x >> 6) * (kRecWords * P.rayQueueCap + kReadyWords * kReadyRays);
-  lds_float *const rdBase = qBase + kRecWords * P.rayQueueCap;   // ready rays: word w of slot s at rdBase[w * kReadyRays + s]
+  constexpr int kReady = DIRECT ? kDirectReady : kReadyRays;     // slots of the wave's ready store
+  lds_float *const qBase = L.queue + (threadIdx.x >> 6) * (kRecWords * P.rayQueueCap + kReadyWords * kReady);
+  lds_float *const rdBase = qBase + kRecWords * P.rayQueueCap;   // ready rays: word w of slot s at rdBase[w * kReady + s]
   const unsigned qMask = (unsigned)P.rayQueueCap - 1u;
   const unsigned qMagic = ((1u << 20) + (unsigned)P.nDir - 1u) / (unsigned)(P.nDir > 0 ? P.nDir : 1);   // t / nDir = (t * qMagic) >> 20 for t < nDir + 64 <= 319 (nDir <= 255)
   bool pendingShadow = false;
@@ -591,7 +612,23 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
   auto flush_counters = [&]() {
     adapt_thresholds();
     raysSeen = 0u;
-    if (!BATCHED && (threadIdx.x & 63) == 0) {   // (BATCHED: per lane and batch, see flush_lane)
+    if constexpr (BATCHED && INTENSITY) {   // per wave, to the batch in hand (LANE_COUNTS above)
+      uint32_t draws = rng.take_used();
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) draws += (uint32_t)__shfl_xor((int)draws, off, 64);
+      if ((threadIdx.x & 63) == 0) {
+        double *const c = counter_block(res.batch);
+        const uint32_t v[8] = {wc.steps, wc.scat, wc.surf, wc.top, wc.roul, wc.shadow, wc.scat + wc.surf + wc.top + wc.calls, draws};
+        const int at[8] = {I3RC_CNT_CELL_STEPS, I3RC_CNT_SCATTERINGS, I3RC_CNT_SURFACE_HITS, I3RC_CNT_EXITS_TOP, I3RC_CNT_ROULETTE,
+                           I3RC_CNT_SHADOW_STEPS, I3RC_CNT_TRACER_CALLS, I3RC_CNT_RNG_DRAWS};
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (v[k] != 0u) unsafeAtomicAdd(c + at[k], (double)v[k]);
+        if (raysSkipped != 0u) unsafeAtomicAdd(c + I3RC_CNT_RAYS_SKIPPED, (double)raysSkipped);
+      }
+      raysSkipped = 0u;
+    }
+    if (!BATCHED && (threadIdx.x & 63) == 0) {   // (BATCHED flux kernels: per lane and batch, see flush_lanes)
       const uint32_t c[9] = {wc.photons, wc.dropped, wc.steps, wc.scat, wc.surf, wc.top, wc.roul, wc.shadow, wc.calls};
       const ColdArgs ka = cold_args();
       double *const counters = ka->P.tally + ka->P.oCnt;
@@ -600,6 +637,48 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
         if (c[k] != 0u) unsafeAtomicAdd(counters + k, (double)c[k]);
     }
     wc = WaveCounters();
+  };
+  // One (event, direction) pair -> a ready-made local-estimate ray (:1473-1559): the phase-function factor (acos, table
+  // look-up), the ray's own Philox block (counter: photon, block of its event, direction + 1), free path, roulette stage and
+  // target.  false: the ray is known to contribute nothing and is not traced (below).  Called by the EXPAND phase of ray mode
+  // (the event from the wave's ring) and, in DIRECT kernels, by the event phase itself (the event from registers).
+  // The ray's info word: component | direction << 8 | stage << 16 (0: plain local estimate, 1: small contribution, 2 / 3: the two
+  // legs of a large one) | roulette won << 18 | batch << 19 (fused launches: the batch of the ray's photon, relative to the launch's first).
+  auto make_ray = [&](const auto &Px, const auto &Ax, int info, float inX, float inY, float inZ, uint32_t photonLo, uint32_t photonHi,
+                      uint32_t eventBlock, uint32_t batch, int dIdx, float &word6, float &normOut, float &tauFreeOut, float &targetOut) -> bool {
+    const int comp = info & 0xff;
+    const float uz = L.dirCos[3 * dIdx + 2];
+    float norm;
+    if (comp < 1) norm = 1.0f / kPi;
+    else {
+      float proj = 0.0f;
+      proj += inX * L.dirCos[3 * dIdx]; proj += inY * L.dirCos[3 * dIdx + 1]; proj += inZ * uz;
+      if (fabsf(proj) > 1.0f) proj = copysignf(1.0f, proj);
+      const float ang = acosf(proj);
+      const int pfi = (int)((unsigned)info >> 16);   // (table entries up to 65535: the record's upper half is unsigned)
+      const CompTables ct = GENERAL ? load_tables(Px.comp[comp - 1]) : load_tables(Px.comp0);
+      const float *tab = ((info & 0x100) ? ct.fwdOrig : ct.fwd) + (size_t)(pfi - 1) * ct.nFwd;
+      norm = fast_div(lookup_phase_fast(tab, ct.nFwd, ang), (4.0f * kPi) * fabsf(uz));
+    }
+    int stg = 0;
+    bool won = false;
+    float tauFree = 0.0f, target = 0.0f;
+    if (Px.useRRI) {
+      const Philox4 q4 = philox4x32_10(photonLo, photonHi, eventBlock, (uint32_t)dIdx + 1u, Ax.seed0, BATCHED ? Ax.seed1 + batch : Ax.seed1);
+      rng.count_draws(2u);
+      tauFree = -fast_log(fmaxf(kTiny, u32_to_unit_float(q4.v[0])));
+      // small contribution: it counts -- with the weight of the roulette's bound -- with probability pi normPF / zetaMin
+      // (:1551-1559); the deviate is compared here, the outcome travels as bit 18 of the ray's info word
+      const float r2 = u32_to_unit_float(q4.v[1]);
+      if (kPi * norm <= Px.zetaMin) { stg = 1; won = r2 * Px.zetaMin <= kPi * norm; target = tauFree; }
+      else { stg = 2; target = -fast_log(fast_div(Px.zetaMin, fmaxf(kTiny, kPi * norm))); }   // tauMax
+    }
+    word6 = __int_as_float(comp | (dIdx << 8) | (stg << 16) | (won ? 1 << 18 : 0) | (int)(batch << 19));
+    normOut = norm; tauFreeOut = tauFree; targetOut = target;
+    // A small contribution that has lost its roulette (:1554: the deviate is independent of the path) is 0 whatever
+    // the trace would find: such a ray is not traced at all -- the same estimator, evaluated lazily.  (The
+    // reference traces first and draws afterwards; the replay build keeps that order.)
+    return stg != 1 || won;   // (a small contribution that lost its roulette is dropped; stages 0 and 2 are always traced)
   };
   // a photon's record for i3rc_hip_run_replay; production builds keep no per-photon record
   auto close_photon = [&]() {
@@ -628,9 +707,9 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
     if (DEFER) {
       // ============================================================================================== RAY MODE?
       // enough local-estimate rays to fill the wavefront (or no room for the next event phase, or no photons left)?
-      const int work = (int)((qTail - qHeadEv) * (unsigned)P.nDir - qHeadSub) + (int)(rdTail - rdHead);
+      const int work = DIRECT ? (int)(rdTail - rdHead) : (int)((qTail - qHeadEv) * (unsigned)P.nDir - qHeadSub) + (int)(rdTail - rdHead);
       photonsLeft = __ballot(st != ST_DONE) != 0ull;
-      if (work > 0 && (work >= 64 || !photonsLeft || wantSlots)) {
+      if (work > 0 && (work >= (DIRECT ? kDirectEnter : 64) || !photonsLeft || wantSlots)) {
         wantSlots = false;
         // this lane's shadow ray: registers of the ray loop only (rays still under way when the wave leaves go back to the
         // ready buffer), so that the photon loop's register allocation knows nothing of them and the other way round
@@ -642,12 +721,12 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
         // registers in one set at the head and in another at the latch and copied them to and fro, some forty vector
         // moves in every pass: "Exchanging two register sets")
         for (;;) {
-          for (;;) {
+          if constexpr (!DIRECT) for (;;) {
             const int ringRays0 = (int)((qTail - qHeadEv) * (unsigned)P.nDir - qHeadSub);
             const int ready0 = (int)(rdTail - rdHead);
-            if (!(ringRays0 > 0 && ready0 <= kReadyRays - kExpandBatch)) break;
+            if (!(ringRays0 > 0 && ready0 <= kReady - kExpandBatch)) break;
             // ------------------------------------------------------------ EXPAND phase: (event, direction) -> ready ray
-            const int room = kReadyRays - ready0;
+            const int room = kReady - ready0;
             const int n = ringRays0 < room ? ringRays0 : room;
             const int lane = (int)(threadIdx.x & 63);
             PROF_BEGIN();
@@ -663,52 +742,21 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
               const int dIdx = (int)(t - eOff * (unsigned)Px.nDir);
               const lds_float *rec = qBase + ((qHeadEv + eOff) & qMask);
               const int cap = Px.rayQueueCap;
-              const int info = __float_as_int(rec[10 * cap]);
-              const int comp = info & 0xff;
-              const float uz = L.dirCos[3 * dIdx + 2];
-              float norm;
-              if (comp < 1) norm = 1.0f / kPi;
-              else {
-                float proj = 0.0f;
-                proj += rec[7 * cap] * L.dirCos[3 * dIdx]; proj += rec[8 * cap] * L.dirCos[3 * dIdx + 1]; proj += rec[9 * cap] * uz;
-                if (fabsf(proj) > 1.0f) proj = copysignf(1.0f, proj);
-                const float ang = acosf(proj);
-                const int pfi = (int)((unsigned)info >> 16);   // (table entries up to 65535: the record's upper half is unsigned)
-                const CompTables ct = GENERAL ? load_tables(Px.comp[comp - 1]) : load_tables(Px.comp0);
-                const float *tab = ((info & 0x100) ? ct.fwdOrig : ct.fwd) + (size_t)(pfi - 1) * ct.nFwd;
-                norm = fast_div(lookup_phase_fast(tab, ct.nFwd, ang), (4.0f * kPi) * fabsf(uz));
-              }
-              int stg = 0;
-              float tauFree = 0.0f, target = 0.0f;
-              if (Px.useRRI) {
-                // the ray's own Philox block: counter (photon, block of its event, direction + 1)
-                const Philox4 q4 = philox4x32_10(__float_as_uint(rec[11 * cap]), __float_as_uint(rec[12 * cap]),
-                                                 __float_as_uint(rec[13 * cap]), (uint32_t)dIdx + 1u, Ax.seed0, Ax.seed1);
-                rng.count_draws(2u);
-                tauFree = -fast_log(fmaxf(kTiny, u32_to_unit_float(q4.v[0])));
-                // small contribution: it counts -- with the weight of the roulette's bound -- with probability pi normPF / zetaMin
-                // (:1551-1559); the deviate is compared here, the outcome travels as bit 24 of the ray's info word
-                const float r2 = u32_to_unit_float(q4.v[1]);
-                if (kPi * norm <= Px.zetaMin) { stg = 1 | (r2 * Px.zetaMin <= kPi * norm ? 0x100 : 0); target = tauFree; }
-                else { stg = 2; target = -fast_log(fast_div(Px.zetaMin, fmaxf(kTiny, kPi * norm))); }   // tauMax
-              }
-              // A small contribution that has lost its roulette (:1554: the deviate is independent of the path) is 0 whatever
-              // the trace would find: such a ray is not traced at all -- the same estimator, evaluated lazily.  (The
-              // reference traces first and draws afterwards; the replay build keeps that order.)
-              keep = stg != 1;   // (stg == 1: small contribution, roulette lost; 1 | 0x100: won; 0 and 2: always traced)
-              evWord6 = __int_as_float(comp | (dIdx << 8) | (stg << 16));
-              evNorm = norm; evTauFree = tauFree; evTarget = target;
+              // (fused launches: photon numbers are below 2^32 and the record's twelfth word carries the photon's batch instead)
+              const uint32_t word12 = __float_as_uint(rec[12 * cap]);
+              keep = make_ray(Px, Ax, __float_as_int(rec[10 * cap]), rec[7 * cap], rec[8 * cap], rec[9 * cap], __float_as_uint(rec[11 * cap]),
+                              BATCHED ? 0u : word12, __float_as_uint(rec[13 * cap]), BATCHED ? word12 : 0u, dIdx, evWord6, evNorm, evTauFree, evTarget);
               evRec = rec;
             }
             const unsigned long long keepMask = __ballot(keep);
             if (keep) {
               const int cap = Px.rayQueueCap;
-              lds_float *out = rdBase + ((rdTail + (unsigned)lanes_below(keepMask)) & (unsigned)(kReadyRays - 1));
-              out[0] = evRec[0]; out[kReadyRays] = evRec[cap]; out[2 * kReadyRays] = evRec[2 * cap];
-              out[3 * kReadyRays] = evRec[3 * cap]; out[4 * kReadyRays] = evRec[4 * cap]; out[5 * kReadyRays] = evRec[5 * cap];
-              out[6 * kReadyRays] = evWord6;
-              out[7 * kReadyRays] = evRec[6 * cap];
-              out[8 * kReadyRays] = evNorm; out[9 * kReadyRays] = evTauFree; out[10 * kReadyRays] = evTarget; out[11 * kReadyRays] = 0.0f;
+              lds_float *out = rdBase + ((rdTail + (unsigned)lanes_below(keepMask)) & (unsigned)(kReady - 1));
+              out[0] = evRec[0]; out[kReady] = evRec[cap]; out[2 * kReady] = evRec[2 * cap];
+              out[3 * kReady] = evRec[3 * cap]; out[4 * kReady] = evRec[4 * cap]; out[5 * kReady] = evRec[5 * cap];
+              out[6 * kReady] = evWord6;
+              out[7 * kReady] = evRec[6 * cap];
+              out[8 * kReady] = evNorm; out[9 * kReady] = evTauFree; out[10 * kReady] = evTarget; out[11 * kReady] = 0.0f;
             }
             {   // ring bookkeeping (wave-uniform)
               const unsigned t = qHeadSub + (unsigned)n;
@@ -720,13 +768,15 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
             }
             PROF_END(PH_EXPAND, n);
           }
-          const int ringRays = (int)((qTail - qHeadEv) * (unsigned)P.nDir - qHeadSub);   // rays waiting in the ring, not yet expanded
+          const int ringRays = DIRECT ? 0 : (int)((qTail - qHeadEv) * (unsigned)P.nDir - qHeadSub);   // rays waiting in the ring, not yet expanded
           const int ready = (int)(rdTail - rdHead);                                        // ready-made rays
           const unsigned long long actMask = __ballot(rst == R_TRACE), endMask = __ballot(rst == R_ENDED);
           const int nAct = (int)__popcll(actMask), nIdle = 64 - nAct;
           // with photons still to run, the wave leaves its rays once there is nothing left to hand out and few are under way
           // (no more rays can be made ready at this point: the ring is empty, or the ready buffer is full)
-          const bool leaving = ringRays == 0 && photonsLeft && ready + nAct < kLowWater;   // too few for a wavefront: gather more first
+          // (DIRECT: see kDirectLeave -- nothing left to hand out and only a few rays still under way)
+          const bool leaving = DIRECT ? (photonsLeft && ready == 0 && nAct < kDirectLeave)
+                                      : (ringRays == 0 && photonsLeft && ready + nAct < kLowWater);   // too few for a wavefront: gather more first
           const bool canServe = endMask != 0ull || (!leaving && ready > 0 && nIdle > 0);
           const bool serve = canServe && (nIdle >= liThr || nAct == 0 || leaving);
           if (serve) {
@@ -734,21 +784,23 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
             PROF_BEGIN();
             const ColdArgs kx = cold_args();
             const auto &Px = kx->P;
-            const Tally<ColdProblem> tally{Px, L, nullptr};
             bool secondLeg = false;
             if (rst == R_ENDED) {                                           // the ray that just ended (:1517-1596)
+              double *rayBlk = nullptr;                                     // (fused launches: the tally block of the ray's batch)
+              if constexpr (BATCHED) rayBlk = lane_block((uint32_t)sInfo >> 19);
+              const Tally<ColdProblem, BATCHED> tally{Px, L, rayBlk};
               const float tauB = sr.acc;
               const bool outTop = sr.iz >= Px.nz + 1;
-              const int comp = sInfo & 0xff, dIdx = (sInfo >> 8) & 0xff, stage = (sInfo >> 16) & 0xff;
+              const int comp = sInfo & 0xff, dIdx = (sInfo >> 8) & 0xff, stage = (sInfo >> 16) & 3;
               const float direct = tauB >= 0.0f ? (sW * sNorm) * fast_exp(-tauB) : 0.0f;   // plain local estimate
               const float capped = outTop ? sW * Px.zetaMin * (1.0f / kPi) : 0.0f;          // roulette survivor
               float con = 0.0f;
               if (stage == 0) con = direct;
-              else if (stage == 1) con = (sInfo & (0x100 << 16)) ? capped : 0.0f;
+              else if (stage == 1) con = (sInfo & (1 << 18)) ? capped : 0.0f;
               else if (stage == 2) {
                 if (outTop) con = direct;
                 else if (tauB >= 0.0f && sr.iz >= 1) {                      // second leg, up to the free path (:1576-1587)
-                  sr.acc = 0.0f; sr.target = sTauFree; sInfo = (sInfo & 0xffff) | (3 << 16); rst = R_TRACE; secondLeg = true;
+                  sr.acc = 0.0f; sr.target = sTauFree; sInfo |= 1 << 16; rst = R_TRACE; secondLeg = true;   // (stage 2 -> 3)
                 }
                 // (a first leg that left through the BOTTOM -- a downward radiance direction -- gets no second leg: the
                 // reference starts one from outside the grid, reads zPosition(0) / totalExt(:, :, 0) out of bounds and
@@ -756,7 +808,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
               } else con = capped;
               if (rst == R_ENDED) {
                 if (Px.limitContrib && con > Px.maxContrib) {                // :1598-1609
-                  add_global(Px.tally + Px.oExc + comp * Px.nDir + dIdx, con - Px.maxContrib);
+                  add_global(tally.base() + Px.oExc + comp * Px.nDir + dIdx, con - Px.maxContrib);
                   con = Px.maxContrib;
                 }
                 // (most rays of the roulette end without a contribution: no atomic for adding nothing -- on the radar
@@ -771,12 +823,12 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
             const int take = leaving ? 0 : (nFree < ready ? nFree : ready);   // (a wave about to leave ends its rays but takes no new ones)
             const int rank = lanes_below(freeMask);
             if (rst == R_EMPTY && rank < take) {
-              const lds_float *in = rdBase + ((rdHead + (unsigned)rank) & (unsigned)(kReadyRays - 1));
-              sr.x = in[0]; sr.y = in[kReadyRays]; sr.z = in[2 * kReadyRays];
-              sr.ix = __float_as_int(in[3 * kReadyRays]); sr.iy = __float_as_int(in[4 * kReadyRays]); sr.iz = __float_as_int(in[5 * kReadyRays]);
-              sInfo = __float_as_int(in[6 * kReadyRays]);
-              sW = in[7 * kReadyRays]; sNorm = in[8 * kReadyRays]; sTauFree = in[9 * kReadyRays];
-              sr.target = in[10 * kReadyRays]; sr.acc = in[11 * kReadyRays];
+              const lds_float *in = rdBase + ((rdHead + (unsigned)rank) & (unsigned)(kReady - 1));
+              sr.x = in[0]; sr.y = in[kReady]; sr.z = in[2 * kReady];
+              sr.ix = __float_as_int(in[3 * kReady]); sr.iy = __float_as_int(in[4 * kReady]); sr.iz = __float_as_int(in[5 * kReady]);
+              sInfo = __float_as_int(in[6 * kReady]);
+              sW = in[7 * kReady]; sNorm = in[8 * kReady]; sTauFree = in[9 * kReady];
+              sr.target = in[10 * kReady]; sr.acc = in[11 * kReady];
               const int dIdx = (sInfo >> 8) & 0xff;
               sr.dx = L.dirCos[3 * dIdx]; sr.dy = L.dirCos[3 * dIdx + 1]; sr.dz = L.dirCos[3 * dIdx + 2];
               sr.set_direction(L);
@@ -794,14 +846,14 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
           const unsigned long long backMask = __ballot(rst == R_TRACE);   // (after the service phase, if there was one)
           const int nBack = (int)__popcll(backMask);
           const int readyNow = (int)(rdTail - rdHead);
-          if ((leaving && ready + nBack < kLowWater) || (nBack == 0 && readyNow == 0 && ringRays == 0)) {
+          if ((leaving && (DIRECT || ready + nBack < kLowWater)) || (nBack == 0 && readyNow == 0 && ringRays == 0)) {
             if (rst == R_TRACE) {
-              lds_float *out = rdBase + ((rdTail + (unsigned)lanes_below(backMask)) & (unsigned)(kReadyRays - 1));
-              out[0] = sr.x; out[kReadyRays] = sr.y; out[2 * kReadyRays] = sr.z;
-              out[3 * kReadyRays] = __int_as_float(sr.ix); out[4 * kReadyRays] = __int_as_float(sr.iy); out[5 * kReadyRays] = __int_as_float(sr.iz);
-              out[6 * kReadyRays] = __int_as_float(sInfo);
-              out[7 * kReadyRays] = sW; out[8 * kReadyRays] = sNorm; out[9 * kReadyRays] = sTauFree;
-              out[10 * kReadyRays] = sr.target; out[11 * kReadyRays] = sr.acc;
+              lds_float *out = rdBase + ((rdTail + (unsigned)lanes_below(backMask)) & (unsigned)(kReady - 1));
+              out[0] = sr.x; out[kReady] = sr.y; out[2 * kReady] = sr.z;
+              out[3 * kReady] = __int_as_float(sr.ix); out[4 * kReady] = __int_as_float(sr.iy); out[5 * kReady] = __int_as_float(sr.iz);
+              out[6 * kReady] = __int_as_float(sInfo);
+              out[7 * kReady] = sW; out[8 * kReady] = sNorm; out[9 * kReady] = sTauFree;
+              out[10 * kReady] = sr.target; out[11 * kReady] = sr.acc;
             }
             rdTail += (unsigned)nBack;
             wc.calls -= (unsigned)nBack;      // (they are counted again when they are taken up: one tracer call each, whatever the schedule)
@@ -817,7 +869,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
             wc.shadow += nTracing;
             PROF_BEGIN();
             if (tracing) {   // a failed shadow ray contributes nothing (:1531-1535: its optical path is -2)
-              if (trace_step<GRID>(P, L, sr, (sInfo >> 16) != 0) != STEP_CONTINUE) rst = R_ENDED;
+              if (trace_step<GRID>(P, L, sr, ((sInfo >> 16) & 3) != 0) != STEP_CONTINUE) rst = R_ENDED;
             }
             PROF_END(PH_RAYSTEP, nTracing);
           };
@@ -855,7 +907,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
     const bool doTurn = nTu >= kTurnMin || trMask == 0ull || nSc == 0;
     const bool wantEvent = wantScat || (doTurn && wantTurn);
     const unsigned long long evMask = __ballot(wantEvent);            // the lanes this event phase serves
-    if (DEFER && runEvent && (int)(P.rayQueueCap - (int)(qTail - qHeadEv)) < nSc) {
+    if (DEFER && runEvent && (DIRECT ? kReady - (int)(rdTail - rdHead) : (int)(P.rayQueueCap - (int)(qTail - qHeadEv))) < nSc) {
       // every lane of the event phase may push one record: without room for all of them the rays are served first
       wantSlots = true;
       runEvent = false;
@@ -869,8 +921,9 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
       const ColdArgs ke = cold_args();
       const auto &Pe = ke->P;
       const auto &Ae = ke->A;
-      if constexpr (BATCHED) {   // a 16-bit count about to overflow (one event adds at most one to each): hand over now
-        const bool full = ((accA | accB) & 0x80008000u) != 0u || accSteps >= 0x80000000u;
+      if constexpr (LANE_COUNTS) {   // a 16-bit count about to overflow (one event adds at most one to each): hand over now
+        // (steps: a hand-over sums the lanes' counts across the wave in 32 bits -- 64 lanes of less than 2^25 each)
+        const bool full = ((accA | accB) & 0x80008000u) != 0u || accSteps >= (1u << 25);
         if (__ballot(full) != 0ull) flush_lanes(full);
       }
       double *laneBlk = nullptr;
@@ -889,7 +942,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
       wc.top += count_lanes(atTop);
       wc.surf += count_lanes(atSurface);
       if constexpr (BATCHED) {
-        accB += (atSurface ? 1u : 0u) + (atTop ? 0x10000u : 0u);
+        if constexpr (LANE_COUNTS) accB += (atSurface ? 1u : 0u) + (atTop ? 0x10000u : 0u);
         if (dropped) {
           double *const c = counter_block(rng.batch);
           unsafeAtomicAdd(c + I3RC_CNT_DROPPED, 1.0);
@@ -940,8 +993,10 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
             if (res.end < 0 || res.batch != oldBatch) hand_over_taken(oldBatch);
           }
           // a lane whose next photon belongs to another batch hands over what it has counted for the batch it leaves
-          const bool leaves = isNew && mine >= 0 && mineBatch != rng.batch && (accSteps | accA | accB | rng.used) != 0u;
-          if (__ballot(leaves) != 0ull) flush_lanes(leaves);
+          if constexpr (LANE_COUNTS) {
+            const bool leaves = isNew && mine >= 0 && mineBatch != rng.batch && (accSteps | accA | accB | rng.used) != 0u;
+            if (__ballot(leaves) != 0ull) flush_lanes(leaves);
+          }
           if (isNew) {
             if (mine < 0) st = ST_DONE;   // (only when the launch has no chunks left)
             else rng.start((uint64_t)(Ae.firstPhoton + mine), mineBatch);
@@ -1145,6 +1200,27 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
         // a photon that died in part C (roulette, absorbing surface) is closed here and respawns at the next event phase
         if (st == ST_NEW) close_photon();
       }
+      if constexpr (DIRECT) {   // one radiance direction: the event becomes a ready ray here and now (make_ray), survivors only go to LDS
+        if (defer) {
+          bool keep = false;
+          float word6 = 0.0f, norm = 0.0f, tauFree = 0.0f, target = 0.0f;
+          if (pendingShadow)
+            keep = make_ray(Pe, Ae, evInfo, inDx, inDy, inDz, rng.photon_lo(), rng.photon_hi(), rng.event_block(), rng.lane_batch(), 0, word6, norm, tauFree, target);
+          const unsigned long long madeMask = __ballot(pendingShadow), keepMask = __ballot(keep);
+          if (keep) {
+            lds_float *out = rdBase + ((rdTail + (unsigned)lanes_below(keepMask)) & (unsigned)(kReady - 1));
+            out[0] = r.x; out[kReady] = r.y; out[2 * kReady] = r.z;
+            out[3 * kReady] = __int_as_float(r.ix); out[4 * kReady] = __int_as_float(r.iy); out[5 * kReady] = __int_as_float(r.iz);
+            out[6 * kReady] = word6;
+            out[7 * kReady] = wI;
+            out[8 * kReady] = norm; out[9 * kReady] = tauFree; out[10 * kReady] = target; out[11 * kReady] = 0.0f;
+          }
+          pendingShadow = false;
+          const unsigned kept = (unsigned)__popcll(keepMask);
+          rdTail += kept;
+          raysSkipped += (unsigned)__popcll(madeMask) - kept;
+        }
+      } else
       if (defer) {   // push the events of this phase into the wave's ring: one record serves all D rays of an event
         const unsigned long long pushMask = __ballot(pendingShadow);
         if (pendingShadow) {
@@ -1155,16 +1231,16 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
           rec[6 * cap] = wI;
           rec[7 * cap] = inDx; rec[8 * cap] = inDy; rec[9 * cap] = inDz;
           rec[10 * cap] = __int_as_float(evInfo);
-          rec[11 * cap] = __uint_as_float(rng.photon_lo()); rec[12 * cap] = __uint_as_float(rng.photon_hi());
+          rec[11 * cap] = __uint_as_float(rng.photon_lo()); rec[12 * cap] = __uint_as_float(BATCHED ? rng.lane_batch() : rng.photon_hi());
           rec[13 * cap] = __uint_as_float(rng.event_block());
           pendingShadow = false;
         }
         qTail += (unsigned)__popcll(pushMask);
       }
-      if constexpr (BATCHED) accA += (didScatter ? 1u : 0u) + (didRoulette ? 0x10000u : 0u);
+      if constexpr (LANE_COUNTS) accA += (didScatter ? 1u : 0u) + (didRoulette ? 0x10000u : 0u);
       wc.scat += count_lanes(didScatter);
       wc.roul += count_lanes(didRoulette);
-      wc.calls += count_lanes(startedTrace);
+      if constexpr (!BATCHED) wc.calls += count_lanes(startedTrace);   // (BATCHED: a batch's photon traces = its scatterings + surface arrivals + exits + drops)
       PROF_END(PH_EVENT, __popcll(evMask));
     }
     // -------------------------------------------------------------- VOXEL-STEP phase (photons)
@@ -1176,7 +1252,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
       wc.steps += nTracing;
       PROF_BEGIN();
       if (tracing) {
-        if constexpr (BATCHED) accSteps++;
+        if constexpr (LANE_COUNTS) accSteps++;
         const StepResult s = trace_step<GRID, !INTENSITY>(P, L, r, true);
         // (an exit through the top, or onto a black surface, ends the photon: such lanes wait for the turnover quorum)
         if (s != STEP_CONTINUE)
@@ -1202,7 +1278,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
 
   // ------------------------------------------------------------------ epilogue: flush tallies + counters
   if constexpr (BATCHED) {   // what the lanes still hold for their last batches; the tallies themselves are in global memory already
-    flush_lanes(true);
+    if constexpr (LANE_COUNTS) flush_lanes(true); else flush_counters();
     hand_over_taken(res.batch);
     return;
   }
@@ -1243,6 +1319,8 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
 }
 
 // Test hook: independent tracer calls, one ray per thread.
+// (CLEARMAP = false: domains of more than 65534 layers, whose clear-air map -- 16 bits per bound -- is not used: i3rc_hip.hip)
+template <bool CLEARMAP>
 __global__ void __launch_bounds__(256) trace_rays_kernel(const DevProblem P, long long n, const float *dir, float *pos,
                                                          int32_t *idx, const float *target, float *tau, int32_t *steps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1267,7 +1345,7 @@ __global__ void __launch_bounds__(256) trace_rays_kernel(const DevProblem P, lon
   r.target = target[i];
   int ns = 0;
   StepResult s;
-  do { ns++; s = trace_step<GRID_BRICKS, true>(P, L, r, hasTarget); } while (s == STEP_CONTINUE && ns < (1 << 24));
+  do { ns++; s = trace_step<GRID_BRICKS, CLEARMAP>(P, L, r, hasTarget); } while (s == STEP_CONTINUE && ns < (1 << 24));
   pos[3 * i] = r.x; pos[3 * i + 1] = r.y; pos[3 * i + 2] = r.z;
   idx[3 * i] = r.ix; idx[3 * i + 1] = r.iy; idx[3 * i + 2] = r.iz;
   tau[i] = r.acc;

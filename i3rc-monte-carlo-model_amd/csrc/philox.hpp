@@ -13,15 +13,26 @@ namespace i3rc {
 
 struct Philox4 { uint32_t v[4]; };
 
-__host__ __device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                                 uint32_t k0, uint32_t k1) {
+// A round is two 32 x 32 -> 64-bit multiplies (v_mad_u64_u32) and two three-input exclusive ors: gfx950's v_bitop3_b32 (any
+// three-input bitwise function, truth table 0x96 = a ^ b ^ c) does `hi ^ counter ^ key` in ONE instruction where the compiler
+// emits two v_xor_b32 -- four vector instructions a round instead of six, the same bits.
+#ifndef I3RC_PHILOX_ROUNDS
+#define I3RC_PHILOX_ROUNDS 10   /* (measurement knob: tools/README.md "Philox rounds"; the tests pin 10) */
+#endif
+#ifdef I3RC_PHILOX_PLAIN_XOR   /* (measurement knob: the round as the compiler emits it from a ^ b ^ c) */
+__device__ inline uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
+#else
+__device__ inline uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+#endif
+__device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                        uint32_t k0, uint32_t k1) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < I3RC_PHILOX_ROUNDS; ++r) {
     const uint64_t p0 = (uint64_t)M0 * c0;
     const uint64_t p1 = (uint64_t)M1 * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
+    const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
     c1 = (uint32_t)p1;
     c3 = (uint32_t)p0;
     c0 = n0;
@@ -85,6 +96,7 @@ struct PhiloxStreamT {
   __device__ inline uint32_t photon_lo() const { return id_lo; }
   __device__ inline uint32_t photon_hi() const { return id_hi; }
   __device__ inline uint32_t event_block() const { return block - 1u; }
+  __device__ inline uint32_t lane_batch() const { return BATCHED ? batch : 0u; }   // fused launches: batch of this lane's photon
   __device__ inline uint32_t draws_of_photon() const { return 0u; }   // per-photon records are a replay-stream feature
   // deviates consumed by this lane so far (kernel epilogue)
   __device__ inline uint32_t total() const { return used; }
@@ -156,6 +168,7 @@ struct ReplayStream {
   __device__ inline uint32_t photon_lo() const { return 0u; }   // (the replay build keeps the nested local estimate)
   __device__ inline uint32_t photon_hi() const { return 0u; }
   __device__ inline uint32_t event_block() const { return 0u; }
+  __device__ inline uint32_t lane_batch() const { return 0u; }
   __device__ inline float next() {
     // a photon that parts from the reference's path (1-ulp differences of log / cos / ...) may ask for more deviates
     // than were recorded: past the end the recorded ones are used again from the start (a constant would be

@@ -125,6 +125,10 @@ constexpr int kRecWords = 14;   // x y z | ix iy iz | weight | incoming directio
 // ... and one ready-made shadow ray of the wave's ready buffer (kReadyRays of them, one expand phase's worth)
 constexpr int kReadyWords = 12;  // x y z | ix iy iz | component, direction, stage | weight | phase-function factor | free path | target | optical path so far
 constexpr int kReadyRays = 64;
+#ifndef I3RC_DIRECT_READY
+#define I3RC_DIRECT_READY 128
+#endif
+constexpr int kDirectReady = I3RC_DIRECT_READY;   // ... of the one-direction radiance kernels, which have no event ring (photon_kernel, DIRECT): a power of two >= 128
 constexpr int kCounterReplicas = 64;   // fused multi-batch launches: copies of a batch's counter block (RunArgs::counterBlocks)
 
 // Fortran SPACING() for real(4)

@@ -433,6 +433,34 @@ class Integrator:
                                                    C.byref(s), int(inFlight), raw.ctypes.data_as(B.dp)), "computeRadiativeTransfer")
         return [self.finish(raw[k]) for k in range(int(numBatches))]
 
+    def computeRadiativeTransferBatchMoments(self, seed, numBatches, solarMu, solarAzimuth, numberOfPhotons):
+        """A driver's batch loop with its statistics gathered on the device (i3rc_hip_run_batches_moments): the sums and sums of
+        squares over the batches of everything reportResults hands out (monteCarloDriver.f95:300-321), as two dicts of arrays in
+        reportResults' shapes, plus the work counters summed over the batches.  No per-batch block comes back to the host."""
+        if not self.isReady_Integrator():
+            raise I3RCError("computeRadiativeTransfer: problem not completely specified.")
+        self._ensure_tables()
+        lay = B.MomentsLayout()
+        self._check(self._lib.i3rc_hip_get_moments_layout(self._h, C.byref(lay)), "computeRadiativeTransfer")
+        s1, s2, cnt = np.zeros(lay.total, np.float64), np.zeros(lay.total, np.float64), np.zeros(B.NUM_COUNTERS, np.float64)
+        s = B.Source()
+        s.kind, s.solarMu, s.solarAzimuth = 0, solarMu, solarAzimuth
+        self._check(self._lib.i3rc_hip_run_batches_moments(self._h, int(seed[0]), int(seed[1]), int(numBatches), int(numberOfPhotons), C.byref(s),
+                                                           s1.ctypes.data_as(B.dp), s2.ctypes.data_as(B.dp), cnt.ctypes.data_as(B.dp)), "computeRadiativeTransfer")
+        nd, ncol = len(self.intensityDirections), self.nx * self.ny
+
+        def unpack(m):
+            out = dict(fluxUp=m[lay.fluxUp:lay.fluxUp + ncol].reshape(self.ny, self.nx), fluxDown=m[lay.fluxDown:lay.fluxDown + ncol].reshape(self.ny, self.nx),
+                       fluxAbsorbed=m[lay.fluxAbsorbed:lay.fluxAbsorbed + ncol].reshape(self.ny, self.nx),
+                       volumeAbsorption=m[lay.volumeAbsorption:lay.volumeAbsorption + ncol * self.nz].reshape(self.nz, self.ny, self.nx),
+                       absorbedProfile=m[lay.absorbedProfile:lay.absorbedProfile + self.nz], meanFluxUp=m[lay.meanFluxUp],
+                       meanFluxDown=m[lay.meanFluxDown], meanFluxAbsorbed=m[lay.meanFluxAbsorbed])
+            if nd:
+                out["intensity"] = m[lay.intensity:lay.intensity + nd * ncol].reshape(nd, self.ny, self.nx)
+                out["meanIntensity"] = m[lay.meanIntensity:lay.meanIntensity + nd]
+            return out
+        return unpack(s1), unpack(s2), {k: float(cnt[i]) for i, k in enumerate(B.COUNTER_NAMES)}
+
     def set_batch_fusion(self, mode):
         """-1: automatic (default), 0: every batch a launch of its own, 1: fuse a loop's batches into one grid whenever the
         problem allows (i3rc_hip_set_batch_fusion)."""
@@ -473,7 +501,7 @@ class Integrator:
         return out
 
     # -- test hooks
-    KERNELS = {"auto": 0, "general": 1, "lane": 2}
+    KERNELS = {"auto": 0, "general": 1, "lane": 2, "ring": 3}
 
     def set_tuning(self, evThreshold=0, blocksPerCU=0, forceGeneral=None, kernel=None, lightThreshold=None):
         """Experiment knobs of the C ABI (i3rc_hip_set_tuning / i3rc_hip_select_kernel); kernel is one of KERNELS."""

@@ -178,6 +178,32 @@ int i3rc_hip_launch_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1
 int i3rc_hip_run_batches(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int nBatches, int64_t nPhotons,
                          const i3rc_source *src, int inFlight, double *hostTallies);
 
+/* Layout (in float64 elements) of a block of batch moments (i3rc_hip_run_batches_moments): the quantities reportResults (:711-826)
+ * hands out, in its shapes. */
+typedef struct i3rc_moments_layout {
+  int64_t fluxUp, fluxDown, fluxAbsorbed;                /* nx*ny each ([ny][nx])                       */
+  int64_t volumeAbsorption;                              /* nx*ny*nz ([nz][ny][nx])                     */
+  int64_t intensity;                                     /* nDir*nx*ny ([nDir][ny][nx])                 */
+  int64_t absorbedProfile;                               /* nz         (:780)                           */
+  int64_t meanFluxUp, meanFluxDown, meanFluxAbsorbed;    /* 1 each     (:739-742)                       */
+  int64_t meanIntensity;                                 /* nDir                                        */
+  int64_t total;
+} i3rc_moments_layout;
+int i3rc_hip_get_moments_layout(const i3rc_hip_integrator *h, i3rc_moments_layout *layout);
+
+/* A driver's batch loop with its STATISTICS gathered on the device.  The reference's drivers keep, of every batch, only the
+ * first two moments of what reportResults returns (Example-Drivers/monteCarloDriver.f95:300-321: stats(1) += x, stats(2) += x**2
+ * for the domain means, the pixel fluxes, the absorption profile and volume, the radiances; reduced over processes at :333-352,
+ * turned into mean and standard error at :358-378).  This call traces batches k = 0 .. nBatches-1 exactly as i3rc_hip_run_batches
+ * does (keys (seed0, seed1 + k), fused groups where the problem allows), normalises every batch's block ON THE DEVICE as
+ * i3rc_hip_normalise does (:327-395, float64, rounded to the reference's real(4)) and adds x and x*x per element -- and per
+ * domain mean / profile layer / mean radiance -- to two blocks of the layout above, in float64: sum[e] = sum over the batches
+ * of x_k[e], sumSquares[e] likewise of x_k[e]^2.  Only those two blocks come back (and, optionally, the work counters summed
+ * over the batches, I3RC_NUM_COUNTERS values): the per-batch tally blocks -- 5 MB per batch for a 128 x 128 x 36 domain --
+ * are never copied to the host.  Directional sources only.  Synchronous. */
+int i3rc_hip_run_batches_moments(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int nBatches, int64_t nPhotons,
+                                 const i3rc_source *src, double *sum, double *sumSquares, double *counters);
+
 /* computeRadiativeTransfer (:262-398) for ONE batch of a driver's loop -- i3rc_hip_zero_tallies + i3rc_hip_launch_batch(seed0,
  * seed1, 0, nPhotons) + i3rc_hip_fetch_tallies into hostTallies, in a tally buffer and on a stream of the library's own --
  * that LOOKS AHEAD: the reference's drivers call computeRadiativeTransfer once per batch with
@@ -274,8 +300,10 @@ int i3rc_hip_set_batch_fusion(i3rc_hip_integrator *h, int mode);
  * problem class (regular x / y grid, ray tracing, one component, no BRDF grid, Directional source) when the problem is
  * in it, else the general kernel.  All kernels trace the same photon paths from the same per-photon random streams,
  * so tests run one against the other.
- *   GENERAL: always the general kernel;  LANE: same choice as AUTO. */
-enum { I3RC_KERNEL_AUTO = 0, I3RC_KERNEL_GENERAL = 1, I3RC_KERNEL_LANE = 2 };
+ *   GENERAL: always the general kernel;  LANE: same choice as AUTO;  RING: as AUTO, but a radiance problem with ONE
+ *   direction goes through the event ring like any other (AUTO gives such problems the kernels without a ring, in which
+ *   the event phase itself makes the event's ray ready and a ready store of two wavefronts gathers the survivors). */
+enum { I3RC_KERNEL_AUTO = 0, I3RC_KERNEL_GENERAL = 1, I3RC_KERNEL_LANE = 2, I3RC_KERNEL_RING = 3 };
 int i3rc_hip_select_kernel(i3rc_hip_integrator *h, int variant);
 /* = i3rc_hip_select_kernel(h, on ? I3RC_KERNEL_GENERAL : I3RC_KERNEL_AUTO) */
 int i3rc_hip_force_general_kernel(i3rc_hip_integrator *h, int on);

@@ -65,7 +65,7 @@ def test_steps_in_flight_on_one_gpu():
     assert abs(j["roofline"]["reference_equivalent"]["achieved"] - j["roofline"]["achieved"]) < 1e-6 * j["roofline"]["achieved"]
 
 
-@pytest.mark.parametrize("config,kernel", [("radar64_nadir", "photon_kernel<PhiloxStream, true, false, GRID_GLOBAL>"),
+@pytest.mark.parametrize("config,kernel", [("radar64_nadir", "photon_kernel<PhiloxStream, true, false, GRID_GLOBAL, one direction>"),
                                            ("landsat36", "photon_kernel<PhiloxStream, false, false, GRID_GLOBAL, table in LDS>"),
                                            ("landsat119_7dir", "photon_kernel<PhiloxStream, true, false, GRID_BRICKS>")])
 def test_other_baseline_workloads(config, kernel):

@@ -375,17 +375,24 @@ def test_results_do_not_depend_on_the_schedule(oracle):
     # wave-uniform flag once made shadow rays depend on which other lanes were active (tests/test_build_isa.py).
     rad = dict(intensityMus=[1.0, 0.5], intensityPhis=[0.0, 40.0], useRussianRouletteForIntensity=True, zetaMin=0.3)
     keys = ("cellSteps", "scatterings", "surfaceHits", "exitsTop", "roulette", "shadowSteps", "tracerCalls")
+    # (one direction: the kernels without an event ring -- the event phase makes its event's ray ready itself --, against the ring)
+    rad1 = dict(intensityMus=[0.8], intensityPhis=[200.0], useRussianRouletteForIntensity=True, zetaMin=0.3, surfaceAlbedo=0.2)
     tunings = [dict(evThreshold=8), dict(evThreshold=44), dict(evThreshold=0), dict(evThreshold=24, blocksPerCU=1),
-               dict(evThreshold=24, forceGeneral=True), dict(evThreshold=24, lightThreshold=8)]
+               dict(evThreshold=24, forceGeneral=True), dict(evThreshold=24, lightThreshold=8), dict(evThreshold=24, kernel="ring"),
+               dict(evThreshold=60, lightThreshold=40)]
     for name, d in (("landsat", cases.landsat_cloud(ssa=0.99)), ("radar", cases.radar_cloud())):
-        for params in ({}, rad, dict(rad, useRayTracing=False)):
-            seen = []
+        for params in ({}, rad, rad1, dict(rad1, useRussianRouletteForIntensity=False), dict(rad, useRayTracing=False)):
+            seen, fields = [], []
             for tune in tunings:
                 g = make_gpu(d, hg_table(0.85, 299), **params)
                 g.set_tuning(**tune)
                 r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 1)), M.new_PhotonStream(0.7, 25.0, 100000))
                 seen.append({k: r["counters"][k] for k in keys})
+                if "intensity" in r:   # ... and the radiance field itself, to the order of the additions
+                    fields.append(r["intensity"].astype(np.float64))
             assert all(c == seen[0] for c in seen), (name, params, seen)
+            for f in fields[1:]:
+                assert abs(f.mean() - fields[0].mean()) <= 1e-5 * fields[0].mean() and np.abs(f - fields[0]).max() <= 2e-3 * fields[0].max(), (name, params)
     # features only the general kernel has: two components, irregular grid, BRDF grid, hybrid phase function + limit
     t2 = [M.PhaseFunctionTable([M.henyey_greenstein(0.85, 32), M.henyey_greenstein(0.6, 16)]),
           M.PhaseFunctionTable([M.PhaseFunction(legendre=np.array([0.0, 0.1], np.float32))])]

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 import i3rc_monte_carlo_model_amd as M
+from i3rc_monte_carlo_model_amd import binding as B
 from tests import cases
 from tests.philox_ref import philox4x32_10
 
@@ -566,8 +567,10 @@ def test_looking_ahead_never_changes_a_batch():
     def both(seed, n, mu0=0.8, az=25.0, look=3):
         a = plain.computeRadiativeTransfer(M.new_RandomNumberSequence(seed), M.new_PhotonStream(mu0, az, n))
         b = ahead.computeRadiativeTransferLookingAhead(M.new_RandomNumberSequence(seed), M.new_PhotonStream(mu0, az, n), lookAhead=look)
-        assert a["counters"] == b["counters"], (seed, n)
-        assert np.allclose(a["raw"], b["raw"], rtol=1e-5, atol=1e-6)
+        # (since round 4 a radiance problem's batches are looked ahead in fused groups as well: photons and dropped photons are
+        # counted per batch, the radiance kernels' other counters per group -- _same_batches)
+        assert all(a["counters"][k] == b["counters"][k] for k in ("photons", "dropped")), (seed, n)
+        assert np.allclose(_tallies_only(plain, a), _tallies_only(ahead, b), rtol=1e-5, atol=1e-6), (seed, n)
 
     both((7, 0), 1)                                     # the drivers' one-photon warm-up
     for b in range(1, 9):
@@ -591,11 +594,28 @@ def test_looking_ahead_never_changes_a_batch():
     plain.finalize_Integrator(); ahead.finalize_Integrator()
 
 
-def _same_batches(one, many, what):
+def _tallies_only(g, r):
+    """The raw tally block without its counter words."""
+    lay = g.layout()
+    return np.delete(r["raw"], np.s_[lay.counters:lay.counters + B.NUM_COUNTERS])
+
+
+def _same_batches(one, many, what, g=None):
+    """Batch by batch: the same photons traced.  Flux problems: every integer work counter identical per batch.  Radiance
+    problems in a fused launch (g given): the radiance kernels count per wave and hand their counts to the batch a wave was
+    given last -- photons and dropped photons (what the normalisation needs) are exact per batch, the other counters over the
+    batches together; the tallies are per batch either way."""
     assert len(one) == len(many), what
     for b, (a, f) in enumerate(zip(one, many)):
-        assert a["counters"] == f["counters"], (what, b, {k: (a["counters"][k], f["counters"][k]) for k in a["counters"] if a["counters"][k] != f["counters"][k]})
-        assert np.allclose(a["raw"], f["raw"], rtol=1e-5, atol=1e-6), (what, b)
+        if g is None:
+            assert a["counters"] == f["counters"], (what, b, {k: (a["counters"][k], f["counters"][k]) for k in a["counters"] if a["counters"][k] != f["counters"][k]})
+            assert np.allclose(a["raw"], f["raw"], rtol=1e-5, atol=1e-6), (what, b)
+        else:
+            assert all(a["counters"][k] == f["counters"][k] for k in ("photons", "dropped")), (what, b, a["counters"], f["counters"])
+            assert np.allclose(_tallies_only(g, a), _tallies_only(g, f), rtol=1e-5, atol=1e-6), (what, b)
+    if g is not None:
+        for k in one[0]["counters"]:
+            assert sum(r["counters"][k] for r in one) == sum(r["counters"][k] for r in many), (what, k)
 
 
 def test_fused_batches_equal_one_launch_per_batch():
@@ -604,12 +624,22 @@ def test_fused_batches_equal_one_launch_per_batch():
     of its own gives it -- integer work counters identical, tallies equal to the order of the additions -- whatever the
     batch size (shorter than a wavefront, not a multiple of a chunk, one batch only), with absorption (volume tallies), a
     reflecting surface, a slant sun, for the extinction grid in LDS, in global memory and in bricks."""
+    # (round 4) ... and for radiance problems: a local-estimate ray carries its batch, radiances go to the batch's block -- with
+    # the roulette, hybrid tables and the contribution limit, through the event ring (several directions) and without it (one)
+    rri = dict(useRussianRouletteForIntensity=True, zetaMin=0.3)
+    full = dict(rri, intensityMus=[1.0, 0.4, 0.7], intensityPhis=[0.0, 80.0, 250.0], surfaceAlbedo=0.3, useHybridPhaseFunsForIntenCalcs=True,
+                hybridPhaseFunWidth=7.0, numOrdersOrigPhaseFunIntenCalcs=1, limitIntensityContributions=True, maxIntensityContribution=0.4)
     problems = [("step cloud, absorbing, surface", cases.step_cloud(ssa=0.9), dict(surfaceAlbedo=0.3), 0.7, [(20000, 7), (50, 5), (1000, 1), (777, 33)]),
                 ("step cloud, conservative", cases.step_cloud(nlayers=16), dict(), 1.0, [(30011, 12)]),
                 ("radar field (grid in global memory)", cases.radar_cloud(), dict(surfaceAlbedo=0.1), 0.9, [(20000, 5)]),
-                ("Landsat field (bricks), absorbing", cases.landsat_cloud(ssa=0.98), dict(), 0.5, [(15000, 3)])]
+                ("Landsat field (bricks), absorbing", cases.landsat_cloud(ssa=0.98), dict(), 0.5, [(15000, 3)]),
+                ("step cloud, three radiances, hybrid tables, limit", cases.step_cloud(ssa=0.95, nlayers=8), full, 0.7, [(20000, 7), (50, 5), (777, 33)]),
+                ("step cloud, nadir radiance, plain local estimate", cases.step_cloud(ssa=0.95, nlayers=8), dict(intensityMus=[1.0], intensityPhis=[0.0], surfaceAlbedo=0.2), 0.7, [(20000, 7), (60, 9)]),
+                ("radar field, nadir radiance (one direction: no ring)", cases.radar_cloud(), dict(rri, intensityMus=[1.0], intensityPhis=[0.0], surfaceAlbedo=0.1), 0.9, [(20000, 5), (3000, 24)]),
+                ("Landsat field (bricks), two radiances", cases.landsat_cloud(ssa=0.98), dict(rri, intensityMus=[0.8, 0.3], intensityPhis=[90.0, 225.0], surfaceAlbedo=0.2), 0.5, [(15000, 3)])]
     for what, d, params, mu0, runs in problems:
         g = make_gpu(d, hg_table(), **params)
+        rad = g if "intensityMus" in params else None
         for n, nb in runs:
             g.set_batch_fusion(0)
             one = g.computeRadiativeTransferBatches((5, 3), nb, mu0, 25.0, n)
@@ -617,31 +647,45 @@ def test_fused_batches_equal_one_launch_per_batch():
             g.set_batch_fusion(1)
             fused = g.computeRadiativeTransferBatches((5, 3), nb, mu0, 25.0, n)
             assert "PhiloxBatchStream" in g.kernel_name(), g.kernel_name()
-            _same_batches(one, fused, (what, n, nb))
+            _same_batches(one, fused, (what, n, nb), rad)
             plain = g.computeRadiativeTransfer(M.new_RandomNumberSequence((5, 3 + nb - 1)), M.new_PhotonStream(mu0, 25.0, n))
-            _same_batches([plain], [fused[-1]], (what, n, nb, "plain call"))
+            _same_batches([plain], [one[-1]], (what, n, nb, "plain call"))
+            if rad is None: _same_batches([plain], [fused[-1]], (what, n, nb, "plain call, fused"))
             assert all(r["counters"]["photons"] == n for r in fused)
         g.finalize_Integrator()
 
 
 def test_fused_groups_and_chunks_do_not_matter(monkeypatch):
     """Group size (batches per fused launch) and chunk size (photons a wave takes from one batch at a time) only schedule
-    work: the same batches come out, whether the loop is one launch or many, the chunks long or short."""
+    work: the same batches come out, whether the loop is one launch or many, the chunks long or short -- for a flux problem
+    (every counter per batch) and for a radiance problem (tallies, photons and dropped photons per batch; the radiance kernels'
+    other counters over the loop: _same_batches)."""
     import subprocess, sys, json, os
     code = ("import sys, json, numpy as np; sys.path.insert(0, %r)\n"
             "import i3rc_monte_carlo_model_amd as M\nfrom tests import cases\nfrom tests.test_gpu_parity import make_gpu, hg_table\n"
-            "g = make_gpu(cases.step_cloud(ssa=0.95), hg_table(), surfaceAlbedo=0.2)\ng.set_batch_fusion(1)\n"
-            "r = g.computeRadiativeTransferBatches((9, 1), 21, 0.8, 10.0, 4000)\n"
-            "print(json.dumps([[x['counters'], [float(v) for v in x['raw']]] for x in r]))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            "out = []\n"
+            "for params in (dict(surfaceAlbedo=0.2), dict(surfaceAlbedo=0.2, intensityMus=[1.0, 0.5], intensityPhis=[0.0, 70.0], useRussianRouletteForIntensity=True, zetaMin=0.3)):\n"
+            "    g = make_gpu(cases.step_cloud(ssa=0.95), hg_table(), **params)\n    g.set_batch_fusion(1)\n"
+            "    r = g.computeRadiativeTransferBatches((9, 1), 21, 0.8, 10.0, 4000)\n"
+            "    assert 'PhiloxBatchStream' in g.kernel_name()\n"
+            "    out.append([int(g.layout().counters), [[x['counters'], [float(v) for v in x['raw']]] for x in r]])\n"
+            "print(json.dumps(out))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for env in ({}, {"I3RC_FUSED_GROUP_PHOTONS": "9000", "I3RC_FUSED_CHUNK": "64"}, {"I3RC_FUSED_GROUP_PHOTONS": "30000", "I3RC_FUSED_CHUNK": "4096"}):
         p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
     for other in outs[1:]:
-        for (c0, r0), (c1, r1) in zip(outs[0], other):
-            assert c0 == c1
-            assert np.allclose(r0, r1, rtol=1e-5, atol=1e-6)
+        for problem, ((cnt0, base), (cnt1, run)) in enumerate(zip(outs[0], other)):
+            for (c0, r0), (c1, r1) in zip(base, run):
+                if problem == 0:
+                    assert c0 == c1
+                    assert np.allclose(r0, r1, rtol=1e-5, atol=1e-6)
+                else:
+                    assert c0["photons"] == c1["photons"] == 4000 and c0["dropped"] == c1["dropped"]
+                    assert np.allclose(r0[:cnt0], r1[:cnt1], rtol=1e-5, atol=1e-6)   # (the counter words are the block's last)
+            for k in base[0][0]:
+                assert sum(c[k] for c, _ in base) == sum(c[k] for c, _ in run), (problem, k)
 
 
 def test_looking_ahead_in_fused_groups_never_changes_a_batch():
@@ -732,8 +776,59 @@ def test_an_announced_loop_is_streamed_and_never_overshot():
         check(100 + b)
     check(300)                          # out of order: the announced rest is called off
     check(301); check(302)
-    # a radiance problem is left to i3rc_hip_run_batches
-    stream.specifyParameters(intensityMus=[1.0], intensityPhis=[0.0])
+    # a radiance problem is streamed in the same way (round 4: fused launches for radiance problems)
+    for g in (plain, stream):
+        g.specifyParameters(intensityMus=[1.0], intensityPhis=[0.0], useRussianRouletteForIntensity=True, zetaMin=0.3)
+        g._ensure_tables()
+    raw = np.zeros(stream.layout().total, np.float64)
+    assert lib.i3rc_hip_expect_batches(stream._h, 21, 5, nb, n, C.byref(s), C.byref(acc)) == 0 and acc.value == 1
+    for b in range(nb):
+        assert lib.i3rc_hip_compute_batch(stream._h, 21, 5 + b, n, C.byref(s), 3, raw.ctypes.data_as(B.dp)) == 0, lib.i3rc_hip_last_error(stream._h)
+        got = stream.finish(raw.copy())
+        want = plain.computeRadiativeTransfer(M.new_RandomNumberSequence((21, 5 + b)), M.new_PhotonStream(0.7, 40.0, n))
+        assert got["counters"]["photons"] == want["counters"]["photons"] == n
+        assert np.allclose(_tallies_only(stream, got), _tallies_only(plain, want), rtol=1e-5, atol=1e-6), b
+        assert got["intensity"].mean() > 0
+    # a problem of the general kernels (a BRDF grid) is left to i3rc_hip_run_batches
+    stream.specifyParameters(surfaceBDRF=M.new_SurfaceDescription(np.array([[0.1, 0.3], [0.2, 0.4]], np.float32), np.array([0.0, 250.0, 500.0], np.float32),
+                                                                  np.array([0.0, 250.0, 500.0], np.float32)))
     stream._ensure_tables()
     assert lib.i3rc_hip_expect_batches(stream._h, 21, 5, nb, n, C.byref(s), C.byref(acc)) == 0 and acc.value == 0
     plain.finalize_Integrator(); stream.finalize_Integrator()
+
+
+def test_batch_moments_on_the_device_equal_the_drivers_sums():
+    """i3rc_hip_run_batches_moments: the sums and sums of squares over a loop's batches of everything reportResults hands out,
+    normalised and added up on the device, against the same batches fetched block by block (i3rc_hip_run_batches), normalised
+    by i3rc_hip_normalise and summed the way the drivers do (monteCarloDriver.f95:300-321) -- for a flux problem in fused
+    launches (LDS grid), a radiance problem with hybrid tables and limited contributions (the excess redistribution :327-347),
+    a one-direction radiance problem on the radar field, and an irregular two-component domain (general kernels: one launch per
+    batch; columns weighted by their area :358-366)."""
+    rri = dict(useRussianRouletteForIntensity=True, zetaMin=0.3)
+    full = dict(rri, intensityMus=[1.0, 0.4, 0.7], intensityPhis=[0.0, 80.0, 250.0], surfaceAlbedo=0.3, useHybridPhaseFunsForIntenCalcs=True,
+                hybridPhaseFunWidth=7.0, numOrdersOrigPhaseFunIntenCalcs=1, limitIntensityContributions=True, maxIntensityContribution=0.4)
+    t2 = [M.PhaseFunctionTable([M.henyey_greenstein(0.85, 32), M.henyey_greenstein(0.6, 16)]),
+          M.PhaseFunctionTable([M.PhaseFunction(legendre=np.array([0.0, 0.1], np.float32))])]
+    problems = [("step cloud, absorbing, surface", cases.step_cloud(ssa=0.9), hg_table(), dict(surfaceAlbedo=0.3), 20000, 11, "PhiloxBatchStream, false"),
+                ("step cloud, radiances, hybrid tables, limit", cases.step_cloud(ssa=0.95, nlayers=8), hg_table(), full, 8000, 9, "PhiloxBatchStream, true"),
+                ("radar field, nadir", cases.radar_cloud(), hg_table(), dict(rri, intensityMus=[1.0], intensityPhis=[0.0], surfaceAlbedo=0.1), 15000, 5, "one direction"),
+                ("two components, irregular grid", cases.two_component(), t2, dict(rri, intensityMus=[0.6], intensityPhis=[30.0], surfaceAlbedo=0.2), 6000, 7, "true, true")]
+    for what, d, tab, params, n, nb, kernel in problems:
+        g = make_gpu(d, tab, **params)
+        s1, s2, cnt = g.computeRadiativeTransferBatchMoments((5, 3), nb, 0.7, 25.0, n)
+        assert kernel in g.kernel_name(), (what, g.kernel_name())
+        assert cnt["photons"] == n * nb
+        rs = g.computeRadiativeTransferBatches((5, 3), nb, 0.7, 25.0, n)
+        per = []
+        for r in rs:
+            g._results = r
+            per.append(g.reportResults())
+        assert sum(r["counters"]["scatterings"] for r in rs) == cnt["scatterings"]
+        for key in s1:
+            x = np.stack([np.asarray(p[key], np.float64) for p in per])
+            want1, want2 = x.sum(0), (x * x).sum(0)
+            # (the device sums the same float32 values in float64; domain means: Fortran's sum() in real(4) against float64 rounded once)
+            tol = 2e-6 if key.startswith("mean") or key == "absorbedProfile" else 1e-9
+            assert np.allclose(s1[key], want1, rtol=tol, atol=1e-12), (what, key, np.abs(s1[key] - want1).max())
+            assert np.allclose(s2[key], want2, rtol=2 * tol, atol=1e-12), (what, key)
+        g.finalize_Integrator()
