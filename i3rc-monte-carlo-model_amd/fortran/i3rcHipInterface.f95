@@ -28,7 +28,12 @@ module i3rcHipInterface
                           counters, total
   end type i3rc_tally_layout
 
-  integer, parameter :: I3RC_CNT_PHOTONS = 0, I3RC_CNT_DROPPED = 1
+  type, bind(C) :: i3rc_moments_layout
+    integer(c_int64_t) :: fluxUp, fluxDown, fluxAbsorbed, volumeAbsorption, intensity, absorbedProfile, &
+                          meanFluxUp, meanFluxDown, meanFluxAbsorbed, meanIntensity, total
+  end type i3rc_moments_layout
+
+  integer, parameter :: I3RC_CNT_PHOTONS = 0, I3RC_CNT_DROPPED = 1, I3RC_NUM_COUNTERS = 16
   integer, parameter :: I3RC_MAX_COMPONENTS = 255, I3RC_MAX_DIRECTIONS = 255
 
   interface
@@ -126,6 +131,24 @@ module i3rcHipInterface
       integer(c_int64_t), value     :: nPhotons
       type(i3rc_source), intent(in) :: src
       real(c_double), intent(out)   :: hostTallies(*)        ! nBatches * layout%total
+      integer(c_int)                :: rc
+    end function
+    function i3rc_hip_get_moments_layout(h, layout) bind(C, name = "i3rc_hip_get_moments_layout") result(rc)
+      import
+      type(c_ptr), value                     :: h
+      type(i3rc_moments_layout), intent(out) :: layout
+      integer(c_int)                         :: rc
+    end function
+    function i3rc_hip_run_batches_moments(h, seed0, seed1, nBatches, nPhotons, src, total, totalSquares, counters) &
+             bind(C, name = "i3rc_hip_run_batches_moments") result(rc)
+      import
+      type(c_ptr), value            :: h
+      integer(c_int32_t), value     :: seed0, seed1          ! batch k is traced with the key (seed0, seed1 + k)
+      integer(c_int), value         :: nBatches
+      integer(c_int64_t), value     :: nPhotons
+      type(i3rc_source), intent(in) :: src
+      real(c_double), intent(out)   :: total(*), totalSquares(*)   ! i3rc_moments_layout%total each
+      real(c_double), intent(out)   :: counters(*)                 ! I3RC_NUM_COUNTERS
       integer(c_int)                :: rc
     end function
     function i3rc_hip_expect_batches(h, seed0, seed1, nBatches, nPhotons, src, accepted) &

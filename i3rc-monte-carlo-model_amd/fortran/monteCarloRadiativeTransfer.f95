@@ -61,6 +61,10 @@ module monteCarloRadiativeTransfer
     ! ... of which the first batchesFetched have arrived (a streamed loop: see computeRadiativeTransferBatches), and the loop itself
     integer :: batchesFetched = 0, batchSeed0 = 0, batchFirst = 0, batchPhotons = 0
     real    :: batchMu = 0., batchAzimuth = 0.
+    logical :: resultsValid = .false.      ! reportResults has a batch to report (not so between announcing a streamed loop and its first selectBatchResults)
+    ! sums and sums of squares over the batches of the last computeRadiativeTransferBatchMoments (i3rc_moments_layout)
+    real(c_double), dimension(:), pointer :: momentSums => null(), momentSquares => null()
+    integer :: momentBatches = 0
   end type integrator
 
   public :: integrator
@@ -68,6 +72,8 @@ module monteCarloRadiativeTransfer
             specifyParameters, computeRadiativeTransfer, reportResults
   ! Not in the reference: a driver's batch loop as one call, the batches overlapping on the device (see the procedures)
   public :: computeRadiativeTransferBatches, selectBatchResults
+  ! ... and the same loop with its statistics -- all a driver keeps of its batches -- gathered on the device
+  public :: computeRadiativeTransferBatchMoments, reportBatchMoments
 contains
   ! ------------------------------------------------------------------------------------------------
   ! Creation
@@ -547,6 +553,7 @@ contains
     if(.not. ok) return
     thisIntegrator%photonsProcessed = raw(layout%counters + 1 + I3RC_CNT_PHOTONS)
     thisIntegrator%photonsDropped   = raw(layout%counters + 1 + I3RC_CNT_DROPPED)
+    thisIntegrator%resultsValid     = .true.
   end function unpackTallies
 
   ! ------------------------------------------------------------------------------------------------
@@ -616,6 +623,9 @@ contains
       thisIntegrator%batchesFetched = numBatches
       call selectBatchResults(thisIntegrator, numBatches, status)   ! (as after a loop of computeRadiativeTransfer calls: the last batch)
     else
+      ! (streamed: nothing has been traced to the end yet.  Whatever an earlier call left in the integrator is not this loop's:
+      ! reportResults fails until selectBatchResults has made one of the loop's batches current)
+      thisIntegrator%resultsValid = .false.
       call setStateToSuccess(status)
     end if
   end subroutine computeRadiativeTransferBatches
@@ -635,6 +645,13 @@ contains
       return
     end if
     if(.not. deviceCall(thisIntegrator, i3rc_hip_get_tally_layout(thisIntegrator%device, layout), "selectBatchResults", status)) return
+    ! the loop was announced with the tally layout of its time: a specifyParameters in between (other radiance directions, say)
+    ! changes what a batch's block holds and how long it is -- neither the blocks already here nor the rest of the loop fit any more
+    if(layout%total /= size(thisIntegrator%batchTallies, 1)) then
+      call setStateToFailure(status, "selectBatchResults: the problem has changed since the batches were announced " // &
+                                     "(another tally layout); call computeRadiativeTransferBatches again.")
+      return
+    end if
     ! a streamed loop: take over the batches up to this one (in the loop's order: the library traces them ahead of us)
     source%kind = 0; source%solarMu = thisIntegrator%batchMu; source%solarAzimuth = thisIntegrator%batchAzimuth
     do while(thisIntegrator%batchesFetched < batch)
@@ -653,6 +670,148 @@ contains
   end subroutine selectBatchResults
 
   ! ------------------------------------------------------------------------------------------------
+  ! Not in the reference: the batch loop of a driver WITH its statistics.  The reference's drivers keep of every batch only the
+  !   first two moments of what reportResults returns (Example-Drivers/monteCarloDriver.f95:300-321) and turn them into mean
+  !   and standard error (:358-378).  computeRadiativeTransferBatchMoments traces batches firstBatch ... firstBatch + numBatches - 1
+  !   exactly as computeRadiativeTransferBatches does, but every batch is normalised (:353-395) and its values and their squares
+  !   are added up ON THE DEVICE (i3rc_hip_run_batches_moments): the per-batch tallies -- megabytes per batch on a cloud field --
+  !   never come to the host.  reportBatchMoments hands the sums out in the shapes of the drivers' ...Stats arrays
+  !   (last dimension: 1 = sum of x, 2 = sum of x**2 over the batches).  reportResults is not served by this call.
+  ! ------------------------------------------------------------------------------------------------
+  subroutine computeRadiativeTransferBatchMoments(thisIntegrator, iseed, firstBatch, numBatches, solarMu, solarAzimuth, &
+                                                  numberOfPhotons, status)
+    type(integrator),   intent(inout) :: thisIntegrator
+    integer,            intent(in   ) :: iseed, firstBatch, numBatches, numberOfPhotons
+    real,               intent(in   ) :: solarMu, solarAzimuth
+    type(ErrorMessage), intent(inout) :: status
+    type(i3rc_source)         :: source
+    type(i3rc_moments_layout) :: layout
+    real(c_double)            :: counters(I3RC_NUM_COUNTERS)
+
+    if(.not. isReady_Integrator(thisIntegrator)) then
+      call setStateToFailure(status, "computeRadiativeTransfer: problem not completely specified.")
+      return
+    end if
+    if(numBatches < 1 .or. numberOfPhotons < 1) then
+      call setStateToFailure(status, "computeRadiativeTransfer: Didn't process any photons.")
+      return
+    end if
+    call ensureTables(thisIntegrator, status)
+    if(stateIsFailure(status)) return
+    source%kind = 0; source%solarMu = solarMu; source%solarAzimuth = solarAzimuth
+    if(.not. deviceCall(thisIntegrator, i3rc_hip_get_moments_layout(thisIntegrator%device, layout), &
+                        "computeRadiativeTransfer", status)) return
+    if(associated(thisIntegrator%momentSums)) deallocate(thisIntegrator%momentSums, thisIntegrator%momentSquares)
+    allocate(thisIntegrator%momentSums(layout%total), thisIntegrator%momentSquares(layout%total))
+    thisIntegrator%momentBatches = 0
+    if(.not. deviceCall(thisIntegrator, i3rc_hip_run_batches_moments(thisIntegrator%device, int(iseed, c_int32_t),          &
+                        int(firstBatch, c_int32_t), int(numBatches, c_int), int(numberOfPhotons, c_int64_t), source,       &
+                        thisIntegrator%momentSums, thisIntegrator%momentSquares, counters), "computeRadiativeTransfer", status)) then
+      deallocate(thisIntegrator%momentSums, thisIntegrator%momentSquares)
+      return
+    end if
+    thisIntegrator%momentBatches    = numBatches
+    thisIntegrator%photonsProcessed = counters(1 + I3RC_CNT_PHOTONS)
+    thisIntegrator%photonsDropped   = counters(1 + I3RC_CNT_DROPPED)
+    if(thisIntegrator%photonsProcessed > 0.d0) then
+      call setStateToCompleteSuccess(status, "computeRadiativeTransfer: finished with photons")
+    else
+      call setStateToFailure(status, "computeRadiativeTransfer: Didn't process any photons.")
+    end if
+  end subroutine computeRadiativeTransferBatchMoments
+
+  subroutine reportBatchMoments(thisIntegrator, numBatches, meanFluxUpStats, meanFluxDownStats, meanFluxAbsorbedStats,      &
+                                fluxUpStats, fluxDownStats, fluxAbsorbedStats, absorbedProfileStats, volumeAbsorptionStats, &
+                                meanIntensityStats, intensityStats, status)
+    type(integrator),                      intent(in   ) :: thisIntegrator
+    integer,                     optional, intent(  out) :: numBatches
+    real, dimension(2),          optional, intent(  out) :: meanFluxUpStats, meanFluxDownStats, meanFluxAbsorbedStats
+    real, dimension(:, :, :),    optional, intent(  out) :: fluxUpStats, fluxDownStats, fluxAbsorbedStats   ! (nx, ny, 2)
+    real, dimension(:, :),       optional, intent(  out) :: absorbedProfileStats                            ! (nz, 2)
+    real, dimension(:, :, :, :), optional, intent(  out) :: volumeAbsorptionStats                           ! (nx, ny, nz, 2)
+    real, dimension(:, :),       optional, intent(  out) :: meanIntensityStats                              ! (nDir, 2)
+    real, dimension(:, :, :, :), optional, intent(  out) :: intensityStats                                  ! (nx, ny, nDir, 2)
+    type(ErrorMessage),                    intent(inout) :: status
+    type(i3rc_moments_layout) :: layout
+    integer :: nx, ny, nz, nDir
+
+    if(.not. associated(thisIntegrator%momentSums)) then
+      call setStateToFailure(status, "reportBatchMoments: no batch moments have been computed.")
+      return
+    end if
+    if(.not. deviceCall(thisIntegrator, i3rc_hip_get_moments_layout(thisIntegrator%device, layout), "reportBatchMoments", status)) return
+    if(layout%total /= size(thisIntegrator%momentSums)) then
+      call setStateToFailure(status, "reportBatchMoments: the problem has changed since the moments were computed.")
+      return
+    end if
+    nx = size(thisIntegrator%fluxUp, 1); ny = size(thisIntegrator%fluxUp, 2); nz = size(thisIntegrator%volumeAbsorption, 3)
+    nDir = 0
+    if(thisIntegrator%computeIntensity) nDir = size(thisIntegrator%intensity, 3)
+    if(present(numBatches)) numBatches = thisIntegrator%momentBatches
+    if(present(meanFluxUpStats))       meanFluxUpStats       = scalarMoments(layout%meanFluxUp)
+    if(present(meanFluxDownStats))     meanFluxDownStats     = scalarMoments(layout%meanFluxDown)
+    if(present(meanFluxAbsorbedStats)) meanFluxAbsorbedStats = scalarMoments(layout%meanFluxAbsorbed)
+    if(present(fluxUpStats))       call fieldMoments(layout%fluxUp,       nx * ny, fluxUpStats,       "fluxUpStats")
+    if(present(fluxDownStats))     call fieldMoments(layout%fluxDown,     nx * ny, fluxDownStats,     "fluxDownStats")
+    if(present(fluxAbsorbedStats)) call fieldMoments(layout%fluxAbsorbed, nx * ny, fluxAbsorbedStats, "fluxAbsorbedStats")
+    if(present(absorbedProfileStats)) then
+      if(any(shape(absorbedProfileStats) /= (/ nz, 2 /))) then
+        call setStateToFailure(status, "reportBatchMoments: absorbedProfileStats array is the wrong size")
+      else
+        absorbedProfileStats(:, 1) = real(thisIntegrator%momentSums   (layout%absorbedProfile + 1:layout%absorbedProfile + nz))
+        absorbedProfileStats(:, 2) = real(thisIntegrator%momentSquares(layout%absorbedProfile + 1:layout%absorbedProfile + nz))
+      end if
+    end if
+    if(present(volumeAbsorptionStats)) then
+      if(any(shape(volumeAbsorptionStats) /= (/ nx, ny, nz, 2 /))) then
+        call setStateToFailure(status, "reportBatchMoments: volumeAbsorptionStats array is the wrong size")
+      else
+        volumeAbsorptionStats(:, :, :, 1) = reshape(real(thisIntegrator%momentSums   (layout%volumeAbsorption + 1:layout%volumeAbsorption + nx * ny * nz)), (/ nx, ny, nz /))
+        volumeAbsorptionStats(:, :, :, 2) = reshape(real(thisIntegrator%momentSquares(layout%volumeAbsorption + 1:layout%volumeAbsorption + nx * ny * nz)), (/ nx, ny, nz /))
+      end if
+    end if
+    if(present(meanIntensityStats)) then
+      if(nDir < 1) then
+        call setStateToFailure(status, "reportBatchMoments: intensity information not available")
+      else if(any(shape(meanIntensityStats) /= (/ nDir, 2 /))) then
+        call setStateToFailure(status, "reportBatchMoments: requesting mean intensity in the wrong number of directions.")
+      else
+        meanIntensityStats(:, 1) = real(thisIntegrator%momentSums   (layout%meanIntensity + 1:layout%meanIntensity + nDir))
+        meanIntensityStats(:, 2) = real(thisIntegrator%momentSquares(layout%meanIntensity + 1:layout%meanIntensity + nDir))
+      end if
+    end if
+    if(present(intensityStats)) then
+      if(nDir < 1) then
+        call setStateToFailure(status, "reportBatchMoments: intensity information not available")
+      else if(any(shape(intensityStats) /= (/ nx, ny, nDir, 2 /))) then
+        call setStateToFailure(status, "reportBatchMoments: intensity array has wrong dimensions.")
+      else
+        intensityStats(:, :, :, 1) = reshape(real(thisIntegrator%momentSums   (layout%intensity + 1:layout%intensity + nx * ny * nDir)), (/ nx, ny, nDir /))
+        intensityStats(:, :, :, 2) = reshape(real(thisIntegrator%momentSquares(layout%intensity + 1:layout%intensity + nx * ny * nDir)), (/ nx, ny, nDir /))
+      end if
+    end if
+    if(.not. stateIsFailure(status)) call setStateToSuccess(status)
+  contains
+    function scalarMoments(at) result(m)
+      integer(c_int64_t), intent(in) :: at
+      real :: m(2)
+      m(1) = real(thisIntegrator%momentSums(at + 1)); m(2) = real(thisIntegrator%momentSquares(at + 1))
+    end function scalarMoments
+    subroutine fieldMoments(at, n, to, name)
+      integer(c_int64_t),       intent(in ) :: at
+      integer,                  intent(in ) :: n
+      real, dimension(:, :, :), intent(out) :: to
+      character(len = *),       intent(in ) :: name
+      if(any(shape(to) /= (/ nx, ny, 2 /))) then
+        call setStateToFailure(status, "reportBatchMoments: " // name // " array is the wrong size")
+      else
+        to(:, :, 1) = reshape(real(thisIntegrator%momentSums   (at + 1:at + n)), (/ nx, ny /))
+        to(:, :, 2) = reshape(real(thisIntegrator%momentSquares(at + 1:at + n)), (/ nx, ny /))
+      end if
+    end subroutine fieldMoments
+  end subroutine reportBatchMoments
+
+  ! ------------------------------------------------------------------------------------------------
   ! Reporting
   ! ------------------------------------------------------------------------------------------------
   subroutine reportResults(thisIntegrator, meanFluxUp, meanFluxDown, meanFluxAbsorbed, fluxUp, fluxDown, fluxAbsorbed, &
@@ -669,6 +828,11 @@ contains
 
     if(.not. associated(thisIntegrator%fluxUp)) then
       call setStateToFailure(status, "reportResults: integrator hasn't been initialized.")
+      return
+    end if
+    if(.not. thisIntegrator%resultsValid .and. associated(thisIntegrator%batchTallies)) then
+      ! a streamed loop has been announced (computeRadiativeTransferBatches) and none of its batches selected yet
+      call setStateToFailure(status, "reportResults: no batch of the loop has been selected (selectBatchResults).")
       return
     end if
     nColumns = size(thisIntegrator%fluxUp)
@@ -758,6 +922,7 @@ contains
     copy%fluxUp = original%fluxUp; copy%fluxDown = original%fluxDown; copy%fluxAbsorbed = original%fluxAbsorbed
     copy%volumeAbsorption = original%volumeAbsorption
     copy%readyToCompute = original%readyToCompute
+    copy%resultsValid   = original%resultsValid
     if(original%useSurfaceBDRF) then
       call specifyParameters(copy, surfaceBDRF = original%surfaceBDRF, status = status)
     else
@@ -803,6 +968,7 @@ contains
     if(associated(thisIntegrator%intensity))            deallocate(thisIntegrator%intensity)
     if(associated(thisIntegrator%intensityByComponent)) deallocate(thisIntegrator%intensityByComponent)
     if(associated(thisIntegrator%batchTallies))         deallocate(thisIntegrator%batchTallies)
+    if(associated(thisIntegrator%momentSums))           deallocate(thisIntegrator%momentSums, thisIntegrator%momentSquares)
     thisIntegrator%readyToCompute = .false.; thisIntegrator%computeIntensity = .false.
     thisIntegrator%useSurfaceBDRF = .false.
   end subroutine finalize_Integrator

@@ -16,7 +16,8 @@ program i3rcDriver
   use monteCarloIllumination,      only: photonStream, new_PhotonStream, finalize_PhotonStream
   use monteCarloRadiativeTransfer, only: integrator, new_Integrator, specifyParameters, isReady_Integrator, &
                                          finalize_Integrator, computeRadiativeTransfer, reportResults,           &
-                                         computeRadiativeTransferBatches, selectBatchResults
+                                         computeRadiativeTransferBatches, selectBatchResults, &
+                                         computeRadiativeTransferBatchMoments, reportBatchMoments
   use UserInterface,               only: printStatus, getOneArgument
   implicit none
 
@@ -46,7 +47,7 @@ program i3rcDriver
 
   character(len = 256) :: namelistFile
   integer :: nx, ny, nz, nDir, numProcs, thisProc, perProc, batch, firstBatch
-  integer :: inFlight, groupSize, groupStart, inGroup
+  integer :: inFlight, groupSize, groupStart, inGroup, deviceMoments
   real    :: tallyWords
   character(len = 32) :: envText
   logical :: wantRadiance
@@ -136,6 +137,25 @@ program i3rcDriver
   inFlight = 0
   call get_environment_variable("I3RC_BATCHES_IN_FLIGHT", envText, status = rc)
   if(rc == 0 .and. len_trim(envText) > 0) read(envText, *, iostat = rc) inFlight
+  ! All this driver keeps of a batch are the first two moments of its results (below; monteCarloDriver.f95:300-321): by default they
+  ! are gathered on the device (computeRadiativeTransferBatchMoments) and the batches' tallies -- megabytes each on a cloud
+  ! field -- never come to the host.  I3RC_DRIVER_MOMENTS=0 in the environment keeps the batch-by-batch loop.
+  deviceMoments = 1
+  call get_environment_variable("I3RC_DRIVER_MOMENTS", envText, status = rc)
+  if(rc == 0 .and. len_trim(envText) > 0) read(envText, *, iostat = rc) deviceMoments
+  if(deviceMoments /= 0 .and. inFlight /= 1) then
+    call computeRadiativeTransferBatchMoments(mc, iseed, firstBatch, perProc, solarMu, solarAzimuth, numPhotonsPerBatch, status)
+    call printStatus(status)
+    call reportBatchMoments(mc, meanFluxUpStats = mMeans(1, :), meanFluxDownStats = mMeans(2, :), meanFluxAbsorbedStats = mMeans(3, :), &
+                            fluxUpStats = mUp, fluxDownStats = mDown, fluxAbsorbedStats = mAbs, absorbedProfileStats = mProfile,        &
+                            volumeAbsorptionStats = mVolume, status = status)
+    call printStatus(status)
+    if(wantRadiance) then
+      call reportBatchMoments(mc, intensityStats = mRad, status = status)
+      call printStatus(status)
+    end if
+    perProc = 0   ! (the loop below has nothing left to do)
+  end if
   tallyWords = 3. * nx * ny + real(nx) * ny * nz + 2. * nDir * nx * ny
   groupSize = max(1, min(4096, int(256. * 1024. * 1024. / (8. * tallyWords))))
   do groupStart = firstBatch, firstBatch + perProc - 1, groupSize

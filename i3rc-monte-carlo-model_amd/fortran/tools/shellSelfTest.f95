@@ -110,8 +110,58 @@ contains
     print '(a, 4f10.5, l2)', "surface   ", fluxUp(1, 1), fluxDown(1, 1), meanI, stateIsFailure(status)
     call finalize_Integrator(mc)
     call otherSources(slab)
+    call streamedLoop(slab)
     print '(a)', "gpu checks done"
   end subroutine gpuChecks
+
+  ! The batch loop as the shell's own entry points run it: announced and streamed (computeRadiativeTransferBatches /
+  ! selectBatchResults), and with its statistics gathered on the device (computeRadiativeTransferBatchMoments / reportBatchMoments).
+  ! Prints "streamed" with: reportResults before any batch was selected fails (T); sum over the batches of fluxUp taken batch by
+  ! batch; the same from the device's moments; sum of squares likewise, twice; a change of the radiance directions in mid-loop
+  ! makes the next selectBatchResults fail (T) instead of writing a block of another length into the loop's storage.
+  subroutine streamedLoop(slab)
+    type(domain), intent(in) :: slab
+    type(integrator) :: mc
+    integer, parameter :: nBatches = 12, nPhotons = 50000
+    real    :: fluxUp(1, 1), upStats(1, 1, 2), meanUp(2)
+    double precision :: s1, s2
+    logical :: staleRefused, changeRefused
+    integer :: batch, nDone
+
+    mc = new_Integrator(slab, status)
+    call specifyParameters(mc, surfaceAlbedo = 0.2, status = status)
+    call computeRadiativeTransferBatches(mc, 7, 1, nBatches, 0.5, 0., nPhotons, status)
+    if(stateIsFailure(status)) then
+      print *, "computeRadiativeTransferBatches failed"; stop 1
+    end if
+    call reportResults(mc, fluxUp = fluxUp, status = status)        ! nothing selected yet: must not report an earlier call's numbers
+    staleRefused = stateIsFailure(status)
+    call setStateToSuccess(status)
+    s1 = 0.d0; s2 = 0.d0
+    do batch = 1, nBatches
+      call selectBatchResults(mc, batch, status)
+      call reportResults(mc, fluxUp = fluxUp, status = status)
+      if(stateIsFailure(status)) then
+        print *, "streamed batch failed ", batch; stop 1
+      end if
+      s1 = s1 + fluxUp(1, 1); s2 = s2 + dble(fluxUp(1, 1))**2
+    end do
+    call computeRadiativeTransferBatchMoments(mc, 7, 1, nBatches, 0.5, 0., nPhotons, status)
+    call reportBatchMoments(mc, numBatches = nDone, meanFluxUpStats = meanUp, fluxUpStats = upStats, status = status)
+    if(stateIsFailure(status) .or. nDone /= nBatches) then
+      print *, "batch moments failed"; stop 1
+    end if
+    ! a parameter change in mid-loop: announced with no radiance directions, asked for with one
+    call computeRadiativeTransferBatches(mc, 7, 1, nBatches, 0.5, 0., nPhotons, status)
+    call selectBatchResults(mc, 2, status)
+    call specifyParameters(mc, intensityMus = (/ 1. /), intensityPhis = (/ 0. /), status = status)
+    call setStateToSuccess(status)
+    call selectBatchResults(mc, 5, status)
+    changeRefused = stateIsFailure(status)
+    call setStateToSuccess(status)
+    print '(a, l2, 2f12.6, 2f12.7, 2f12.6, l2)', "streamed  ", staleRefused, s1, upStats(1, 1, 1), s2, upStats(1, 1, 2), meanUp, changeRefused
+    call finalize_Integrator(mc)
+  end subroutine streamedLoop
 
   ! The photon sources that hand the kernel explicit start positions and directions (monteCarloIllumination.f95
   ! :106-424): on a horizontally uniform slab the azimuth and the place of entry do not matter, so RandomAzimuth and

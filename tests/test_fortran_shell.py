@@ -257,6 +257,14 @@ def test_shell_integrator_on_gpu():
         assert abs(f_up + f_dn - 1.0) < 2e-4
     assert float(up) * 0.5 < flux[0] < 0.5          # isotropic-flux illumination: between overhead and grazing sun
     assert 0.5 < internal[0] < 1.0                   # upward-looking detector in mid-slab: most photons leave through the top
+    # the batch loop through the shell's own entry points: streamed (announced, taken over batch by batch) and with its moments
+    # gathered on the device -- the same twelve batches, so the same sums; reportResults before a batch is selected and
+    # selectBatchResults after a change of the tally layout in mid-loop are refused
+    st = _fields(r.stdout, "streamed")
+    assert st[0] == "T" and st[-1] == "T", st
+    s1, m1, s2, m2, mean1, mean2 = (float(v) for v in st[1:7])
+    assert abs(s1 - m1) < 2e-6 * s1 and abs(s2 - m2) < 4e-6 * s2 and abs(mean1 - m1) < 2e-6 * m1 and abs(mean2 - m2) < 4e-6 * m2
+    assert 12 * 0.2 < s1 < 12 * 0.5                  # (a slab of optical depth 1 over a surface of albedo 0.2, sun at 60 degrees)
 
 
 @pytest.mark.gpu
@@ -307,12 +315,39 @@ def test_reference_drivers_run_unchanged_on_gpu(tmp_path):
         r2 = _run([own, str(out / "own.nml")], cwd=ROOT)
         assert r2.returncode == 0 and "Wrote ASCII results" in r2.stdout and "Wrote netCDF results" in r2.stdout, r2.stdout + r2.stderr
         own_flux = open(str(out / "own_flux.txt")).read()
-        # same seeds, same kernel, same statistics: the two flux files agree line by line
-        assert own_flux.splitlines()[9:] == flux.splitlines()[9:]
+        # Same seeds, same kernels, the same statistics: the files agree to the digits their formats print.  The shell's driver
+        # gathers its batch moments on the device in float64 (computeRadiativeTransferBatchMoments), the reference's driver adds
+        # real(4) values one after the other: where a value lies within 1e-7 of a rounding boundary of F9.4 the last printed digit
+        # may differ by one -- allowed for at most one value in a hundred, by one unit.
+        def same_to_the_printed_digits(a, b, what):
+            assert len(a) == len(b), what
+            values = off = 0
+            for x, y in zip(a, b):
+                if x == y or "Property_File" in x:
+                    continue
+                fx, fy = x.split(), y.split()
+                assert len(fx) == len(fy), (what, x, y)
+                assert not x.lstrip().startswith("!") or "Average" in x, (what, x, y)   # (header lines agree as text)
+                for u, v in zip(fx, fy):
+                    if u != v:
+                        assert abs(float(u) - float(v)) <= 1.0001e-4, (what, x, y)
+                        off += 1
+            values = sum(len(x.split()) for x in a)
+            assert off <= max(1, values // 100), (what, off, values)
+        same_to_the_printed_digits(own_flux.splitlines()[9:], flux.splitlines()[9:], "flux")
         for name in ("rad", "absprof", "absvol"):   # whole files, headers included (Property_File differs by name only)
             a = open(str(out / f"own_{name}.txt")).read().splitlines()
             b = open(str(out / f"stepCloud_{name}.txt")).read().splitlines()
-            assert len(a) == len(b) and [x for x, y in zip(a, b) if x != y and "Property_File" not in x] == [], name
+            same_to_the_printed_digits(a, b, name)
+        # ... and the shell's driver with the batch-by-batch loop (I3RC_DRIVER_MOMENTS=0) gives what its device moments give
+        nml3 = nml2.replace("own_", "loop_")
+        open(str(out / "loop.nml"), "w").write(nml3)
+        r3 = subprocess.run([own, str(out / "loop.nml")], cwd=ROOT, env=dict(os.environ, I3RC_DRIVER_MOMENTS="0"), capture_output=True, text=True, timeout=600)
+        assert r3.returncode == 0 and "Wrote ASCII results" in r3.stdout, r3.stdout + r3.stderr
+        for name in ("flux", "rad", "absprof", "absvol"):
+            a = open(str(out / f"own_{name}.txt")).read().splitlines()
+            b = open(str(out / f"loop_{name}.txt")).read().splitlines()
+            same_to_the_printed_digits(a[9:] if name == "flux" else a, b[9:] if name == "flux" else b, "loop " + name)
         from scipy.io import netcdf_file as _nc
 
         fo = _nc(str(out / "own_results.nc"), "r", mmap=False)

@@ -828,7 +828,8 @@ def test_batch_moments_on_the_device_equal_the_drivers_sums():
             x = np.stack([np.asarray(p[key], np.float64) for p in per])
             want1, want2 = x.sum(0), (x * x).sum(0)
             # (the device sums the same float32 values in float64; domain means: Fortran's sum() in real(4) against float64 rounded once)
-            tol = 2e-6 if key.startswith("mean") or key == "absorbedProfile" else 1e-9
+            # (batches in launches of their own gather partial sums in float32 in LDS: two runs of a batch agree to 1e-7, not to the bit)
+            tol = 2e-6 if key.startswith("mean") or key == "absorbedProfile" else (1e-9 if "PhiloxBatchStream" in g.kernel_name() else 1e-6)
             assert np.allclose(s1[key], want1, rtol=tol, atol=1e-12), (what, key, np.abs(s1[key] - want1).max())
             assert np.allclose(s2[key], want2, rtol=2 * tol, atol=1e-12), (what, key)
         g.finalize_Integrator()
