@@ -55,6 +55,12 @@ def parse_args():
     ap.add_argument("--overlap", choices=("auto", "0", "1", "2"), default="auto",
                     help="1: two steps in flight (two handles / streams / tally buffers), 2: three; auto = three for N > 1, else one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--contact-timeout", type=float, default=float(os.environ.get("I3RC_BENCH_CONTACT_TIMEOUT", "180")),
+                    help="N > 1: seconds every rank has for init_process_group and a first all-reduce before the run is called off (naming the rank)")
+    ap.add_argument("--contact-only", action="store_true", help="N > 1: stop after the first-contact check (process group up, one all-reduce on every rank)")
+    ap.add_argument("--scale-photons", type=float, default=1.0,
+                    help="test knob: scales the workload's photon counts (per GPU and per node), so that the default N > 1 mode -- configs 3 / 4 "
+                         "shard the node's batch of 1e9 photons -- can be rehearsed at a small size")
     a = ap.parse_args()
     if a.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -75,12 +81,15 @@ def run_cpu_baseline(a):
         return {"value": None, "unit": "photons/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
 
 
-def wait_for_ranks(procs, poll_s=0.2, grace_s=10.0):
+def wait_for_ranks(procs, poll_s=0.2, grace_s=10.0, contact=None):
     """Wait for all rank processes; when one exits non-zero the others are terminated (then killed) instead of being
-    left in a rendezvous or a barrier.  Returns rank 0's stdout / stderr and every exit code."""
+    left in a rendezvous or a barrier.  Returns rank 0's stdout / stderr and every exit code.
+    contact = (status directory, seconds): every rank must have reported its first contact (process group up, one all-reduce:
+    worker's first_contact) within that time, else the run is called off and the silent ranks are named."""
     import threading
 
     captured = {}
+    t_start = time.time()
 
     def drain():   # rank 0's pipes are read while we poll, so that a long line never blocks the child
         captured["out"], captured["err"] = procs[0].communicate()
@@ -95,6 +104,13 @@ def wait_for_ranks(procs, poll_s=0.2, grace_s=10.0):
             break
         if all(c == 0 for c in codes):
             break
+        if contact is not None and time.time() - t_start > contact[1]:
+            missing = [r for r in range(len(procs)) if not os.path.exists(os.path.join(contact[0], f"rank{r}.contact"))]
+            if missing:
+                sys.stderr.write(f"bench.py: no first contact from rank(s) {missing} within {contact[1]:.0f} s (process group / first all-reduce): calling the run off\n")
+                failed = True
+                break
+            contact = None
         time.sleep(poll_s)
     if failed:
         t_fail = time.time()   # (ranks that fail for the same reason -- no GPU, a bad argument -- say so themselves within a moment)
@@ -124,28 +140,35 @@ def launcher(a):
     # Ranks rendezvous on a port found by bind-and-close: somebody else may take it before rank 0 binds it (EADDRINUSE in
     # its stderr) -- then the whole set is started again on a fresh port.  All children are polled: the first one that
     # fails takes the others with it (they would sit in the rendezvous or in a barrier until its timeout).
+    import tempfile
+
     for attempt in range(3):
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
         procs = []
+        status_dir = tempfile.mkdtemp(prefix="i3rc_bench_")   # every rank reports its first contact here (see first_contact)
         for r in range(a.gpus):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
-                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), I3RC_BENCH_SPAWNED="1")
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), I3RC_BENCH_SPAWNED="1", I3RC_BENCH_STATUS_DIR=status_dir)
             if cpu_baseline is not None and r == 0:   # rank 0 writes the line: it quotes the oracle's work counters in its roofline
                 env["I3RC_BENCH_CPU_BASELINE"] = json.dumps(cpu_baseline)
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                           stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
                                           stderr=subprocess.PIPE if r == 0 else None, text=True))
-        out0, err0, codes = wait_for_ranks(procs)
+        # (the deadline allows for a fresh box's first `import torch`: up to two minutes)
+        out0, err0, codes = wait_for_ranks(procs, contact=(status_dir, a.contact_timeout + 150.0) if a.gpus > 1 else None)
         sys.stderr.write(err0 or "")
+        import shutil
+
+        shutil.rmtree(status_dir, ignore_errors=True)
         if any(codes) and attempt < 2 and ("EADDRINUSE" in (err0 or "") or "Address already in use" in (err0 or "")):
             sys.stderr.write(f"bench.py: port {port} was taken before the ranks met; starting them again on another one\n")
             continue
         break
     if any(codes):
-        sys.stderr.write(f"bench.py: rank exit codes {codes}\n")
+        sys.stderr.write(f"bench.py: rank exit codes {codes}" + "".join(f"; rank {r} failed with code {c}" for r, c in enumerate(codes) if c not in (0, None, -15)) + "\n")
         sys.stdout.write(out0 or "")
         return max(abs(c) for c in codes) or 1
     line = None
@@ -212,6 +235,39 @@ def load_calibration(config):
             "ratio_range": [j["ratio_min"], j["ratio_max"]], "note": j["note"]}
 
 
+def first_contact(a, dist, torch, rank, world, local_rank, rehearsal, pg_seconds):
+    """First-contact check of an N > 1 run: one small all-reduce (every rank contributes rank + 1) and a barrier, under a watchdog --
+    a rank whose collective does not come back within --contact-timeout says so on stderr and leaves with exit code 5 instead
+    of sitting in RCCL until somebody kills the job.  Reports to the launcher's status directory."""
+    import threading
+
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(a.contact_timeout):
+            sys.stderr.write(f"bench.py: rank {rank} (cuda:{local_rank}): first all-reduce did not complete within {a.contact_timeout:.0f} s "
+                             f"(backend {dist.get_backend()}, world {world}): giving up\n")
+            sys.stderr.flush()
+            os._exit(5)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    t0 = time.perf_counter()
+    probe = torch.full((4,), float(rank + 1), dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+    dist.all_reduce(probe)
+    if not rehearsal:
+        torch.cuda.synchronize()
+    want = world * (world + 1) / 2.0
+    ok = bool((probe.cpu() == want).all())
+    dist.barrier()
+    done.set()
+    sys.stderr.write(f"[bench] rank {rank}/{world} cuda:{local_rank}: process group ({dist.get_backend()}) up in {pg_seconds:.1f} s, "
+                     f"first all-reduce {'ok' if ok else 'WRONG: ' + str(probe.tolist())} in {time.perf_counter() - t0:.2f} s\n")
+    d = os.environ.get("I3RC_BENCH_STATUS_DIR")
+    if d and os.path.isdir(d):
+        open(os.path.join(d, f"rank{rank}.contact"), "w").write("ok" if ok else "wrong sum")
+    return 0 if ok else 5
+
+
 def worker(a):
     rank = int(os.environ["RANK"])
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
@@ -253,11 +309,21 @@ def worker(a):
     if n_gpus > 1:
         import torch.distributed as dist
 
+        import datetime
+
+        t_pg = time.perf_counter()
+        limit = datetime.timedelta(seconds=a.contact_timeout)
         if rehearsal:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", timeout=limit)
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
         assert dist.get_world_size() == a.gpus
+        rc = first_contact(a, dist, torch, rank, n_gpus, local_rank, rehearsal, time.perf_counter() - t_pg)
+        if rc or a.contact_only:
+            if not rc and rank == 0:
+                print(json.dumps({"contact": "ok", "n_gpus": n_gpus, "backend": dist.get_backend(), "timeout_s": a.contact_timeout}), flush=True)
+            dist.destroy_process_group()
+            return rc
 
     # ---- problem: resident on the device before timing -------------------------------------------------
     name, w = W.get(a.config)
@@ -295,9 +361,9 @@ def worker(a):
     def measure(scaling, steps, warmup):
         """`steps` timed steps of the workload's batch: weak = every rank its own --photons photons, strong = one batch of
         --photons photons sharded over the ranks by photon range."""
-        per_step = a.photons or w["photons"]
+        per_step = a.photons or int(round(w["photons"] * a.scale_photons))
         if scaling == "strong" and n_gpus > 1 and not a.photons:
-            per_step = w.get("photons_node", per_step)   # configs 3 / 4: the batch BASELINE.json quotes for the whole node (1e9 photons)
+            per_step = int(round(w.get("photons_node", w["photons"]) * a.scale_photons))   # configs 3 / 4: the batch BASELINE.json quotes for the whole node (1e9 photons)
         if scaling == "strong":
             first, mine = shard_photons(per_step, n_gpus, rank)
             total_per_step = per_step
@@ -451,7 +517,8 @@ def worker(a):
                        "overlap": (f"{len(lanes)} steps in flight: as many handles, each with a stream and a tally buffer of its own, take the steps in turn -- "
                                    "the tail and the all-reduce of step k overlap the trace of step k + 1" if overlap else
                                    "none: zero, trace, all-reduce one after the other on one stream"),
-                       "rng": "Philox4x32-10 per photon, key (iseed=10, batch)"},
+                       "rng": "Philox4x32-10 per photon, key (iseed=10, batch)",
+                       **({"scale_photons": a.scale_photons} if a.scale_photons != 1.0 else {})},
             "world_size": dist.get_world_size() if dist is not None else 1,
             "backend": (dist.get_backend() if dist is not None else None),
             "devices": devices,

@@ -54,6 +54,34 @@ def test_two_ranks_default_is_the_metrics_case_with_the_weak_figure_beside_it():
     assert abs(j["result_check"]["meanFluxUp"] - 0.3253) < 3e-3
 
 
+@pytest.mark.parametrize("config,scale", [("landsat36", 4e-4), ("landsat119_7dir", 4e-5)])
+def test_configs_3_and_4_shard_the_nodes_batch_with_three_steps_in_flight(config, scale):
+    # The default N > 1 mode on BASELINE.json's configs 3 / 4: ONE batch of the node's photons (1e9, here scaled down) per step
+    # sharded over the ranks, three steps in flight (--overlap 2: three handles / streams / tally buffers whose all-reduces are
+    # issued in step order), the weak figure beside it; every run starts with the first-contact check (process group up, one
+    # all-reduce on every rank, under a watchdog).  Rehearsal mode: both ranks on GPU 0, tallies through gloo.
+    j = _bench(["--gpus", "2", "--config", config, "--steps", "4", "--warmup", "1", "--overlap", "2", "--scale-photons", str(scale), "--contact-timeout", "120"],
+               env=dict(I3RC_BENCH_REHEARSAL="1"))
+    node = int(round(1_000_000_000 * scale))
+    assert j["scaling"] == "strong" and j["config"]["photons_per_step"] == node and j["config"]["photons_per_gpu_per_step"] == node // 2
+    assert j["config"]["steps_in_flight"] == 3 and j["config"]["scale_photons"] == scale and j["world_size"] == 2
+    assert j["weak"]["photons_per_gpu_per_step"] == int(round(125_000_000 * scale)) and j["weak"]["photons_per_step"] == 2 * j["weak"]["photons_per_gpu_per_step"]
+    assert 0.2 < j["result_check"]["meanFluxUp"] < 0.7
+    if config == "landsat119_7dir":
+        assert len(j["result_check"]["meanIntensity"]) == 7 and all(0.01 < x < 1.0 for x in j["result_check"]["meanIntensity"])
+
+
+def test_first_contact_only():
+    # --contact-only: the ranks bring the process group up, do one all-reduce each and leave; the launcher relays rank 0's line
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e["I3RC_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--contact-only", "--contact-timeout", "120"], env=e, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout + r.stderr
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["contact"] == "ok" and j["n_gpus"] == 2 and j["backend"] == "gloo"
+    assert r.stderr.count("first all-reduce ok") == 2, r.stderr
+
+
 def test_steps_in_flight_on_one_gpu():
     # --overlap 1: two handles / streams / tally buffers take the steps in turn; every step is still checked in full
     j = _bench(["--gpus", "1", "--steps", "4", "--warmup", "2", "--photons", "3000000", "--overlap", "1", "--no-cpu-baseline"])

@@ -2,6 +2,8 @@
 logic that bench.py and the drivers use on GPUs (there with backend nccl = RCCL)."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -166,3 +168,86 @@ def test_eight_ranks_shard_reduce_normalise(tmp_path):
     assert np.all(np.abs(flux[1] - np.exp(-tau)) < 4 * np.sqrt(np.exp(-tau) * (1 - np.exp(-tau)) / per_col) + 4 / per_col)
     assert np.allclose(flux[1] + flux[2], flux[1:].sum(axis=0))
     assert abs((flux[1] + flux[2]).mean() - 1.0) < 1e-12
+
+
+# ---- first contact of an N > 1 bench run (bench.first_contact): gloo here, RCCL on the node -------------------------------------
+_CONTACT = r'''
+import argparse, os, sys, time
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist, datetime
+import bench
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+a = argparse.Namespace(contact_timeout=float(os.environ["T"]))
+dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=30))
+if os.environ.get("HANG") == str(rank):
+    time.sleep(60)          # a rank that joins the group and never reaches its first collective
+rc = bench.first_contact(a, dist, torch, rank, world, rank, True, 0.0)
+# the steps of a run with three in flight: every rank issues the lanes' all-reduces in the same order (lane k %% 3), each on its own buffer
+if rc == 0:
+    lanes = [torch.zeros(5, dtype=torch.float64) for _ in range(3)]
+    for k in range(7):
+        t = lanes[k %% 3]; t.zero_(); t += (rank + 1) * (k + 1)
+        dist.all_reduce(t)
+        assert float(t[0]) == (k + 1) * world * (world + 1) / 2, (k, t)
+    dist.barrier()
+    dist.destroy_process_group()
+sys.exit(rc)
+'''
+
+
+def _contact_ranks(world, timeout_s, hang=None, status_dir=None):
+    import socket
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), T=str(timeout_s))
+        if hang is not None:
+            env["HANG"] = str(hang)
+        if status_dir:
+            env["I3RC_BENCH_STATUS_DIR"] = status_dir
+        procs.append(subprocess.Popen([sys.executable, "-c", _CONTACT % root], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    return procs
+
+
+def test_first_contact_check_passes_and_names_a_rank_that_hangs(tmp_path):
+    # all ranks there: every one reports "first all-reduce ok", leaves its mark in the status directory, and the three lanes'
+    # all-reduces -- issued in the order a run with three steps in flight issues them -- give the right sums
+    d = tmp_path / "status"
+    d.mkdir()
+    procs = _contact_ranks(3, 30, status_dir=str(d))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0, 0], outs
+    assert all("first all-reduce ok" in e for _, e in outs)
+    assert sorted(os.listdir(d)) == ["rank0.contact", "rank1.contact", "rank2.contact"]
+    # rank 1 never reaches its first collective: the others do not wait for ever -- they say which rank they are, what they were
+    # waiting for, and leave with exit code 5 within the stated time
+    import time
+    t0 = time.time()
+    procs = _contact_ranks(2, 4, hang=1)
+    out0, err0 = procs[0].communicate(timeout=60)
+    assert procs[0].returncode == 5 and "rank 0" in err0 and "first all-reduce did not complete within 4 s" in err0, err0
+    assert time.time() - t0 < 40
+    procs[1].kill(); procs[1].wait()
+
+
+def test_launcher_calls_a_run_off_when_a_rank_makes_no_first_contact(tmp_path):
+    # bench.wait_for_ranks with a status directory: a set of ranks of which one never reports is terminated and the silent rank named
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    d = tmp_path / "status"
+    d.mkdir()
+    good = "import os, time; open(os.path.join(%r, 'rank0.contact'), 'w').write('ok'); time.sleep(60)" % str(d)
+    procs = [subprocess.Popen([sys.executable, "-c", good], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True),
+             subprocess.Popen([sys.executable, "-c", "import time; time.sleep(60)"], stdout=subprocess.DEVNULL)]
+    import contextlib, io
+    err = io.StringIO()
+    with contextlib.redirect_stderr(err):
+        out, e, codes = bench.wait_for_ranks(procs, contact=(str(d), 2.0), grace_s=5.0)
+    assert "no first contact from rank(s) [1] within 2 s" in err.getvalue(), err.getvalue()
+    assert all(c not in (0, None) for c in codes), codes

@@ -233,6 +233,80 @@ def test_config4_landsat_seven_radiances_at_1e6_photons(tmp_path):
     assert abs(dg - do) < 3 * np.sqrt(do / n_g + do / n_o) + 1e-5, (dg, do)
 
 
+def test_config3_landsat36_column_by_column_with_absorption(tmp_path):
+    """Config 3 (Landsat 128 x 128 x 36) COLUMN BY COLUMN, with omega = 0.99 in the cloudy cells -- so that the value the cells with
+    extinction share (passed in the kernel arguments: i3rc_hip_create), the absorption tallies and the table-in-LDS kernel of
+    1024-thread workgroups are all in it: 4e6 photons on the GPU against 4e6 of the oracle (a child process on the host cores
+    meanwhile), the per-column 3-sigma statistic (_assert_3sigma: Student's t allowance) on fluxUp, fluxDown and fluxAbsorbed
+    of the 16 384 columns, and the absorbed profile layer by layer."""
+    import os
+
+    from tests.test_gpu_parity import _assert_3sigma
+    cores = min(16, len(os.sched_getaffinity(0)))
+    per_core, n_ref = 2, 4_000_000 // (cores * 2)
+    child, out = _oracle_child(tmp_path, "landsat36_absorbing", cores, per_core, n_ref, columns=True)
+    from tools import workloads as W
+
+    name, w = W.get("landsat36_absorbing")
+    g, d = W.make_integrator(w)
+    gr = [g.computeRadiativeTransfer(M.new_RandomNumberSequence((77, b)), M.new_PhotonStream(1.0, 0.0, 125_000)) for b in range(1, 33)]
+    assert "table in LDS" in g.kernel_name() and "GRID_GLOBAL" in g.kernel_name(), g.kernel_name()
+    g.finalize_Integrator()
+    for r in gr:
+        r["absorbedProfile"] = r["volumeAbsorption"].reshape(36, -1).mean(axis=1, dtype=np.float64)
+    so, se = child.communicate(timeout=900)
+    assert child.returncode == 0, so + se
+    z = np.load(out)
+    assert len(z["means"]) == cores * per_core and z["fluxAbsorbed"].shape[1:] == (128, 128)
+    orr = [dict(fluxUp=u, fluxDown=dn, fluxAbsorbed=a, absorbedProfile=p) for u, dn, a, p in zip(z["fluxUp"], z["fluxDown"], z["fluxAbsorbed"], z["absorbedProfile"])]
+    for key in ("fluxUp", "fluxDown", "fluxAbsorbed", "absorbedProfile"):
+        _assert_3sigma(gr, orr, key, floor=1e-7)
+    # energy: what is not dropped is reflected, transmitted or absorbed (black surface) -- in expectation only: below a weight of
+    # 0.5 a photon plays Russian roulette (:673-680), which conserves energy on average, not photon by photon
+    n_g = 125_000 * len(gr)
+    tot = np.mean([r["fluxUp"].mean(dtype=np.float64) + r["fluxDown"].mean(dtype=np.float64) + r["fluxAbsorbed"].mean(dtype=np.float64) for r in gr])
+    assert abs(tot - (1 - sum(r["counters"]["dropped"] for r in gr) / n_g)) < 3e-4
+    assert 0.02 < np.mean([r["fluxAbsorbed"].mean() for r in gr]) < 0.3
+    dg, do = sum(r["counters"]["dropped"] for r in gr) / n_g, z["nBad"].sum() / (n_ref * len(z["nBad"]))
+    assert abs(dg - do) < 3 * np.sqrt(do / n_g + do / (n_ref * len(z["nBad"]))) + 1e-5, (dg, do)
+
+
+def test_config4_column_by_column_against_the_oracles_fixture():
+    """Config 4 (Landsat 128 x 128 x 119 + 7 radiance directions + the surface object) COLUMN BY COLUMN against a fixture the oracle
+    wrote in the build container (tests/golden/make_config4_columns.py: 48 batches of 5e5 photons, 2.4e7 in all -- thirty photons
+    per column and batch, where the batch means of a column are near enough to Gaussian for the per-column statistic that two
+    photons per column were not): per column the mean and the batch standard error of fluxUp, fluxDown and the seven radiance
+    fields.  Here: 32 batches of 1e6 photons on the GPU, the per-column 3-sigma statistic with its Student-t allowance
+    (test_gpu_parity._assert_3sigma's rule, the reference side from its recorded mean / standard error) on all nine fields
+    of 16 384 columns, the domain means of each, the dropped-photon rate and the scatterings per photon."""
+    import os
+
+    from scipy import stats
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config4_columns.npz"))
+    nb_ref, n_ref = int(z["batches"]), int(z["photonsPerBatch"])
+    assert str(z["config"]) == "landsat119_7dir" and z["mean"].shape == (9, 128, 128) and nb_ref >= 40 and nb_ref * n_ref >= 20_000_000
+    gr = _gpu_batches("landsat119_7dir", 32, 1_000_000)
+    fields = np.stack([np.concatenate([r["fluxUp"][None], r["fluxDown"][None], r["intensity"]]).astype(np.float64) for r in gr])   # [32][9][128][128]
+    mg, sg = fields.mean(0), fields.std(0, ddof=1) / np.sqrt(len(fields))
+    dof = len(fields) + nb_ref - 2
+    p3 = 2 * stats.t.sf(3.0, dof)
+    for k, name in enumerate(z["fieldNames"]):
+        zz = np.abs(mg[k] - z["mean"][k]) / (np.sqrt(sg[k] ** 2 + z["stderr"][k].astype(np.float64) ** 2) + 1e-7)
+        expected = p3 * zz.size
+        allowed = int(np.ceil(expected + 3 * np.sqrt(expected) + 1))
+        assert (zz > 3.0).sum() <= allowed, (str(name), int((zz > 3.0).sum()), allowed, zz.max())
+        assert zz.max() < stats.t.isf(1e-3 / (2 * zz.size), dof), (str(name), zz.max())
+        assert 0.85 < np.mean(zz ** 2) < 1.25, (str(name), np.mean(zz ** 2))     # (E[t^2] = dof / (dof - 2) = 1.03 here)
+        # the domain mean of the field, from the batch means of both sides
+        _assert_means_3sigma(fields[:, k].mean(axis=(1, 2)), z["batchMeans"][:, k], str(name))
+    c = dict(zip((str(x) for x in z["counterNames"]), z["counters"].sum(0)))
+    n_g, n_o = 1_000_000 * len(gr), nb_ref * n_ref
+    dg, do = sum(r["counters"]["dropped"] for r in gr) / n_g, c["nBad"] / n_o
+    assert abs(dg - do) < 3 * np.sqrt(do / n_g + do / n_o) + 1e-5, (dg, do)
+    kg = sum(r["counters"]["scatterings"] for r in gr) / n_g
+    assert abs(kg - c["scatterings"] / n_o) < 0.003 * kg
+
+
 @pytest.mark.parametrize("config,nb,n", [("landsat_tiled", 10, 40_000), ("landsat_tiled_7dir", 10, 20_000)])
 def test_fields_beyond_16_MB_against_the_oracle(tmp_path, config, nb, n):
     """The Landsat scene tiled 2 x 2 (256 x 256 x 119: 31 MB of extinction) runs the instantiation and the launch set-up of fields

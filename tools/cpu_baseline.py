@@ -52,6 +52,8 @@ def _worker(args):
         small = columns or r["fluxUp"].size <= 5000     # per-column fields of small domains (or on request); domain means (float64) of all
         inten = r.get("intensity")
         cols.append(dict(fluxUp=r["fluxUp"].copy() if small else None, fluxDown=r["fluxDown"].copy() if small else None,
+                         fluxAbsorbed=r["fluxAbsorbed"].copy() if small else None,
+                         absorbedProfile=r["volumeAbsorption"].reshape(r["volumeAbsorption"].shape[0], -1).mean(axis=1, dtype=np.float64),
                          intensity=inten.copy() if (small and inten is not None) else None,
                          means=[float(r[k].mean(dtype=np.float64)) for k in ("fluxUp", "fluxDown", "fluxAbsorbed")],
                          intensityMeans=[] if inten is None else [float(v) for v in inten.mean(axis=(1, 2), dtype=np.float64)],
@@ -93,7 +95,7 @@ def main():
         out = dict(means=np.array([c["means"] for c in allb]), intensityMeans=np.array([c["intensityMeans"] for c in allb]),
                    nBad=np.array([c["nBad"] for c in allb]), cellSteps=np.array([c["cellSteps"] for c in allb]),
                    scatterings=np.array([c["scatterings"] for c in allb]), photonsPerBatch=np.array(photons))
-        for k in ("fluxUp", "fluxDown", "intensity"):
+        for k in ("fluxUp", "fluxDown", "fluxAbsorbed", "intensity", "absorbedProfile"):
             if allb[0][k] is not None:
                 out[k] = np.stack([c[k] for c in allb])
         np.savez(a.save, **out)

@@ -35,6 +35,10 @@ WORKLOADS = {
     "landsat36": dict(label="i3rcLandsatCloud 128x128x36 (labelled synthetic, HG g=0.85 299 moments, mu0=1), flux",
                       baseline_config=3, domain=("landsat_cloud", dict(nlayers=36)), moments=299, mu0=1.0, params={},
                       photons=125_000_000, photons_node=1_000_000_000, cpu_photons=60_000),
+    # config 3 with omega = 0.99 in the cloudy cells (parity test: the value the cells with extinction share, volume absorption)
+    "landsat36_absorbing": dict(label="i3rcLandsatCloud 128x128x36 (labelled synthetic), omega = 0.99, mu0=1, flux + absorption", baseline_config=3,
+                                domain=("landsat_cloud", dict(nlayers=36, ssa=0.99)), moments=299, mu0=1.0, params={},
+                                photons=125_000_000, photons_node=1_000_000_000, cpu_photons=60_000),
     "landsat119": dict(label="i3rcLandsatCloud 128x128x119 (reference-exact field, mu0=1), flux", baseline_config=3,
                        domain=("landsat_cloud", {}), moments=299, mu0=1.0, params={}, photons=125_000_000, photons_node=1_000_000_000, cpu_photons=40_000),
     "landsat119_7dir": dict(label="i3rcLandsatCloud 128x128x119 + 7 radiance directions + Lambertian surface 0.2 "
