@@ -733,6 +733,7 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false) {
   // (one direction: no ring, a ready store of two wavefronts -- photon_kernel, DIRECT)
   P.rayQueueCap = h->nDir > 0 && !direct_rays(h) ? 64 : 0;   // (an event phase pushes at most 64 records; the rays go on to the ready buffer)
   if (h->nDir > 0) lds += sizeof(float) * 4 * (kRecWords * (size_t)P.rayQueueCap + kReadyWords * (size_t)(direct_rays(h) ? kDirectReady : kReadyRays));
+  if (h->nDir > 0) lds += sizeof(float) * (16 * (size_t)h->nDir + 3);   // per direction: what a ray derives from it (Lds::dirTab, 16-byte aligned)
   if (h->nDir > 0)
     for (int c = 0; c < h->ncomp; ++c)
       if (h->maxPfIndex[c] >= 65536) return h->fail("radiance runs take at most 65535 phase-function table entries per component");

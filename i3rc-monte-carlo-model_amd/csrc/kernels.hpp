@@ -367,6 +367,9 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
     L.tUp = p; L.tDown = p + ncol; L.tAbs = p + 2 * ncol;
     if (P.ldsTallies) p += 3 * ncol;
     L.dirCos = p; p += 3 * P.nDir;
+    p += (4 - (int)((p - (lds_float *)smem) & 3)) & 3;   // (16-byte alignment for the 128-bit reads of dirTab)
+    L.dirTab = p;
+    if (INTENSITY && !Rng::kReplay) p += 16 * P.nDir;
     L.queue = p;
     if (INTENSITY && !Rng::kReplay) p += 4 * (kRecWords * P.rayQueueCap + kReadyWords * (DIRECT ? kDirectReady : kReadyRays));
     L.tInt = p;
@@ -398,6 +401,15 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
     for (int i = threadIdx.x; i < P.comp0.nInv; i += blockDim.x) L.cosTab[i] = src[i];
   }
   __syncthreads();
+  if (INTENSITY && !Rng::kReplay) {   // what a ray of each radiance direction derives from it, once per workgroup (Ray::load_direction)
+    for (int d = threadIdx.x; d < P.nDir; d += blockDim.x) {
+      Ray t;
+      t.dx = L.dirCos[3 * d]; t.dy = L.dirCos[3 * d + 1]; t.dz = L.dirCos[3 * d + 2];
+      t.set_direction(L);
+      t.store_direction(L.dirTab + 16 * d);
+    }
+    __syncthreads();
+  }
 
   constexpr bool REPLAY = Rng::kReplay;        // per-photon fates are recorded by i3rc_hip_run_replay only
   constexpr bool BATCHED = Rng::kBatched;      // fused multi-batch launch: every lane knows its photon's batch (rng.batch)
@@ -554,18 +566,19 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
 #define I3RC_EXPAND_BATCH 64   /* = the ready buffer: expand when it is empty, a whole wavefront at a time */
 #endif
   constexpr int kExpandBatch = I3RC_EXPAND_BATCH;   // an expand phase runs when the ready buffer has room for this many rays
-  // DIRECT: rays are traced once this many survivors are ready (an event phase adds at most 64 to fewer than that: the store
-  // of 128 never overflows), and the wave goes back to its photons when nothing is left to hand out and fewer than
+  // DIRECT: rays are traced once this many survivors are ready (or when the next event phase's rays would not fit into the store
+  // of 128: wantSlots), and the wave goes back to its photons when nothing is left to hand out and fewer than
   // kDirectLeave rays are still under way (those few go back to the store: with rays of one or two voxel steps, a wave that
   // left with a wavefront's worth under way -- the ring mode's rule -- would write back and take up again most of its rays)
 #ifndef I3RC_DIRECT_ENTER
-#define I3RC_DIRECT_ENTER 64
+#define I3RC_DIRECT_ENTER 96   /* (radar-64 + nadir, 5e7 photons: 64 -> 59.1 ms, 80 -> 58.8, 96 -> 58.2, 112 -> 58.3; leave level 8 ... 48: within 1 %) */
 #endif
 #ifndef I3RC_DIRECT_LEAVE
 #define I3RC_DIRECT_LEAVE 24
 #endif
   constexpr int kDirectEnter = I3RC_DIRECT_ENTER, kDirectLeave = I3RC_DIRECT_LEAVE;
-  static_assert(!DIRECT || (kDirectReady >= kDirectEnter + 64 && (kDirectReady & (kDirectReady - 1)) == 0), "the ready store must take an event phase's rays on top of the entry level");
+  // (an event phase that would not fit -- possible when kDirectEnter is set above kDirectReady - 64 -- sends the wave to its rays first: wantSlots)
+  static_assert(!DIRECT || (kDirectReady >= kDirectEnter && (kDirectReady & (kDirectReady - 1)) == 0), "the ready store holds the entry level; a power of two");
   constexpr int kLowWater = I3RC_LOW_WATER, kStepAhead = I3RC_STEP_AHEAD, kPhotonStepAhead = I3RC_PHOTON_STEP_AHEAD;
   bool wantSlots = false, photonsLeft = true;         // wave-uniform
   unsigned qTail = 0u, qHeadEv = 0u, qHeadSub = 0u;   // events pushed / events expanded completely / rays expanded of event qHeadEv
@@ -829,9 +842,13 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
               sInfo = __float_as_int(in[6 * kReady]);
               sW = in[7 * kReady]; sNorm = in[8 * kReady]; sTauFree = in[9 * kReady];
               sr.target = in[10 * kReady]; sr.acc = in[11 * kReady];
+#ifdef I3RC_NO_DIRTAB   /* (measurement knob: the direction's derived values worked out at every ray start, as before round 4) */
               const int dIdx = (sInfo >> 8) & 0xff;
               sr.dx = L.dirCos[3 * dIdx]; sr.dy = L.dirCos[3 * dIdx + 1]; sr.dz = L.dirCos[3 * dIdx + 2];
               sr.set_direction(L);
+#else
+              sr.load_direction(L.dirTab + 16 * ((sInfo >> 8) & 0xff));
+#endif
               rst = R_TRACE;
             }
             rdHead += (unsigned)take;

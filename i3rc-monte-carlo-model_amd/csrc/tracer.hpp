@@ -115,6 +115,7 @@ struct Lds {
   lds_float *tUp, *tDown, *tAbs;  // privatised flux tallies (valid when ldsTallies)
   lds_float *ext;             // totalExt copy (valid when ldsGrid); bricked fields: the clear-air map (DevProblem::clearMap) as words
   lds_float *dirCos;          // intensity directions
+  lds_float *dirTab;          // ... and, per direction, what a ray of that direction derives from it (Ray::set_direction), 16 words: see photon_kernel
   lds_float *tInt;            // privatised intensityByComponent (valid when ldsIntensity)
   lds_float *cosTab;          // the inverse table's cosines (one entry) where a kernel keeps them in LDS (photon_kernel, TBL)
   lds_float *queue;           // [waves][kRecWords][rayQueueCap]: every wave's ring of local-estimate events (see kernels.hpp)
@@ -247,6 +248,21 @@ struct Ray {
     ex = lds_address(L.xE) - (px ? 0 : 4); ey = lds_address(L.yE) - (py ? 0 : 4); ez = lds_address(L.zE) - (pz ? 0 : 4);
     cx = px ? 1 : -1; cy = py ? 1 : -1; cz = pz ? 1 : -1;
     nudge = px ? 2.0f : -2.0f;
+  }
+  // the same from a radiance direction's entry of Lds::dirTab (written once per workgroup by store_direction): four 128-bit LDS
+  // reads instead of three reciprocals with their refinements and a dozen selects at every start of a local-estimate ray
+  __device__ __forceinline__ void store_direction(lds_float *t) const {
+    t[0] = dx; t[1] = dy; t[2] = dz; t[3] = nudge; t[4] = rx; t[5] = ry; t[6] = rz; t[7] = __int_as_float(slow);
+    t[8] = __int_as_float(ex); t[9] = __int_as_float(ey); t[10] = __int_as_float(ez); t[11] = __int_as_float(cx);
+    t[12] = __int_as_float(cy); t[13] = __int_as_float(cz); t[14] = 0.0f; t[15] = 0.0f;
+  }
+  __device__ __forceinline__ void load_direction(const lds_float *t) {
+    typedef float vec4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const vec4 lds_vec4;
+    const vec4 a = ((lds_vec4 *)t)[0], b = ((lds_vec4 *)t)[1], c = ((lds_vec4 *)t)[2], d = ((lds_vec4 *)t)[3];
+    dx = a.x; dy = a.y; dz = a.z; nudge = a.w; rx = b.x; ry = b.y; rz = b.z; slow = __float_as_int(b.w);
+    ex = __float_as_int(c.x); ey = __float_as_int(c.y); ez = __float_as_int(c.z); cx = __float_as_int(c.w);
+    cy = __float_as_int(d.x); cz = __float_as_int(d.y);
   }
 };
 

@@ -68,9 +68,10 @@ def test_production_kernels_keep_their_state_in_registers():
     everything = resources()
     # every PhiloxStream instantiation, the table-in-LDS ones among them: BENCH's headline (step cloud) and Landsat-36 run those
     rows = [r for r in everything if r["name"].startswith("photon_kernel<PhiloxStream")]
-    assert len(rows) == 15 and sum("table in LDS" in r["name"] for r in rows) == 3, [r["name"] for r in rows]
-    fused = [r for r in everything if r["name"].startswith("photon_kernel<PhiloxBatchStream")]   # the fused multi-batch flux kernels
-    assert len(fused) == 5, [r["name"] for r in fused]
+    # (round 4: ... and the radiance kernels without an event ring, "one direction")
+    assert len(rows) == 21 and sum("table in LDS" in r["name"] for r in rows) == 3 and sum("one direction" in r["name"] for r in rows) == 6, [r["name"] for r in rows]
+    fused = [r for r in everything if r["name"].startswith("photon_kernel<PhiloxBatchStream")]   # the fused multi-batch kernels: five flux, six radiance (round 4)
+    assert len(fused) == 11 and sum(r["name"].startswith("photon_kernel<PhiloxBatchStream, true") for r in fused) == 6, [r["name"] for r in fused]
     for r in rows + fused:
         if r in fused and "table in LDS" in r["name"]:
             # the fused kernels want 66 vector registers; their table-in-LDS instantiations (1024 threads, two workgroups per CU: eight
