@@ -163,13 +163,18 @@ int i3rc_hip_launch_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1
  * the order of the float64 additions.
  * A batch ends with a long tail -- the few photons of a million that scatter a thousand times keep a handful of
  * wavefronts busy for a millisecond --, so batches of the reference drivers' size (1e5 ... 1e6 photons) must overlap:
- *   - FUSED (flux problems of the common class: regular x / y grid, ray tracing, one component, no BRDF grid, no radiance
- *     directions; two batches or more of at most 2e7 photons): a group of consecutive batches is ONE kernel launch
- *     (photon_kernel<PhiloxBatchStream, ...>).  Every lane carries the batch of its photon in its Philox key, tallies
- *     go to per-batch blocks in global memory (spread over replicas where a domain has few columns), work counters are
- *     gathered per lane and handed over per batch: one batch's tail is filled by the next batch's photons inside the
- *     launch.  Groups hold about 2.5e8 photons (bounded by 1 GiB of tally blocks), up to three groups are in flight.  Step
- *     cloud, 1e6-photon batches: 0.34 ms per batch (2.9e9 photons/s) against 1.6 ms one call at a time.
+ *   - FUSED (problems of the common class: regular x / y grid, ray tracing, one component, no BRDF grid -- with or, since
+ *     round 4, without radiance directions; two batches or more of at most 2e7 photons): a group of consecutive batches is
+ *     ONE kernel launch (photon_kernel<PhiloxBatchStream, ...>).  Every lane carries the batch of its photon in its Philox
+ *     key, a local-estimate ray the batch of its photon in its info word; tallies go to per-batch blocks in global memory
+ *     (spread over replicas where a domain has few columns): one batch's tail is filled by the next batch's photons
+ *     inside the launch.  Groups hold about 2.5e8 photons (bounded by 1 GiB of tally blocks), up to three groups are in
+ *     flight.  Work counters: flux problems gather them per lane and hand them over per batch -- every counter of a batch is
+ *     what a launch of its own gives.  Radiance kernels have no register for that: photons and dropped photons (what the
+ *     normalisation needs) are exact per batch, their other counters (steps, scatterings, ray starts ...) are counted per
+ *     wavefront and handed to the batch the wavefront was given last -- exact over the batches of a group, not per batch.
+ *     The TALLIES are per batch in every case.  Timings: profiles/r04_fused_timing.txt (step cloud, radar and Landsat fields,
+ *     with and without radiances, against one launch per batch).
  *   - otherwise up to inFlight batches (1..8; 0 = 6) are on the device at a time, each a launch on a HIP stream of its
  *     own with its own tally buffer (GPU_MAX_HW_QUEUES=8 in the environment gives these another 10-15 %).
  * i3rc_hip_set_batch_fusion chooses between the two.  Directional sources only (an explicit stream differs from batch
@@ -216,8 +221,10 @@ int i3rc_hip_run_batches_moments(i3rc_hip_integrator *h, uint32_t seed0, uint32_
  * (tables, parameters, surface, directions, tuning), calls the work launched ahead off -- fused groups poll an abort word
  * and end within one chunk per wavefront --, waits for it and forgets it: results never depend on the guess, a wrong
  * guess (and the end of the loop) costs the device a few milliseconds.  So does i3rc_hip_destroy.  Launches made ahead are
- * not recorded in i3rc_hip_kernel_ms_history.  Unchanged reference driver, 1000 batches of 1e6 photons on the step
- * cloud, process start to result files: 2.2 s (one launch per call) -> 0.8 s.  Directional sources only.  Synchronous. */
+ * not recorded in i3rc_hip_kernel_ms_history.  A loop that is only guessed at keeps each of its three slots within 96 MiB of
+ * pinned memory (groups of a Landsat-sized field then hold 18 batches); a group that cannot be launched for want of memory is
+ * not tried again at every call -- such a loop goes on with single batches launched ahead.  The unchanged reference driver
+ * end to end: profiles/r04_driver_timing.txt.  Directional sources only.  Synchronous. */
 int i3rc_hip_compute_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int64_t nPhotons,
                            const i3rc_source *src, int lookAhead, double *hostTallies);
 
@@ -225,10 +232,11 @@ int i3rc_hip_compute_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed
  * with the seed words seed1, seed1 + 1 ... seed1 + nBatches - 1 (nPhotons photons each, this sun), one
  * i3rc_hip_compute_batch call per batch, in this order.  On problems whose batches can share a grid (see
  * i3rc_hip_run_batches) the library starts tracing them at once, in fused groups of 32, 64, 128, 256 ... batches, three groups
- * under way at a time and none beyond the announced loop; *accepted is 1.  The calls then find their batches done or under
+ * under way at a time and none beyond the announced loop (their slots are made for the loop's largest group at once); *accepted is 1.  The calls then find their batches done or under
  * way while the caller works on the ones it has: the shell's computeRadiativeTransferBatches / selectBatchResults stream
- * a driver's loop this way.  On other problems nothing happens and *accepted is 0: i3rc_hip_run_batches (or the calls'
- * own look-ahead) serves those.  A call for any other batch, and every change of the problem, calls the announced work
+ * a driver's loop this way.  On other problems -- and when the first group cannot be launched (memory: the reason stays in
+ * i3rc_hip_last_error) -- nothing happens, the call returns 0 and *accepted is 0: i3rc_hip_run_batches (or the calls' own
+ * look-ahead) serves those.  A call for any other batch, and every change of the problem, calls the announced work
  * off, as for any look-ahead.  Asynchronous. */
 int i3rc_hip_expect_batches(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int nBatches, int64_t nPhotons,
                             const i3rc_source *src, int *accepted);
