@@ -1069,6 +1069,7 @@ int fused_group_size(const i3rc_hip_integrator *h, int nBatches, int64_t nPhoton
   if (!moments) g = std::min<int64_t>(g, ((int64_t)256 << 20) / blockBytes);   // (moments mode: no pinned copy of the blocks)
   static const int64_t target = std::getenv("I3RC_FUSED_GROUP_PHOTONS") ? std::atoll(std::getenv("I3RC_FUSED_GROUP_PHOTONS")) : 250000000ll;
   g = std::min<int64_t>(g, (target + nPhotons - 1) / nPhotons);
+  if (h->nDir > 0) g = std::min<int64_t>(g, 8192);   // (a local-estimate ray carries its batch in 13 bits of its info word: photon_kernel, make_ray)
   return (int)std::max<int64_t>(1, std::min<int64_t>(g, nBatches));
 }
 

@@ -636,7 +636,9 @@ def test_fused_batches_equal_one_launch_per_batch():
                 ("step cloud, three radiances, hybrid tables, limit", cases.step_cloud(ssa=0.95, nlayers=8), full, 0.7, [(20000, 7), (50, 5), (777, 33)]),
                 ("step cloud, nadir radiance, plain local estimate", cases.step_cloud(ssa=0.95, nlayers=8), dict(intensityMus=[1.0], intensityPhis=[0.0], surfaceAlbedo=0.2), 0.7, [(20000, 7), (60, 9)]),
                 ("radar field, nadir radiance (one direction: no ring)", cases.radar_cloud(), dict(rri, intensityMus=[1.0], intensityPhis=[0.0], surfaceAlbedo=0.1), 0.9, [(20000, 5), (3000, 24)]),
-                ("Landsat field (bricks), two radiances", cases.landsat_cloud(ssa=0.98), dict(rri, intensityMus=[0.8, 0.3], intensityPhis=[90.0, 225.0], surfaceAlbedo=0.2), 0.5, [(15000, 3)])]
+                ("Landsat field (bricks), two radiances", cases.landsat_cloud(ssa=0.98), dict(rri, intensityMus=[0.8, 0.3], intensityPhis=[90.0, 225.0], surfaceAlbedo=0.2), 0.5, [(15000, 3)]),
+                # (a ray carries its batch in 13 bits: a loop of more than 8192 tiny batches on a tiny domain is cut into groups within that)
+                ("one column, nadir radiance, 8300 batches of 33 photons", cases.plane_parallel(optical_depth=2.0, ssa=0.9), dict(rri, intensityMus=[1.0], intensityPhis=[0.0], surfaceAlbedo=0.3), 0.6, [(33, 8300)])]
     for what, d, params, mu0, runs in problems:
         g = make_gpu(d, hg_table(), **params)
         rad = g if "intensityMus" in params else None
