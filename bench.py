@@ -52,8 +52,8 @@ def parse_args():
     ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
                     help="default: N = 1 -> the same thing; N > 1 -> strong (ONE batch of --photons photons per step sharded over the GPUs: the "
                          "metric's case) as the headline, the weak figure measured after it and reported beside it")
-    ap.add_argument("--overlap", choices=("auto", "0", "1", "2"), default="auto",
-                    help="1: two steps in flight (two handles / streams / tally buffers), 2: three; auto = three for N > 1, else one")
+    ap.add_argument("--overlap", choices=("auto", "0", "1", "2", "3", "4"), default="auto",
+                    help="k: k + 1 steps in flight (as many handles / streams / tally buffers); auto = three steps in flight for N > 1, else one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--contact-timeout", type=float, default=float(os.environ.get("I3RC_BENCH_CONTACT_TIMEOUT", "180")),
                     help="N > 1: seconds every rank has for init_process_group and a first all-reduce before the run is called off (naming the rank)")
@@ -335,7 +335,7 @@ def worker(a):
     # its all-reduce overlap the trace of step k + 1.  Every step still zeroes, traces and reduces its own buffer.
     overlap = (n_gpus > 1) if a.overlap == "auto" else (a.overlap != "0")
     lanes = []
-    for k in range(1 if not overlap else (2 if a.overlap == "1" else 3)):   # (auto, N > 1: three -- the shard of an 8-GPU run on one GPU: 0.76 / 0.88 / 0.92 of the whole batch's rate with 1 / 2 / 3)
+    for k in range(1 if not overlap else (3 if a.overlap == "auto" else int(a.overlap) + 1)):   # (auto, N > 1: three -- the shard of an 8-GPU run on one GPU: 0.76 / 0.88 / 0.92 of the whole batch's rate with 1 / 2 / 3)
         integ, d = W.make_integrator(w, device=local_rank)
         lay = integ.layout()
         tally = torch.zeros(lay.total, dtype=torch.float64, device="cuda")
