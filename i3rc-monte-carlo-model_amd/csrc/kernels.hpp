@@ -417,7 +417,11 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
   // Work counters of a fused launch.  Flux kernels: exact per batch, gathered per lane (below).  Radiance kernels have no
   // vector register to spare for that: their counters stay per WAVE and are handed to the batch whose photons the wave was
   // given last -- photons and dropped photons (what the normalisation needs) are exact per batch, the others over the group.
+#ifdef I3RC_FUSED_WAVE_COUNTS   /* (measurement knob: the fused flux kernels count per wavefront as the radiance kernels do) */
+  constexpr bool LANE_COUNTS = false;
+#else
   constexpr bool LANE_COUNTS = BATCHED && !INTENSITY;
+#endif
   constexpr bool NEED_PID = REPLAY || GENERAL; // explicit photon sources are indexed by photon number
   const size_t ncell = (size_t)P.nx * P.ny * P.nz;
   const bool rayTracing = GENERAL ? (P.useRayTracing != 0) : true;
@@ -625,7 +629,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
   auto flush_counters = [&]() {
     adapt_thresholds();
     raysSeen = 0u;
-    if constexpr (BATCHED && INTENSITY) {   // per wave, to the batch in hand (LANE_COUNTS above)
+    if constexpr (BATCHED && !LANE_COUNTS) {   // per wave, to the batch in hand (LANE_COUNTS above)
       uint32_t draws = rng.take_used();
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) draws += (uint32_t)__shfl_xor((int)draws, off, 64);

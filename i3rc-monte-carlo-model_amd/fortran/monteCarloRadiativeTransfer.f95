@@ -711,6 +711,7 @@ contains
       return
     end if
     thisIntegrator%momentBatches    = numBatches
+    thisIntegrator%resultsValid     = .false.      ! (no single batch is current after this call: reportResults says so)
     thisIntegrator%photonsProcessed = counters(1 + I3RC_CNT_PHOTONS)
     thisIntegrator%photonsDropped   = counters(1 + I3RC_CNT_DROPPED)
     if(thisIntegrator%photonsProcessed > 0.d0) then
@@ -830,9 +831,11 @@ contains
       call setStateToFailure(status, "reportResults: integrator hasn't been initialized.")
       return
     end if
-    if(.not. thisIntegrator%resultsValid .and. associated(thisIntegrator%batchTallies)) then
-      ! a streamed loop has been announced (computeRadiativeTransferBatches) and none of its batches selected yet
-      call setStateToFailure(status, "reportResults: no batch of the loop has been selected (selectBatchResults).")
+    if(.not. thisIntegrator%resultsValid .and. (associated(thisIntegrator%batchTallies) .or. associated(thisIntegrator%momentSums))) then
+      ! a streamed loop has been announced (computeRadiativeTransferBatches) and none of its batches selected yet, or the last
+      ! call gathered batch moments (computeRadiativeTransferBatchMoments: reportBatchMoments reports those): no single batch is
+      ! current, and an earlier call's numbers are not this call's
+      call setStateToFailure(status, "reportResults: no batch is current (selectBatchResults / reportBatchMoments).")
       return
     end if
     nColumns = size(thisIntegrator%fluxUp)

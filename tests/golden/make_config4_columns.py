@@ -50,12 +50,21 @@ def main():
     counters = np.array([c for _, c in res], np.int64)
     mean = fields.mean(0)
     se = fields.std(0, ddof=1) / np.sqrt(len(fields))
+    # The per-column statistic on the oracle against ITSELF (odd batches against even ones): what z = |difference| / combined
+    # standard error looks like on two samples of the same code when a column sees thirty photons per batch and a radiance is made
+    # of a few large contributions among many small ones -- the baseline the GPU-against-fixture figures are read against.
+    # Per field: share of columns within 3 sigma, mean of z^2, largest z.
+    a, b = fields[0::2], fields[1::2]
+    zz = np.abs(a.mean(0) - b.mean(0)) / (np.sqrt(a.var(0, ddof=1) / len(a) + b.var(0, ddof=1) / len(b)) + 1e-7)
+    self_check = np.stack([(zz <= 3.0).mean(axis=(1, 2)), (zz ** 2).mean(axis=(1, 2)), zz.max(axis=(1, 2))], axis=1)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "config4_columns.npz"),
                         mean=mean.astype(np.float32), stderr=se.astype(np.float32),
                         batchMeans=fields.mean(axis=(2, 3)),   # [nb][9]: fluxUp, fluxDown, radiance 1..7
+                        selfCheck=self_check,                  # [9][3]: odd against even batches (see above)
                         counters=counters, counterNames=np.array(["nBad", "cellSteps", "scatterings", "tracerCalls"]),
                         photonsPerBatch=np.int64(photons), batches=np.int64(len(fields)), config=np.array(CONFIG),
                         fieldNames=np.array(["fluxUp", "fluxDown"] + [f"intensity{d + 1}" for d in range(7)]))
+    print("odd against even batches, per field (share within 3 sigma, mean z^2, max z):", np.round(self_check, 3).tolist())
     print(f"{len(fields)} batches x {photons} photons in {time.time() - t0:.0f} s on {cores} cores; mean fluxUp {mean[0].mean():.5f} "
           f"fluxDown {mean[1].mean():.5f} radiances {[round(float(v), 5) for v in mean[2:].mean(axis=(1, 2))]}")
 

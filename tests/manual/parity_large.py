@@ -22,8 +22,11 @@ PLAN = {
     "step16": (100, 1_000_000, 8, 400_000),          # 1e8 on the GPU, 5.1e7 in the oracle (~7 s)
     "radar64_nadir": (100, 1_000_000, 8, 150_000),   # 1e8 / 1.9e7 (~10 s)
     "landsat36": (100, 1_000_000, 8, 250_000),       # 1e8 / 3.2e7 (~9 s)
+    "landsat36_absorbing": (100, 1_000_000, 8, 250_000),   # omega = 0.99 in the cloudy cells: absorption tallies, the shared-omega argument
     "landsat119_7dir": (100, 250_000, 8, 40_000),    # 2.5e7 / 5.1e6 (~20 s)
 }
+# (round 4) per-column fields of every workload (the oracle child saves them whatever the size of the domain), and config 4 also
+# against the oracle's committed fixture of 2.4e7 photons (tests/golden/config4_columns.npz), with 1e8 photons on the GPU
 
 
 def z_of(a, b):
@@ -51,7 +54,7 @@ def main():
         out = os.path.join(tempfile.mkdtemp(), f"oracle_{name}.npz")
         t0 = time.perf_counter()
         child = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--config", name, "--cores", str(cores),
-                                  "--batches-per-core", str(per_core), "--photons", str(n_ref), "--save", out],
+                                  "--batches-per-core", str(per_core), "--photons", str(n_ref), "--save", out, "--save-columns"],
                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         g, _ = W.make_integrator(w)
         rs = [g.computeRadiativeTransfer(M.new_RandomNumberSequence((91, b)), M.new_PhotonStream(w["mu0"], 0.0, n)) for b in range(1, nb + 1)]
@@ -76,7 +79,7 @@ def main():
             worst = max(worst, abs(zz))
             print(f"   mean radiance {d} (mu {w['params']['intensityMus'][d]:+.1f}, phi {w['params']['intensityPhis'][d]:5.1f})"
                   f"  GPU {a:.6f}  oracle {b:.6f}  combined se {s:.2e}  z {zz:+.2f}")
-        for key in ("fluxUp", "fluxDown") + (("intensity",) if nd else ()):
+        for key in ("fluxUp", "fluxDown", "fluxAbsorbed") + (("intensity",) if nd else ()):
             if key in z.files:
                 frac, zmax, cnt = columns([r[key] for r in rs], list(z[key]))
                 print(f"   columns {key:10s} {cnt} values: {100 * frac:.2f} % within 3 sigma, max |z| {zmax:.2f}")
@@ -87,7 +90,53 @@ def main():
         print(f"   per photon: dropped GPU {dg:.3e} oracle {do:.3e}; scatterings {kg:.4f} / {ko:.4f}; tracer steps {sg:.2f} / "
               f"{z['cellSteps'].sum() / n_o:.2f} (GPU leaves out rays whose roulette is lost before the trace: "
               f"{sum(r['counters']['raysSkipped'] for r in rs) / n_g:.3f} per photon)", flush=True)
+    if "landsat119_7dir" in names:
+        fixture_columns(M)
     print(f"largest |z| of a domain mean: {worst:.2f}")
+
+
+def fixture_columns(M):
+    """Config 4 at 1e8 photons on the GPU against the oracle's fixture, column by column."""
+    from scipy import stats
+    z = np.load(os.path.join(ROOT, "tests", "golden", "config4_columns.npz"))
+    _, w = W.get("landsat119_7dir")
+    g, _ = W.make_integrator(w)
+    nb, n = 100, 1_000_000
+    t0 = time.perf_counter()
+    acc1 = acc2 = 0.0
+    for b in range(1, nb + 1):
+        r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((92, b)), M.new_PhotonStream(w["mu0"], 0.0, n))
+        f = np.concatenate([r["fluxUp"][None], r["fluxDown"][None], r["intensity"]]).astype(np.float64)
+        acc1 = acc1 + f; acc2 = acc2 + f * f
+    g.finalize_Integrator()
+    mg = acc1 / nb
+    sg = np.sqrt(np.maximum(acc2 / nb - mg * mg, 0.0) / (nb - 1))
+    # The same statistic with the GPU in the fixture's place: 48 batches of 5e5 GPU photons (other seeds) against the 1e8 -- two
+    # samples of ONE code, as unequal as fixture and GPU are.  A sample of 48 skewed batch means against a much larger one is nearly a
+    # one-sample t statistic, which skewness inflates (the balanced odd-against-even check in the fixture, selfCheck, is not):
+    # what this pair shows is what the statistic does by itself; what the fixture shows beyond it would be a difference.
+    g, _ = W.make_integrator(w)
+    nbf, nf = int(z["batches"]), int(z["photonsPerBatch"])
+    f1 = f2 = 0.0
+    for b in range(1, nbf + 1):
+        r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((93, b)), M.new_PhotonStream(w["mu0"], 0.0, nf))
+        f = np.concatenate([r["fluxUp"][None], r["fluxDown"][None], r["intensity"]]).astype(np.float64)
+        f1 = f1 + f; f2 = f2 + f * f
+    g.finalize_Integrator()
+    mf = f1 / nbf
+    sf = np.sqrt(np.maximum(f2 / nbf - mf * mf, 0.0) / (nbf - 1))
+    # Welch-Satterthwaite: with the GPU's standard errors half the fixture's, the fixture's 47 degrees of freedom dominate
+    dof = nbf - 1
+    print(f"== landsat119_7dir against tests/golden/config4_columns.npz: GPU {nb} x {n} = {nb * n:.3g} photons ({time.perf_counter() - t0:.1f} s), "
+          f"oracle fixture {nbf} x {nf} = {nbf * nf:.3g} photons; Student's t with about {dof} degrees of freedom expects "
+          f"{100 * (1 - 2 * stats.t.sf(3.0, dof)):.2f} % within 3 sigma and mean z^2 {dof / (dof - 2):.3f} of Gaussian batch means")
+    for k, name in enumerate(z["fieldNames"]):
+        zz = np.abs(mg[k] - z["mean"][k]) / (np.sqrt(sg[k] ** 2 + z["stderr"][k].astype(np.float64) ** 2) + 1e-7)
+        zs = np.abs(mg[k] - mf[k]) / (np.sqrt(sg[k] ** 2 + sf[k] ** 2) + 1e-7)
+        sc = z["selfCheck"][k] if "selfCheck" in z.files else (np.nan, np.nan, np.nan)
+        print(f"   columns {str(name):10s} {zz.size} values: {100 * (zz <= 3.0).mean():.2f} % within 3 sigma, max |z| {zz.max():.2f}, mean z^2 {np.mean(zz ** 2):.3f} "
+              f"| GPU sample of the fixture's size in its place: {100 * (zs <= 3.0).mean():.2f} %, {zs.max():.2f}, {np.mean(zs ** 2):.3f} "
+              f"| oracle odd against even batches: {100 * sc[0]:.2f} %, {sc[2]:.2f}, {sc[1]:.3f}; domain mean GPU {mg[k].mean():.6f} fixture {z['mean'][k].mean(dtype=np.float64):.6f}")
 
 
 if __name__ == "__main__":

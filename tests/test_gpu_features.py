@@ -400,9 +400,10 @@ def test_results_do_not_depend_on_the_schedule(oracle):
                 numOrdersOrigPhaseFunIntenCalcs=1, limitIntensityContributions=True, maxIntensityContribution=0.5)
     for name, d, tab in (("two components", cases.two_component(), t2), ("irregular", cases.irregular_domain(), hg_table()),
                          ("irregular, thin and elevated", cases.irregular_domain(z0=100.0), hg_table())):
-        for params in (full, dict(full, useRayTracing=False)):
+        # (... with one direction too: the general kernels without an event ring, against the ring)
+        for params in (full, dict(full, useRayTracing=False), dict(full, intensityMus=[0.8], intensityPhis=[200.0])):
             seen = []
-            for tune in tunings[:4] + [dict(evThreshold=24, lightThreshold=8)]:
+            for tune in tunings[:4] + [dict(evThreshold=24, lightThreshold=8), dict(evThreshold=24, kernel="ring")]:
                 g = make_gpu(d, tab, **params)
                 g.set_tuning(**tune)
                 r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 1)), M.new_PhotonStream(0.7, 25.0, 100000))
