@@ -13,7 +13,12 @@
 //     ring holds a wavefront's worth of local-estimate (shadow) rays the wave changes to RAY MODE: all lanes turn
 //     (event, direction) pairs into ready rays (a ray whose roulette is already lost is dropped there), lanes take a
 //     ready ray as soon as theirs has ended -- shadow rays run with nearly full wavefronts, independent of the photons
-//     that caused them;
+//     that caused them; with ONE radiance direction (an event is one ray, and the roulette ends most rays where they are made) there
+//     is no ring: the event phase makes its event's ray ready itself and only survivors go to LDS, into a ready store of two
+//     wavefronts (template parameter DIRECT);
+//   * the batches of a driver's loop share ONE grid (PhiloxBatchStream: a lane carries its photon's batch in its Philox key, a
+//     local-estimate ray in its info word; per-batch tally blocks in global memory), so that one batch's tail -- the few photons
+//     with a thousand scatterings -- is filled by the next batch's photons;
 //   * cell edges (and, when they fit, the extinction grid) are staged in LDS with coalesced loads; grids beyond an
 //     XCD's L2 are read from a copy in 32-cell bricks; flux and radiance tallies are privatised per workgroup in LDS
 //     (ds_add_f32) and flushed once with float64 atomics; large domains tally straight to HBM with float64 atomics;
