@@ -734,7 +734,8 @@ contains
     real, dimension(:, :, :, :), optional, intent(  out) :: intensityStats                                  ! (nx, ny, nDir, 2)
     type(ErrorMessage),                    intent(inout) :: status
     type(i3rc_moments_layout) :: layout
-    integer :: nx, ny, nz, nDir
+    integer :: nx, ny, nz, nDir, i, j, k
+    integer(c_int64_t) :: at
 
     if(.not. associated(thisIntegrator%momentSums)) then
       call setStateToFailure(status, "reportBatchMoments: no batch moments have been computed.")
@@ -767,8 +768,16 @@ contains
       if(any(shape(volumeAbsorptionStats) /= (/ nx, ny, nz, 2 /))) then
         call setStateToFailure(status, "reportBatchMoments: volumeAbsorptionStats array is the wrong size")
       else
-        volumeAbsorptionStats(:, :, :, 1) = reshape(real(thisIntegrator%momentSums   (layout%volumeAbsorption + 1:layout%volumeAbsorption + nx * ny * nz)), (/ nx, ny, nz /))
-        volumeAbsorptionStats(:, :, :, 2) = reshape(real(thisIntegrator%momentSquares(layout%volumeAbsorption + 1:layout%volumeAbsorption + nx * ny * nz)), (/ nx, ny, nz /))
+        ! (element by element: a cloud field's volume is millions of cells, and array-valued temporaries of that size have no place on a stack)
+        do k = 1, nz
+          do j = 1, ny
+            do i = 1, nx
+              at = layout%volumeAbsorption + i + nx * ((j - 1) + ny * (k - 1))
+              volumeAbsorptionStats(i, j, k, 1) = real(thisIntegrator%momentSums(at))
+              volumeAbsorptionStats(i, j, k, 2) = real(thisIntegrator%momentSquares(at))
+            end do
+          end do
+        end do
       end if
     end if
     if(present(meanIntensityStats)) then
@@ -787,8 +796,15 @@ contains
       else if(any(shape(intensityStats) /= (/ nx, ny, nDir, 2 /))) then
         call setStateToFailure(status, "reportBatchMoments: intensity array has wrong dimensions.")
       else
-        intensityStats(:, :, :, 1) = reshape(real(thisIntegrator%momentSums   (layout%intensity + 1:layout%intensity + nx * ny * nDir)), (/ nx, ny, nDir /))
-        intensityStats(:, :, :, 2) = reshape(real(thisIntegrator%momentSquares(layout%intensity + 1:layout%intensity + nx * ny * nDir)), (/ nx, ny, nDir /))
+        do k = 1, nDir
+          do j = 1, ny
+            do i = 1, nx
+              at = layout%intensity + i + nx * ((j - 1) + ny * (k - 1))
+              intensityStats(i, j, k, 1) = real(thisIntegrator%momentSums(at))
+              intensityStats(i, j, k, 2) = real(thisIntegrator%momentSquares(at))
+            end do
+          end do
+        end do
       end if
     end if
     if(.not. stateIsFailure(status)) call setStateToSuccess(status)
@@ -803,11 +819,16 @@ contains
       integer,                  intent(in ) :: n
       real, dimension(:, :, :), intent(out) :: to
       character(len = *),       intent(in ) :: name
+      integer :: ii, jj
       if(any(shape(to) /= (/ nx, ny, 2 /))) then
         call setStateToFailure(status, "reportBatchMoments: " // name // " array is the wrong size")
       else
-        to(:, :, 1) = reshape(real(thisIntegrator%momentSums   (at + 1:at + n)), (/ nx, ny /))
-        to(:, :, 2) = reshape(real(thisIntegrator%momentSquares(at + 1:at + n)), (/ nx, ny /))
+        do jj = 1, ny
+          do ii = 1, nx
+            to(ii, jj, 1) = real(thisIntegrator%momentSums   (at + ii + nx * (jj - 1)))
+            to(ii, jj, 2) = real(thisIntegrator%momentSquares(at + ii + nx * (jj - 1)))
+          end do
+        end do
       end if
     end subroutine fieldMoments
   end subroutine reportBatchMoments
