@@ -55,7 +55,7 @@ def parse_args():
     ap.add_argument("--overlap", choices=("auto", "0", "1", "2", "3", "4"), default="auto",
                     help="k: k + 1 steps in flight (as many handles / streams / tally buffers); auto = three steps in flight for N > 1, else one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--contact-timeout", type=float, default=float(os.environ.get("I3RC_BENCH_CONTACT_TIMEOUT", "180")),
+    ap.add_argument("--contact-timeout", type=float, default=float(os.environ.get("I3RC_BENCH_CONTACT_TIMEOUT", "300")),
                     help="N > 1: seconds every rank has for init_process_group and a first all-reduce before the run is called off (naming the rank)")
     ap.add_argument("--contact-only", action="store_true", help="N > 1: stop after the first-contact check (process group up, one all-reduce on every rank)")
     ap.add_argument("--scale-photons", type=float, default=1.0,
