@@ -139,9 +139,10 @@ struct i3rc_hip_integrator {
   bool aheadBounded = false;       // i3rc_hip_expect_batches: the caller has announced its loop -- nothing is launched beyond
   uint32_t aheadEnd = 0;           // ... this seed word (exclusive)
   int fusion = -1;                 // -1: automatic, 0: never fuse, 1: fuse whatever the batch size (i3rc_hip_set_batch_fusion)
-  bool fusedAheadFailed = false;
-  // i3rc_hip_run_batches_moments: sums and sums of squares over a loop's batches, accumulated on the device
-  DevBuf momSum, momSq, momCounters, momArea, momDz;   // a fused group could not be launched ahead (memory): look ahead with single batches until the layout changes
+  bool fusedAheadFailed = false;   // a fused group could not be launched ahead (memory): look ahead with single batches until the layout changes
+  // i3rc_hip_run_batches_moments: sums and sums of squares over a loop's batches, accumulated on the device (momArea / momDz: what
+  // the normalisation needs of the grid -- column area fractions, layer depths)
+  DevBuf momSum, momSq, momCounters, momArea, momDz;
 
   // XCD-aware photon order (launch): the sorted photon numbers and the slab bookkeeping of a launch, per stream (launches
   // on different streams -- i3rc_hip_run_batches -- are in flight together)
