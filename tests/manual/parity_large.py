@@ -139,5 +139,47 @@ def fixture_columns(M):
               f"| oracle odd against even batches: {100 * sc[0]:.2f} %, {sc[2]:.2f}, {sc[1]:.3f}; domain mean GPU {mg[k].mean():.6f} fixture {z['mean'][k].mean(dtype=np.float64):.6f}")
 
 
+def full_size():
+    """BASELINE.json configs[3] and [4] at their FULL size -- 1e9 photons, as 1000 batches of 1e6 through the batch-moments entry
+    point (no per-batch block leaves the device) -- on one GPU: size-independent properties (photon count, energy closure with the
+    dropped-photon deficit) and, for config 4, every column against the oracle's fixture."""
+    import i3rc_monte_carlo_model_amd as M
+    from scipy import stats
+
+    nb, n = 1000, 1_000_000
+    for name in ("landsat36", "landsat119_7dir"):
+        _, w = W.get(name)
+        g, _ = W.make_integrator(w)
+        t0 = time.perf_counter()
+        s1, s2, cnt = g.computeRadiativeTransferBatchMoments((10, 1), nb, w["mu0"], 0.0, n)
+        dt = time.perf_counter() - t0
+        kernel = g.kernel_name()
+        g.finalize_Integrator()
+        mean = {k: np.asarray(v, np.float64) / nb for k, v in s1.items()}
+        se = {k: np.sqrt(np.maximum(np.asarray(s2[k], np.float64) / nb - mean[k] ** 2, 0.0) / (nb - 1)) for k in s1}
+        albedo = w.get("surface", 0.0)
+        closure = float(mean["meanFluxUp"] + mean["meanFluxAbsorbed"] + (1.0 - albedo) * mean["meanFluxDown"]) + cnt["dropped"] / cnt["photons"]
+        print(f"== {name} at BASELINE.json's full size: {nb} x {n} = {cnt['photons']:.4g} photons in {dt:.2f} s = {cnt['photons'] / dt:.3e} photons/s through "
+              f"computeRadiativeTransferBatchMoments ({kernel}); meanFluxUp {float(mean['meanFluxUp']):.6f} +- {float(se['meanFluxUp']):.1e}, "
+              f"meanFluxDown {float(mean['meanFluxDown']):.6f} +- {float(se['meanFluxDown']):.1e}; up + absorbed + (1 - albedo) down + dropped = {closure:.6f}; "
+              f"dropped {cnt['dropped'] / cnt['photons']:.3e}, scatterings per photon {cnt['scatterings'] / cnt['photons']:.4f}")
+        if name == "landsat119_7dir":
+            z = np.load(os.path.join(ROOT, "tests", "golden", "config4_columns.npz"))
+            mg = np.concatenate([mean["fluxUp"][None], mean["fluxDown"][None], mean["intensity"]])
+            sg = np.concatenate([se["fluxUp"][None], se["fluxDown"][None], se["intensity"]])
+            dof = int(z["batches"]) - 1
+            print(f"   against tests/golden/config4_columns.npz ({int(z['batches'])} x {int(z['photonsPerBatch'])} oracle photons; the GPU's standard errors are a sixth of the fixture's: "
+                  f"nearly a one-sample statistic, see above; t with {dof} degrees of freedom: {100 * (1 - 2 * stats.t.sf(3.0, dof)):.2f} %, mean z^2 {dof / (dof - 2):.3f}):")
+            for k, fname in enumerate(z["fieldNames"]):
+                zz = np.abs(mg[k] - z["mean"][k]) / (np.sqrt(sg[k] ** 2 + z["stderr"][k].astype(np.float64) ** 2) + 1e-7)
+                dm, fm = mg[k].mean(), z["mean"][k].mean(dtype=np.float64)
+                sem = np.std(z["batchMeans"][:, k], ddof=1) / np.sqrt(len(z["batchMeans"]))
+                print(f"   columns {str(fname):10s} {100 * (zz <= 3.0).mean():.2f} % within 3 sigma, max |z| {zz.max():.2f}, mean z^2 {np.mean(zz ** 2):.3f}; "
+                      f"domain mean GPU {dm:.6f} fixture {fm:.6f} +- {sem:.1e} (z {(dm - fm) / sem:+.2f})")
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["full"]:
+        full_size()
+    else:
+        main()
