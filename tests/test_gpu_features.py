@@ -624,3 +624,28 @@ def test_thirty_radiance_directions(oracle):
     o.specify(surfaceAlbedo=0.1, useRRForIntensity=1, zetaMin=0.3, **kw)
     _two_stage(oracle, g, o, 16, 10000, 0.8, ("fluxUp", "fluxDown", "intensity"), per_direction=True)
     g.finalize_Integrator()
+
+
+def test_environment_switches_of_the_round_4_kernels():
+    """I3RC_DIRECT=0 (one-direction radiance problems through the event ring) and I3RC_FUSED_RADIANCE=0 (radiance batches one launch
+    each) are read once per process: each in a child process, the same photons either way."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r)\n"
+            "import i3rc_monte_carlo_model_amd as M\nfrom tests import cases\nfrom tests.test_gpu_parity import make_gpu, hg_table\n"
+            "g = make_gpu(cases.step_cloud(ssa=0.97, nlayers=8), hg_table(), surfaceAlbedo=0.2, intensityMus=[0.9], intensityPhis=[30.0], useRussianRouletteForIntensity=True, zetaMin=0.3)\n"
+            "r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((4, 2)), M.new_PhotonStream(0.8, 10.0, 40000))\n"
+            "single = g.kernel_name()\n"
+            "b = g.computeRadiativeTransferBatches((4, 1), 5, 0.8, 10.0, 40000)\n"
+            "print(json.dumps([single, g.kernel_name(), r['counters']['shadowSteps'], float(r['intensity'].mean(dtype=np.float64)), float(b[1]['intensity'].mean(dtype=np.float64))]))\n") % root
+    out = {}
+    for name, env in (("default", {}), ("ring", {"I3RC_DIRECT": "0"}), ("unfused", {"I3RC_FUSED_RADIANCE": "0"})):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=280)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out[name] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert "one direction" in out["default"][0] and "PhiloxBatchStream" in out["default"][1] and "one direction" in out["default"][1]
+    assert "one direction" not in out["ring"][0] and "PhiloxBatchStream, true, false, GRID_LDS>" in out["ring"][1]
+    assert "PhiloxBatchStream" not in out["unfused"][1] and "one direction" in out["unfused"][1]
+    for name in ("ring", "unfused"):   # the same photons and rays: counters identical, radiances to the order of the additions
+        assert out[name][2] == out["default"][2]
+        assert abs(out[name][3] - out["default"][3]) <= 1e-6 * out["default"][3] and abs(out[name][4] - out["default"][4]) <= 1e-6 * out["default"][4]
