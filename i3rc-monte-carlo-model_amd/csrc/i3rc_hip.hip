@@ -72,6 +72,8 @@ struct i3rc_hip_integrator {
   DevBuf dExtBrick;              // totalExt in bricks of 32 cells (DevProblem::extBrick)
   DevBuf dClearMap;              // ... and its clear-air map (DevProblem::clearMap)
   int clearShift = 0, clearNx = 1, clearWords = 1;
+  DevBuf dColRec;                // one record per column where every column is one run of one value (DevProblem::colRec); else empty
+  int gridPlace = I3RC_GRID_AUTO;   // test / tuning knob (i3rc_hip_select_grid_place)
   bool compDirty = true;         // comp[] changed since its device copy (dComp) was made
   int bsx = 0, bsy = 0, bsz = 0, nbx = 0, nby = 0, nbz = 0;
   std::vector<DevBuf> dInv, dInvCos, dFwd, dFwdOrig;   // per component (sized by i3rc_hip_create)
@@ -125,6 +127,7 @@ struct i3rc_hip_integrator {
   struct FusedSlot {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
+    hipEvent_t traced = nullptr;   // the group's blocks are complete on the device (its copy to the host waits for this on the copy stream)
     DevBuf blocks, compact, counter, counterBlocks, excess;
     double *pinned = nullptr; size_t pinnedBytes = 0;
     int *abortFlag = nullptr;      // host-coherent word the kernel polls (RunArgs::abortFlag)
@@ -134,6 +137,10 @@ struct i3rc_hip_integrator {
   };
   static constexpr int kFusedSlots = 3;
   FusedSlot fused[kFusedSlots];
+  // The groups' copies to the host go over a stream of their own: a copy engine does not take compute units from the next group's
+  // kernel (kernels of two streams are time-sliced against each other, which is why the groups themselves share one stream), and
+  // a Landsat-sized group is 100-250 MB -- 4-10 ms of PCIe during which the next group's kernel used to wait in the queue.
+  hipStream_t fusedCopyStream = nullptr;
   std::vector<int> aheadGroups;    // look-ahead: slots of the groups launched ahead, oldest first
   int aheadGroupSize = 0;          // size of the next group to launch ahead (grows 8, 16, 32 ... 256)
   bool aheadBounded = false;       // i3rc_hip_expect_batches: the caller has announced its loop -- nothing is launched beyond
@@ -219,6 +226,7 @@ static void drop_lookahead(i3rc_hip_integrator *h) {
     (void)hipStreamSynchronize(g.stream);
     g.count = 0;
   }
+  if (!h->aheadGroups.empty() && h->fusedCopyStream) (void)hipStreamSynchronize(h->fusedCopyStream);
   h->aheadGroups.clear();
   h->aheadGroupSize = 0;
   h->aheadBounded = false;
@@ -370,6 +378,26 @@ int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int n
     for (size_t c = 0; c < map.size(); ++c) map[c] = lo[c] | (hi[c] << 16);
     CCHK(h->dClearMap.upload(map.data(), sizeof(uint32_t) * map.size()));
   }
+  if (nz <= 65534) {
+    // Column records (DevProblem::colRec): possible when the cells with extinction of every column are one run of layers that
+    // hold one value (compared bit by bit; "no extinction" is the bit pattern of +0, what the record gives outside its run).
+    const size_t ncol = (size_t)nx * ny;
+    std::vector<uint32_t> rec(2 * ncol, 0u);
+    bool ok = true;
+    for (size_t c = 0; c < ncol && ok; ++c) {
+      uint32_t val = 0u; int first = 0, last = 0;   // 1-based layers of the run
+      for (int k = 0; k < nz && ok; ++k) {
+        uint32_t bits; std::memcpy(&bits, &totalExt[(size_t)k * ncol + c], sizeof(bits));
+        if (bits == 0u) continue;
+        if (first == 0) { val = bits; first = last = k + 1; }
+        else if (bits == val && last == k) last = k + 1;
+        else ok = false;
+      }
+      rec[2 * c] = val;
+      rec[2 * c + 1] = first == 0 ? 1u : ((uint32_t)first | ((uint32_t)(last - first) << 16));
+    }
+    if (ok) CCHK(h->dColRec.upload(rec.data(), sizeof(uint32_t) * rec.size()));
+  }
   CCHK(h->dCum.upload(cumExt, sizeof(float) * ncell * ncomp));
   CCHK(h->dSsa.upload(ssa, sizeof(float) * ncell * ncomp));
   CCHK(h->dPf.upload(pfIndex, sizeof(int32_t) * ncell * ncomp));
@@ -447,9 +475,11 @@ int i3rc_hip_destroy(i3rc_hip_integrator *h) {
     for (int j = 0; j < k; ++j) shared = shared || (g.stream && g.stream == h->fused[j].stream);
     if (g.stream && !shared) { (void)hipStreamSynchronize(g.stream); if (tracing()) std::fprintf(stderr, "[i3rc %9.3f ms] destroy: fused stream drained\n", trace_ms()); (void)hipStreamDestroy(g.stream); }
     if (g.done) (void)hipEventDestroy(g.done);
+    if (g.traced) (void)hipEventDestroy(g.traced);
     if (g.pinned) (void)hipHostFree(g.pinned);
     if (g.abortFlag) (void)hipHostFree(g.abortFlag);
   }
+  if (h->fusedCopyStream) { (void)hipStreamSynchronize(h->fusedCopyStream); (void)hipStreamDestroy(h->fusedCopyStream); }
   for (int i = 0; i < i3rc_hip_integrator::kEventRing; ++i) {
     if (h->evStart[i]) (void)hipEventDestroy(h->evStart[i]);
     if (h->evStop[i]) (void)hipEventDestroy(h->evStop[i]);
@@ -615,6 +645,19 @@ int i3rc_hip_select_kernel(i3rc_hip_integrator *h, int variant) {
   return 0;
 }
 
+int i3rc_hip_select_grid_place(i3rc_hip_integrator *h, int place) {
+  if (!h) return 1;
+  drop_lookahead(h);
+  if (place < I3RC_GRID_AUTO || place > I3RC_GRID_COLUMNS) return h->fail("i3rc_hip_select_grid_place: unknown place");
+  if (place == I3RC_GRID_COLUMNS && !h->dColRec.p)
+    return h->fail("i3rc_hip_select_grid_place: the field has no column records (some column holds more than one run of one value)");
+  if (place == I3RC_GRID_BRICKS && h->nz > 65534) return h->fail("i3rc_hip_select_grid_place: more than 65534 layers keep the linear field");
+  h->gridPlace = place;
+  return 0;
+}
+
+int i3rc_hip_has_column_records(const i3rc_hip_integrator *h) { return h && h->dColRec.p ? 1 : 0; }
+
 int i3rc_hip_set_batch_fusion(i3rc_hip_integrator *h, int mode) {
   if (!h) return 1;
   drop_lookahead(h);
@@ -637,6 +680,7 @@ struct LaunchPlan {
   DevProblem P;
   size_t ldsBytes;
   bool intensity;
+  int place;     // GridPlace: where the kernels read the extinction field (make_problem)
 };
 
 constexpr size_t kLdsBudget = 64 * 1024;  // per workgroup: leaves room for >= 2 workgroups per CU
@@ -689,7 +733,13 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false) {
   P.xE = (const float *)h->dxE.p; P.yE = (const float *)h->dyE.p; P.zE = (const float *)h->dzE.p;
   // bricks pay off once the field no longer fits in one XCD's 4 MB of L2
   // (the clear-air map of a bricked field holds layer numbers in 16 bits: domains of more layers than that keep the linear field)
-  P.extBrick = (ncell_bytes(h) > ((size_t)4 << 20) && h->nz <= 65534) ? (const float *)h->dExtBrick.p : nullptr;
+  // Column records where the field has them (and does not fit in LDS, below): the whole field in 8 bytes per column.  Measured:
+  // I3RC_COLUMNS=0 switches them off for the process.
+  static const bool columnsOn = !(std::getenv("I3RC_COLUMNS") && std::atoi(std::getenv("I3RC_COLUMNS")) == 0);
+  const bool columns = h->gridPlace == I3RC_GRID_COLUMNS || (h->gridPlace == I3RC_GRID_AUTO && columnsOn && h->dColRec.p != nullptr);
+  P.colRec = columns ? (const uint2 *)h->dColRec.p : nullptr;
+  const bool bricks = h->gridPlace == I3RC_GRID_BRICKS || (h->gridPlace == I3RC_GRID_AUTO && !columns && ncell_bytes(h) > ((size_t)4 << 20) && h->nz <= 65534);
+  P.extBrick = bricks ? (const float *)h->dExtBrick.p : nullptr;
   P.bsx = h->bsx; P.bsy = h->bsy; P.bsz = h->bsz; P.nbx = h->nbx; P.nbxy = h->nbx * h->nby;
   P.clearMap = (const uint32_t *)h->dClearMap.p; P.clearShift = h->clearShift; P.clearNx = h->clearNx;
   P.totalExt = (const float *)h->dExt.p; P.cumExt = (const float *)h->dCum.p; P.ssa = (const float *)h->dSsa.p;
@@ -749,10 +799,11 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false) {
     if (!fused && h->nDir > 0 && nInt <= 16 * 1024 && lds + nInt <= kLdsBudget) { P.ldsIntensity = 1; lds += nInt; }
   }
   P.ldsGrid = 0;
-  if (lds + ncell * sizeof(float) <= budget) { P.ldsGrid = 1; lds += ncell * sizeof(float); }   // (never when the edges alone are beyond the budget)
+  if (h->gridPlace == I3RC_GRID_AUTO && lds + ncell * sizeof(float) <= budget) { P.ldsGrid = 1; lds += ncell * sizeof(float); P.colRec = nullptr; P.extBrick = nullptr; }   // (never when the edges alone are beyond the budget)
   else if (P.extBrick && h->nDir == 0) lds += sizeof(uint32_t) * (size_t)h->clearWords;          // bricked field, flux kernels: its clear-air map
   plan.ldsBytes = (lds + 15) & ~(size_t)15;
   plan.intensity = h->nDir > 0;
+  plan.place = P.ldsGrid ? GRID_LDS : (P.colRec ? GRID_COLUMNS : (P.extBrick ? GRID_BRICKS : GRID_GLOBAL));
   return 0;
 }
 
@@ -796,20 +847,20 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
   const bool simple = !Rng::kReplay && common_class(h, A.srcKind) && h->kernelVariant != I3RC_KERNEL_GENERAL;
   // the specialised kernels exist once per place of the extinction grid (LDS / global / global in bricks)
   using Kernel = void (*)(DevProblem, RunArgs, int, int);
-  const int place = plan.P.ldsGrid ? GRID_LDS : (plan.P.extBrick ? GRID_BRICKS : GRID_GLOBAL);
-  static const Kernel general[2][3] = {
-      {photon_kernel<Rng, false, true, GRID_LDS>, photon_kernel<Rng, false, true, GRID_GLOBAL>, photon_kernel<Rng, false, true, GRID_BRICKS>},
-      {photon_kernel<Rng, true, true, GRID_LDS>, photon_kernel<Rng, true, true, GRID_GLOBAL>, photon_kernel<Rng, true, true, GRID_BRICKS>}};
+  const int place = plan.place;
+  static const Kernel general[2][4] = {
+      {photon_kernel<Rng, false, true, GRID_LDS>, photon_kernel<Rng, false, true, GRID_GLOBAL>, photon_kernel<Rng, false, true, GRID_BRICKS>, photon_kernel<Rng, false, true, GRID_COLUMNS>},
+      {photon_kernel<Rng, true, true, GRID_LDS>, photon_kernel<Rng, true, true, GRID_GLOBAL>, photon_kernel<Rng, true, true, GRID_BRICKS>, photon_kernel<Rng, true, true, GRID_COLUMNS>}};
   Kernel kern = general[plan.intensity ? 1 : 0][place];
   if constexpr (!Rng::kReplay) {   // (the replay build always runs the general kernel)
-    static const Kernel special[2][3] = {
-        {photon_kernel<Rng, false, false, GRID_LDS>, photon_kernel<Rng, false, false, GRID_GLOBAL>, photon_kernel<Rng, false, false, GRID_BRICKS>},
-        {photon_kernel<Rng, true, false, GRID_LDS>, photon_kernel<Rng, true, false, GRID_GLOBAL>, photon_kernel<Rng, true, false, GRID_BRICKS>}};
+    static const Kernel special[2][4] = {
+        {photon_kernel<Rng, false, false, GRID_LDS>, photon_kernel<Rng, false, false, GRID_GLOBAL>, photon_kernel<Rng, false, false, GRID_BRICKS>, photon_kernel<Rng, false, false, GRID_COLUMNS>},
+        {photon_kernel<Rng, true, false, GRID_LDS>, photon_kernel<Rng, true, false, GRID_GLOBAL>, photon_kernel<Rng, true, false, GRID_BRICKS>, photon_kernel<Rng, true, false, GRID_COLUMNS>}};
     if (simple) kern = special[plan.intensity ? 1 : 0][place];
     if (plan.intensity && direct_rays(h)) {   // (the replay build keeps the nested local estimate: no queue at all)
-      static const Kernel direct[2][3] = {
-          {photon_kernel<Rng, true, true, GRID_LDS, false, true>, photon_kernel<Rng, true, true, GRID_GLOBAL, false, true>, photon_kernel<Rng, true, true, GRID_BRICKS, false, true>},
-          {photon_kernel<Rng, true, false, GRID_LDS, false, true>, photon_kernel<Rng, true, false, GRID_GLOBAL, false, true>, photon_kernel<Rng, true, false, GRID_BRICKS, false, true>}};
+      static const Kernel direct[2][4] = {
+          {photon_kernel<Rng, true, true, GRID_LDS, false, true>, photon_kernel<Rng, true, true, GRID_GLOBAL, false, true>, photon_kernel<Rng, true, true, GRID_BRICKS, false, true>, photon_kernel<Rng, true, true, GRID_COLUMNS, false, true>},
+          {photon_kernel<Rng, true, false, GRID_LDS, false, true>, photon_kernel<Rng, true, false, GRID_GLOBAL, false, true>, photon_kernel<Rng, true, false, GRID_BRICKS, false, true>, photon_kernel<Rng, true, false, GRID_COLUMNS, false, true>}};
       kern = direct[simple ? 1 : 0][place];
     }
   }
@@ -823,11 +874,11 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
   if constexpr (!Rng::kReplay) {
     static const bool tblOn = !(std::getenv("I3RC_TABLE_LDS") && std::atoi(std::getenv("I3RC_TABLE_LDS")) == 0);
     // (grid places as a bit mask: LDS and global memory.  Bricked fields: Landsat-119 -2.5 %, the scene tiled 2 x 2 +10 %: left out)
-    static const int tblPlaces = std::getenv("I3RC_TABLE_LDS_PLACES") ? std::atoi(std::getenv("I3RC_TABLE_LDS_PLACES")) : 3;
+    static const int tblPlaces = std::getenv("I3RC_TABLE_LDS_PLACES") ? std::atoi(std::getenv("I3RC_TABLE_LDS_PLACES")) : 11;
     if (tblOn && simple && !plan.intensity && ((tblPlaces >> place) & 1) && (plan.P.uniformPf >= 1 || h->nInvEntries[0] == 1) && h->kernelVariant == I3RC_KERNEL_AUTO &&
         plan.ldsBytes + sizeof(float) * (size_t)plan.P.comp0.nInv <= 79 * 1024) {
-      static const Kernel tbl[3] = {photon_kernel<Rng, false, false, GRID_LDS, true>, photon_kernel<Rng, false, false, GRID_GLOBAL, true>,
-                                    photon_kernel<Rng, false, false, GRID_BRICKS, true>};
+      static const Kernel tbl[4] = {photon_kernel<Rng, false, false, GRID_LDS, true>, photon_kernel<Rng, false, false, GRID_GLOBAL, true>,
+                                    photon_kernel<Rng, false, false, GRID_BRICKS, true>, photon_kernel<Rng, false, false, GRID_COLUMNS, true>};
       kern = tbl[place];
       threads = 1024;
       ldsBytes = (plan.ldsBytes + sizeof(float) * (size_t)plan.P.comp0.nInv + 15) & ~(size_t)15;
@@ -835,7 +886,7 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
   }
   const void *fn = (const void *)kern;
   {
-    static const char *const placeName[3] = {"GRID_LDS", "GRID_GLOBAL", "GRID_BRICKS"};
+    static const char *const placeName[4] = {"GRID_LDS", "GRID_GLOBAL", "GRID_BRICKS", "GRID_COLUMNS"};
     static thread_local char name[96];
     std::snprintf(name, sizeof(name), "photon_kernel<%s, %s, %s, %s>", Rng::kReplay ? "ReplayStream" : "PhiloxStream",
                        plan.intensity ? "true" : "false", (simple ? "false" : "true"), placeName[place]);
@@ -1093,6 +1144,8 @@ int ready_fused_slot(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g, 
     }
   }
   if (!g.done) HIPCHK(h, hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+  if (!g.traced) HIPCHK(h, hipEventCreateWithFlags(&g.traced, hipEventDisableTiming));
+  if (!h->fusedCopyStream) HIPCHK(h, hipStreamCreateWithFlags(&h->fusedCopyStream, hipStreamNonBlocking));
   if (!g.counter.p) HIPCHK(h, g.counter.alloc(sizeof(unsigned long long)));
   if (!g.abortFlag) HIPCHK(h, hipHostMalloc((void **)&g.abortFlag, sizeof(int), hipHostMallocCoherent | hipHostMallocMapped));
   if (toHost && g.pinnedBytes < outBytes) {
@@ -1140,19 +1193,19 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
   A.counterBlocks = (double *)g.counterBlocks.p;
   if ((uint64_t)count * R >= ((uint64_t)1 << 31)) return h->fail("fused launch: too many tally blocks");
   using Kernel = void (*)(DevProblem, RunArgs, int, int);
-  static const Kernel kernels[3] = {photon_kernel<PhiloxBatchStream, false, false, GRID_LDS>, photon_kernel<PhiloxBatchStream, false, false, GRID_GLOBAL>,
-                                    photon_kernel<PhiloxBatchStream, false, false, GRID_BRICKS>};
-  const int place = plan.P.ldsGrid ? GRID_LDS : (plan.P.extBrick ? GRID_BRICKS : GRID_GLOBAL);
+  static const Kernel kernels[4] = {photon_kernel<PhiloxBatchStream, false, false, GRID_LDS>, photon_kernel<PhiloxBatchStream, false, false, GRID_GLOBAL>,
+                                    photon_kernel<PhiloxBatchStream, false, false, GRID_BRICKS>, photon_kernel<PhiloxBatchStream, false, false, GRID_COLUMNS>};
+  const int place = plan.place;
   // (the inverse table's cosines in LDS, workgroups of 1024 threads: as in launch(); these instantiations are planned for eight
   // waves per SIMD -- two workgroups per compute unit -- and pay for it with two vector registers in scratch)
   Kernel kern = kernels[place];
   int threads = 256;
   size_t ldsBytes = plan.ldsBytes;
   if (plan.intensity) {   // radiance problems: through the event ring, or (one direction) without it -- as in launch()
-    static const Kernel ring[3] = {photon_kernel<PhiloxBatchStream, true, false, GRID_LDS>, photon_kernel<PhiloxBatchStream, true, false, GRID_GLOBAL>,
-                                   photon_kernel<PhiloxBatchStream, true, false, GRID_BRICKS>};
-    static const Kernel direct[3] = {photon_kernel<PhiloxBatchStream, true, false, GRID_LDS, false, true>, photon_kernel<PhiloxBatchStream, true, false, GRID_GLOBAL, false, true>,
-                                     photon_kernel<PhiloxBatchStream, true, false, GRID_BRICKS, false, true>};
+    static const Kernel ring[4] = {photon_kernel<PhiloxBatchStream, true, false, GRID_LDS>, photon_kernel<PhiloxBatchStream, true, false, GRID_GLOBAL>,
+                                   photon_kernel<PhiloxBatchStream, true, false, GRID_BRICKS>, photon_kernel<PhiloxBatchStream, true, false, GRID_COLUMNS>};
+    static const Kernel direct[4] = {photon_kernel<PhiloxBatchStream, true, false, GRID_LDS, false, true>, photon_kernel<PhiloxBatchStream, true, false, GRID_GLOBAL, false, true>,
+                                     photon_kernel<PhiloxBatchStream, true, false, GRID_BRICKS, false, true>, photon_kernel<PhiloxBatchStream, true, false, GRID_COLUMNS, false, true>};
     kern = direct_rays(h) ? direct[place] : ring[place];
   } else {
     static const bool tblOn = !(std::getenv("I3RC_TABLE_LDS") && std::atoi(std::getenv("I3RC_TABLE_LDS")) == 0);
@@ -1167,7 +1220,7 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
   }
   const void *fn = (const void *)kern;
   {
-    static const char *const placeName[3] = {"GRID_LDS", "GRID_GLOBAL", "GRID_BRICKS"};
+    static const char *const placeName[4] = {"GRID_LDS", "GRID_GLOBAL", "GRID_BRICKS", "GRID_COLUMNS"};
     static thread_local char name[96];
     std::snprintf(name, sizeof(name), "photon_kernel<PhiloxBatchStream, %s, false, %s%s>", plan.intensity ? "true" : "false", placeName[place],
                   threads == 1024 ? ", table in LDS" : (plan.intensity && direct_rays(h) ? ", one direction" : ""));
@@ -1213,9 +1266,17 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
                        const_cast<double *>(result), (long long)count, (long long)h->layout.total, (int)h->layout.counters);
     HIPCHK(h, hipGetLastError());
   }
-  if (moments) { if (accumulate_moments(h, g.stream, result, count, g.excess)) return 1; }
-  else HIPCHK(h, hipMemcpyAsync(g.pinned, result, outBytes, hipMemcpyDeviceToHost, g.stream));
-  HIPCHK(h, hipEventRecord(g.done, g.stream));
+  if (moments) {
+    if (accumulate_moments(h, g.stream, result, count, g.excess)) return 1;
+    HIPCHK(h, hipEventRecord(g.done, g.stream));
+  } else {
+    static const bool copyInLine = std::getenv("I3RC_FUSED_COPY_INLINE") && std::atoi(std::getenv("I3RC_FUSED_COPY_INLINE")) != 0;   // (measurement knob: the copy on the groups' own stream, as before round 4)
+    hipStream_t const cs = copyInLine ? g.stream : h->fusedCopyStream;
+    HIPCHK(h, hipEventRecord(g.traced, g.stream));
+    if (!copyInLine) HIPCHK(h, hipStreamWaitEvent(cs, g.traced, 0));
+    HIPCHK(h, hipMemcpyAsync(g.pinned, result, outBytes, hipMemcpyDeviceToHost, cs));
+    HIPCHK(h, hipEventRecord(g.done, cs));
+  }
   g.count = count; g.seed1 = seed1; g.next = 0;
   if (tracing()) std::fprintf(stderr, "[i3rc %9.3f ms] fused group launched: seed words %u .. %u (%d batches of %lld photons, %d replicas, chunk %d)\n", trace_ms(),
                               seed1, seed1 + (unsigned)count - 1u, count, (long long)nPhotons, R, A.chunk);
@@ -1706,7 +1767,11 @@ int i3rc_hip_trace_rays(i3rc_hip_integrator *h, int64_t n, const float *dir, flo
   h->compDirty = true;
   if (rc) return 1;
   plan.P.ldsGrid = 0; plan.P.ldsTallies = 0;
-  plan.P.extBrick = (const float *)h->dExtBrick.p;   // the test hook always reads the bricked copy (its index is checked bit for bit)
+  // the hook reads the bricked copy (its index is checked bit for bit) unless i3rc_hip_select_grid_place asked for the plain
+  // field or the column records
+  const int hookPlace = h->gridPlace == I3RC_GRID_LINEAR ? GRID_GLOBAL : (h->gridPlace == I3RC_GRID_COLUMNS ? GRID_COLUMNS : GRID_BRICKS);
+  plan.P.extBrick = (const float *)h->dExtBrick.p;
+  plan.P.colRec = (const uint2 *)h->dColRec.p;
   DevBuf dDir, dPos, dIdx, dTar, dTau, dSteps;
   HIPCHK(h, dDir.upload(dir, sizeof(float) * 3 * n)); HIPCHK(h, dPos.upload(pos, sizeof(float) * 3 * n));
   HIPCHK(h, dIdx.upload(idx, sizeof(int32_t) * 3 * n)); HIPCHK(h, dTar.upload(target, sizeof(float) * n));
@@ -1714,7 +1779,10 @@ int i3rc_hip_trace_rays(i3rc_hip_integrator *h, int64_t n, const float *dir, flo
   const size_t lds = sizeof(float) * ((h->nx + 1) + (h->ny + 1) + (h->nz + 1)) + sizeof(uint32_t) * (size_t)h->clearWords;
   if (lds > 64 * 1024) return h->fail("i3rc_hip_trace_rays: domain edge vectors do not fit in LDS");
   // (more than 65534 layers: the clear-air map's 16-bit layer numbers do not reach the top -- the hook reads the bricks without it)
-  hipLaunchKernelGGL(h->nz <= 65534 ? trace_rays_kernel<true> : trace_rays_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, h->stream, plan.P, (long long)n,
+  auto *const hook = hookPlace == GRID_GLOBAL ? trace_rays_kernel<GRID_GLOBAL, false>
+                   : (hookPlace == GRID_COLUMNS ? trace_rays_kernel<GRID_COLUMNS, false>
+                                                : (h->nz <= 65534 ? trace_rays_kernel<GRID_BRICKS, true> : trace_rays_kernel<GRID_BRICKS, false>));
+  hipLaunchKernelGGL(hook, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, h->stream, plan.P, (long long)n,
                      (const float *)dDir.p, (float *)dPos.p, (int32_t *)dIdx.p, (const float *)dTar.p, (float *)dTau.p,
                      (int32_t *)dSteps.p);
   HIPCHK(h, hipGetLastError());

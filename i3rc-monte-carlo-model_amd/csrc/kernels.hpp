@@ -19,7 +19,8 @@
 //   * the batches of a driver's loop share ONE grid (PhiloxBatchStream: a lane carries its photon's batch in its Philox key, a
 //     local-estimate ray in its info word; per-batch tally blocks in global memory), so that one batch's tail -- the few photons
 //     with a thousand scatterings -- is filled by the next batch's photons;
-//   * cell edges (and, when they fit, the extinction grid) are staged in LDS with coalesced loads; grids beyond an
+//   * cell edges (and, when they fit, the extinction grid) are staged in LDS with coalesced loads; a field whose columns
+//     each hold one run of one value (the I3RC Landsat scene) is read as one 8-byte record per column; other grids beyond an
 //     XCD's L2 are read from a copy in 32-cell bricks; flux and radiance tallies are privatised per workgroup in LDS
 //     (ds_add_f32) and flushed once with float64 atomics; large domains tally straight to HBM with float64 atomics;
 //   * per-photon Philox4x32-10 streams keyed by (seed, batch) make a photon's path independent of the launch
@@ -1346,15 +1347,17 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
 
 // Test hook: independent tracer calls, one ray per thread.
 // (CLEARMAP = false: domains of more than 65534 layers, whose clear-air map -- 16 bits per bound -- is not used: i3rc_hip.hip)
-template <bool CLEARMAP>
+// (GRID: the bricked copy -- what the hook reads unless i3rc_hip_select_grid_place says otherwise --, the plain field, or the column records)
+template <int GRID, bool CLEARMAP>
 __global__ void __launch_bounds__(256) trace_rays_kernel(const DevProblem P, long long n, const float *dir, float *pos,
                                                          int32_t *idx, const float *target, float *tau, int32_t *steps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   L.xE = (lds_float *)smem; L.yE = L.xE + P.nx + 1; L.zE = L.yE + P.ny + 1;
   L.tUp = L.tDown = L.tAbs = L.dirCos = nullptr;
-  L.ext = L.zE + P.nz + 1;   // the clear-air map of the bricked field (this hook always reads the bricks)
-  for (int i = threadIdx.x; i < P.clearNx * (((P.ny - 1) >> P.clearShift) + 1); i += blockDim.x) L.ext[i] = __uint_as_float(P.clearMap[i]);
+  L.ext = L.zE + P.nz + 1;   // the clear-air map of the bricked field
+  if (GRID == GRID_BRICKS && CLEARMAP)
+    for (int i = threadIdx.x; i < P.clearNx * (((P.ny - 1) >> P.clearShift) + 1); i += blockDim.x) L.ext[i] = __uint_as_float(P.clearMap[i]);
   for (int i = threadIdx.x; i <= P.nx; i += blockDim.x) L.xE[i] = P.xE[i];
   for (int i = threadIdx.x; i <= P.ny; i += blockDim.x) L.yE[i] = P.yE[i];
   for (int i = threadIdx.x; i <= P.nz; i += blockDim.x) L.zE[i] = P.zE[i];
@@ -1371,7 +1374,7 @@ __global__ void __launch_bounds__(256) trace_rays_kernel(const DevProblem P, lon
   r.target = target[i];
   int ns = 0;
   StepResult s;
-  do { ns++; s = trace_step<GRID_BRICKS, CLEARMAP>(P, L, r, hasTarget); } while (s == STEP_CONTINUE && ns < (1 << 24));
+  do { ns++; s = trace_step<GRID, CLEARMAP>(P, L, r, hasTarget); } while (s == STEP_CONTINUE && ns < (1 << 24));
   pos[3 * i] = r.x; pos[3 * i + 1] = r.y; pos[3 * i + 2] = r.z;
   idx[3 * i] = r.ix; idx[3 * i + 1] = r.iy; idx[3 * i + 2] = r.iz;
   tau[i] = r.acc;

@@ -50,6 +50,13 @@ struct DevProblem {
   // crosses on its way out, and those steps' loads were most of the field's traffic beyond L2.
   const uint32_t *clearMap;
   int clearShift, clearNx;
+  // COLUMN RECORDS (round 4): a field in which every column's cells WITH extinction are one run of layers that share one value
+  // -- the I3RC Landsat scene is such a field: per column a cloud of vertically uniform extinction between its base and its top --
+  // is held as one 8-byte record per column {the value's bits, first layer | (run length - 1) << 16} (1-based; a clear column holds
+  // the value 0).  128 x 128 columns are 128 KB where the field is 7.8 MB: the whole scene stays in every XCD's L2 (and much of it
+  // in the vector L1), a cell's extinction is one load and three integer instructions, and what the field holds comes back bit
+  // for bit.  null: the field has no such form (or i3rc_hip_select_grid_place asked for another place).
+  const uint2 *colRec;
   const float *cumExt, *ssa;          // [ncomp][nz][ny][nx]
   const int32_t *pfIndex;             // [ncomp][nz][ny][nx]
   const CompTables *comp;             // [ncomp] phase-function tables (device memory: indexed per lane)
@@ -295,13 +302,22 @@ __device__ __forceinline__ int brick_index(const PR &P, int ix, int iy, int iz) 
 // reused it in the next loop, whose active lanes were not all active there: those lanes took the LDS branch on a
 // grid that lives in global memory and read zeros (found by the replay tests on the I3RC radar / Landsat fields;
 // tests/test_build_isa.py keeps the pattern out of the kernels).
-enum GridPlace { GRID_LDS = 0, GRID_GLOBAL = 1, GRID_BRICKS = 2 };
+enum GridPlace { GRID_LDS = 0, GRID_GLOBAL = 1, GRID_BRICKS = 2, GRID_COLUMNS = 3 };
 // CLEARMAP: consult the clear-air map of a bricked field first (DevProblem::clearMap).  The flux kernels do -- Landsat-119 6.6 ->
 // 7.2e8 photons/s, the scene tiled 2 x 2 5.5 -> 6.0e8 --; the radiance kernels do not: the look-up is an LDS read in front of
 // every load, and with five waves per SIMD and no register to carry it a step ahead it cost them 11 %.
 template <int GRID, bool CLEARMAP = false, class PR>
 __device__ __forceinline__ float cell_extinction(const PR &P, const Lds &L, int ix, int iy, int iz) {
   if (GRID == GRID_LDS) return L.ext[cell_index(P, ix, iy, iz)];   // ds_read
+  if (GRID == GRID_COLUMNS) {   // the column's record (DevProblem::colRec): its value within the run of layers, 0 outside
+    // (ONE 8-byte buffer load: written as a plain load of a uint2, the compiler loaded the range word first, waited for it, and
+    // fetched the value under a branch only for the lanes inside their run -- two memory latencies in a row at every voxel step,
+    // Landsat-36 15 % slower than with the plain field.  The buffer descriptor is three scalar instructions from the pointer.)
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P.colRec, 0, (P.nx * P.ny) << 3, 0x00020000);
+    const u32x2 rec = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)((__umul24((unsigned)(iy - 1), (unsigned)P.nx) + (unsigned)(ix - 1)) << 3), 0, 0);
+    return ((unsigned)iz - (rec.y & 0xffffu)) <= (rec.y >> 16) ? __uint_as_float(rec.x) : 0.0f;
+  }
   if (GRID == GRID_BRICKS && CLEARMAP) {
     const uint32_t range = __float_as_uint(L.ext[__umul24((unsigned)(iy - 1) >> P.clearShift, (unsigned)P.clearNx) + ((unsigned)(ix - 1) >> P.clearShift)]);
     const unsigned z = (unsigned)iz;

@@ -513,6 +513,15 @@ class Integrator:
         if lightThreshold is not None:
             self._check(self._lib.i3rc_hip_set_light_threshold(self._h, int(lightThreshold)), "set_tuning")
 
+    GRID_PLACES = {"auto": 0, "linear": 1, "bricks": 2, "columns": 3}
+
+    def select_grid_place(self, place):
+        """Where the kernels read the extinction field from (i3rc_hip_select_grid_place); place is one of GRID_PLACES."""
+        self._check(self._lib.i3rc_hip_select_grid_place(self._h, self.GRID_PLACES[place]), "select_grid_place")
+
+    def has_column_records(self):
+        return bool(self._lib.i3rc_hip_has_column_records(self._h))
+
     def trace_rays(self, direction, pos, idx, target=None):
         d, p = f32(direction).reshape(-1, 3).copy(), f32(pos).reshape(-1, 3).copy()
         i = np.ascontiguousarray(idx, np.int32).reshape(-1, 3).copy()

@@ -316,6 +316,18 @@ int i3rc_hip_select_kernel(i3rc_hip_integrator *h, int variant);
 /* = i3rc_hip_select_kernel(h, on ? I3RC_KERNEL_GENERAL : I3RC_KERNEL_AUTO) */
 int i3rc_hip_force_general_kernel(i3rc_hip_integrator *h, int on);
 
+/* Test / tuning knob: where the kernels read the extinction field (getOpticalPropertiesByComponent's totalExt, :172) from.
+ *   AUTO (default): LDS when the field fits beside the rest; else COLUMN RECORDS when the field has them -- every column's cells
+ *   with extinction are one run of layers holding one value (the I3RC Landsat scene: per column a cloud of vertically uniform
+ *   extinction), kept as 8 bytes per column: first layer, run length, value; else the plain field while it fits in an XCD's L2
+ *   (4 MB); else a copy in bricks of 32 cells.  LINEAR / BRICKS / COLUMNS force one of them (COLUMNS fails when the field has no
+ *   such form), also for i3rc_hip_trace_rays.  Every place returns what the field holds, bit for bit: photon paths do not depend
+ *   on it (tests run one against the other).  Environment: I3RC_COLUMNS=0 takes the column records out of AUTO. */
+enum { I3RC_GRID_AUTO = 0, I3RC_GRID_LINEAR = 1, I3RC_GRID_BRICKS = 2, I3RC_GRID_COLUMNS = 3 };
+int i3rc_hip_select_grid_place(i3rc_hip_integrator *h, int place);
+/* 1 when the field has column records, else 0 */
+int i3rc_hip_has_column_records(const i3rc_hip_integrator *h);
+
 /* Test hook: the raw Philox4x32-10 blocks (out[n][blocksPerPhoton][4]) of photons firstPhoton..+n-1 and the
  * float32 deviates the photon streams derive from them (outf, same shape). */
 int i3rc_hip_philox_blocks(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int64_t firstPhoton, int64_t n,

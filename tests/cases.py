@@ -60,6 +60,31 @@ def irregular_domain(seed=3, nx=7, ny=5, nz=9, ssa=0.95, z0=0.0):
     return dict(xe=xe, ye=ye, ze=ze, ext=ext, ssa=s, pf=pf)
 
 
+def column_clouds(seed=11, nx=9, ny=6, nz=12, ssa=0.97):
+    """Irregularly spaced domain in which every column holds ONE run of layers with ONE extinction value -- the form the kernels keep
+    as column records (include/i3rc_hip.h, i3rc_hip_select_grid_place): runs that touch the top, the bottom, both, runs of one
+    layer, and clear columns."""
+    rng = np.random.default_rng(seed)
+    xe = np.concatenate([[0.0], np.cumsum(rng.uniform(5, 40, nx))]).astype(np.float32)
+    ye = np.concatenate([[0.0], np.cumsum(rng.uniform(5, 40, ny))]).astype(np.float32)
+    ze = np.concatenate([[0.0], np.cumsum(rng.uniform(5, 30, nz))]).astype(np.float32)
+    ext = np.zeros((nz, ny, nx), np.float32)
+    for j in range(ny):
+        for i in range(nx):
+            kind = rng.integers(0, 6)
+            if kind == 0:
+                continue                                   # a clear column
+            lo, hi = sorted(rng.integers(0, nz, 2))
+            if kind == 1: lo = 0                           # from the surface up
+            if kind == 2: hi = nz - 1                      # up to the top
+            if kind == 3: lo, hi = 0, nz - 1               # the whole column
+            if kind == 4: hi = lo                          # one layer
+            ext[lo:hi + 1, j, i] = f32(rng.uniform(0.002, 0.1))
+    pf = np.where(ext > 0, 1, 0).astype(np.int32)
+    s = np.where(ext > 0, f32(ssa), f32(0.0)).astype(np.float32)
+    return dict(xe=xe, ye=ye, ze=ze, ext=ext, ssa=s, pf=pf)
+
+
 # ---- I3RC phase-1 fields (data fixture made by tests/golden/make_i3rc_inputs.py) ---------------------------
 import os as _os
 

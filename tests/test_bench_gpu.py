@@ -94,8 +94,8 @@ def test_steps_in_flight_on_one_gpu():
 
 
 @pytest.mark.parametrize("config,kernel", [("radar64_nadir", "photon_kernel<PhiloxStream, true, false, GRID_GLOBAL, one direction>"),
-                                           ("landsat36", "photon_kernel<PhiloxStream, false, false, GRID_GLOBAL, table in LDS>"),
-                                           ("landsat119_7dir", "photon_kernel<PhiloxStream, true, false, GRID_BRICKS>")])
+                                           ("landsat36", "photon_kernel<PhiloxStream, false, false, GRID_COLUMNS, table in LDS>"),
+                                           ("landsat119_7dir", "photon_kernel<PhiloxStream, true, false, GRID_COLUMNS>")])
 def test_other_baseline_workloads(config, kernel):
     n = {"radar64_nadir": 2000000, "landsat36": 4000000, "landsat119_7dir": 300000}[config]
     j = _bench(["--config", config, "--steps", "1", "--warmup", "0", "--photons", str(n), "--no-cpu-baseline"])

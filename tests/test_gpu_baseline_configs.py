@@ -250,7 +250,7 @@ def test_config3_landsat36_column_by_column_with_absorption(tmp_path):
     name, w = W.get("landsat36_absorbing")
     g, d = W.make_integrator(w)
     gr = [g.computeRadiativeTransfer(M.new_RandomNumberSequence((77, b)), M.new_PhotonStream(1.0, 0.0, 125_000)) for b in range(1, 33)]
-    assert "table in LDS" in g.kernel_name() and "GRID_GLOBAL" in g.kernel_name(), g.kernel_name()
+    assert "table in LDS" in g.kernel_name() and "GRID_COLUMNS" in g.kernel_name(), g.kernel_name()   # (the scene has column records)
     g.finalize_Integrator()
     for r in gr:
         r["absorbedProfile"] = r["volumeAbsorption"].reshape(36, -1).mean(axis=1, dtype=np.float64)
@@ -307,8 +307,9 @@ def test_config4_column_by_column_against_the_oracles_fixture():
     assert abs(kg - c["scatterings"] / n_o) < 0.003 * kg
 
 
-@pytest.mark.parametrize("config,nb,n", [("landsat_tiled", 10, 40_000), ("landsat_tiled_7dir", 10, 20_000)])
-def test_fields_beyond_16_MB_against_the_oracle(tmp_path, config, nb, n):
+@pytest.mark.parametrize("config,nb,n,place", [("landsat_tiled", 10, 40_000, "bricks"), ("landsat_tiled_7dir", 10, 20_000, "bricks"),
+                                               ("landsat_tiled_7dir", 10, 20_000, "auto")])
+def test_fields_beyond_16_MB_against_the_oracle(tmp_path, config, nb, n, place):
     """The Landsat scene tiled 2 x 2 (256 x 256 x 119: 31 MB of extinction) runs the instantiation and the launch set-up of fields
     beyond 16 MB -- bricks, four workgroups per CU, the XCD-aware photon order also for radiance runs: here against the
     oracle on the same domain (4e5 / 2e5 photons a side), domain means of the fluxes and of every radiance direction, the
@@ -323,8 +324,10 @@ def test_fields_beyond_16_MB_against_the_oracle(tmp_path, config, nb, n):
 
     name, w = W.get(config)
     g, d = W.make_integrator(w)
+    # (the tiled scene has column records, which AUTO reads -- 0.5 MB instead of 31: the third case; the bricks are asked for by name)
+    g.select_grid_place(place)
     rs = [g.computeRadiativeTransfer(M.new_RandomNumberSequence((77, b)), M.new_PhotonStream(w["mu0"], 0.0, n)) for b in range(1, nb + 1)]
-    assert "GRID_BRICKS" in g.kernel_name()
+    assert ("GRID_BRICKS" if place == "bricks" else "GRID_COLUMNS") in g.kernel_name()
     g.finalize_Integrator()
     so, se = child.communicate(timeout=900)
     assert child.returncode == 0, so + se

@@ -530,7 +530,8 @@ print(json.dumps(out))
 ''' % root
     res = {}
     for slabs in ("1", "0"):
-        p = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env=dict(os.environ, I3RC_SLABS=slabs, I3RC_POISON="1"))
+        # (I3RC_COLUMNS=0: the Landsat scene has column records, which the kernels would read instead of the bricks this test is about)
+        p = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env=dict(os.environ, I3RC_SLABS=slabs, I3RC_POISON="1", I3RC_COLUMNS="0"))
         assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
         res[slabs] = json.loads(p.stdout.strip().splitlines()[-1])
     ref = res["0"][0]
@@ -543,6 +544,56 @@ print(json.dumps(out))
     a, b = res["1"][3], res["0"][3]
     assert "true, false, GRID_BRICKS" in a[0] and a[1] == b[1], (a[1], b[1])
     assert abs(a[2] - b[2]) < 1e-6 and abs(a[3] - b[3]) < 1e-6 and np.allclose(np.array(a[4]), np.array(b[4]), rtol=1e-4, atol=1e-6)
+
+
+def test_the_same_photons_wherever_the_field_is_read_from():
+    """Column records (a field whose columns each hold one run of one value: the I3RC Landsat scene, include/i3rc_hip.h
+    i3rc_hip_select_grid_place), the plain field and the bricked copy give the kernels the same extinction bit for bit: integer work
+    counters identical, tallies equal to the order of the float64 additions -- specialised flux kernels with the table in LDS and
+    absorption (Landsat-36, omega = 0.99), the ring kernels (two directions, roulette, surface), the kernels without a ring (one
+    direction), the general kernels (an irregular grid of column clouds with radiances), and fused batches."""
+    rri = dict(useRussianRouletteForIntensity=True, zetaMin=0.3)
+    tab = M.PhaseFunctionTable([M.henyey_greenstein(0.85, 64)])
+
+    def build(d, **kw):
+        dom = M.new_Domain(d["xe"], d["ye"], d["ze"])
+        dom.addOpticalComponent("cloud", d["ext"], d["ssa"], d["pf"], tab)
+        g = M.new_Integrator(dom)
+        g.specifyParameters(**kw)
+        return g
+
+    problems = [("Landsat-36 absorbing, flux", cases.landsat_cloud(ssa=0.99, nlayers=36), dict(surfaceAlbedo=0.1), 400_000, "false, false, GRID_COLUMNS, table in LDS"),
+                ("Landsat-119, two radiances", cases.landsat_cloud(), dict(rri, intensityMus=[0.8, 0.3], intensityPhis=[90.0, 225.0], surfaceAlbedo=0.2), 60_000, "true, false, GRID_COLUMNS>"),
+                ("Landsat-119, nadir radiance", cases.landsat_cloud(), dict(rri, intensityMus=[1.0], intensityPhis=[0.0], surfaceAlbedo=0.2), 100_000, "true, false, GRID_COLUMNS, one direction"),
+                ("column clouds, irregular grid, radiances", cases.column_clouds(), dict(rri, intensityMus=[0.6, 1.0], intensityPhis=[20.0, 0.0], surfaceAlbedo=0.3), 100_000, "true, true, GRID_COLUMNS")]
+    for label, d, kw, n, want in problems:
+        out = {}
+        for place in ("columns", "linear", "bricks"):
+            g = build(d, **kw)
+            assert g.has_column_records(), label
+            g.select_grid_place(place)
+            r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((21, 4)), M.new_PhotonStream(0.7, 40.0, n))
+            out[place] = (r, g.kernel_name())
+        ref, name = out["columns"]
+        assert want in name, (label, name)
+        assert ref["counters"]["photons"] == n and ref["counters"]["scatterings"] > 0
+        for place in ("linear", "bricks"):
+            r, other = out[place]
+            assert ("GRID_GLOBAL" if place == "linear" else "GRID_BRICKS") in other, (label, other)
+            assert r["counters"] == ref["counters"], (label, place, r["counters"], ref["counters"])
+            for k in ("fluxUp", "fluxDown", "fluxAbsorbed", "volumeAbsorption", "intensity"):
+                if k in ref:
+                    np.testing.assert_allclose(r[k], ref[k], rtol=3e-6, atol=1e-9, err_msg=f"{label}: {k} from {place}")
+    # AUTO takes the column records for a field beyond LDS that has them -- and fused batches read them too
+    g = build(cases.landsat_cloud(nlayers=36), surfaceAlbedo=0.0)
+    one = [g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 1 + b)), M.new_PhotonStream(1.0, 0.0, 50_000)) for b in range(3)]
+    assert "GRID_COLUMNS" in g.kernel_name()
+    g.set_batch_fusion(1)
+    fused = g.computeRadiativeTransferBatches((10, 1), 3, 1.0, 0.0, 50_000)
+    assert "PhiloxBatchStream" in g.kernel_name() and "GRID_COLUMNS" in g.kernel_name(), g.kernel_name()
+    for a, b in zip(one, fused):
+        assert a["counters"] == b["counters"]
+        np.testing.assert_allclose(a["fluxUp"], b["fluxUp"], rtol=3e-6, atol=1e-9)
 
 
 # ---- limits the reference does not have -----------------------------------------------------------------------------------
@@ -599,7 +650,7 @@ def test_twenty_thousand_columns(oracle):
     o = make_oracle(oracle, d, [inv])
     o.specify(surfaceAlbedo=0.2)
     gr, orr = _two_stage(oracle, g, o, 6, 30000, 0.6, ("fluxUp", "fluxDown", "fluxAbsorbed"))
-    assert "false, false, GRID_GLOBAL" in g.kernel_name()
+    assert "false, false, GRID_COLUMNS" in g.kernel_name()   # (beyond LDS; one run of one value per column: column records)
     # the flux field follows the cloud: columns over thick cloud reflect more (both sides, 100-column blocks)
     tau = ext.sum(0)[0] * 100.0
     up = np.stack([r["fluxUp"][0] for r in gr]).mean(0).reshape(-1, 100).mean(1)

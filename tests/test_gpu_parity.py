@@ -105,15 +105,24 @@ def _random_rays(rng, d, n, oracle_integ):
     return dirs, pos, idx, target
 
 
-@pytest.mark.parametrize("case", ["step", "irregular"])
-def test_tracer_bit_exact(oracle, case):
+@pytest.mark.parametrize("case,place", [("step", "auto"), ("irregular", "auto"), ("columns", "columns"), ("columns", "linear"),
+                                        ("columns", "auto"), ("step", "columns"), ("irregular", "linear")])
+def test_tracer_bit_exact(oracle, case, place):
+    """accumulateExtinctionAlongPath (:1654-1807) ray by ray against the oracle, every bit of position, cell, optical path and step
+    count -- from the bricked copy of the field (what the hook reads by default), from the plain field, and from the column
+    records of a field whose columns each hold one run of one value (cases.column_clouds, the step cloud)."""
     rng = np.random.default_rng(42)
     if case == "step":
         d = cases.step_cloud()
+    elif case == "columns":
+        d = cases.column_clouds()
     else:
         d = cases.irregular_domain()
     tab = hg_table()
     g = make_gpu(d, tab)
+    assert g.has_column_records() == (case != "irregular")
+    if place != "auto":
+        g.select_grid_place(place)
     o = make_oracle(oracle, d, [tab.inverse_table(9001)])
     n = 4000
     dirs, pos, idx, target = _random_rays(rng, d, n, o)
@@ -125,6 +134,12 @@ def test_tracer_bit_exact(oracle, case):
         assert np.array_equal(pp, p2[k]) and list(i2[k]) == ii and ss == steps[k], (k, pp, p2[k], ii, i2[k])
         nerr += t < 0
     assert nerr < n // 20
+
+
+def test_a_field_without_column_records_refuses_them():
+    g = make_gpu(cases.irregular_domain(), hg_table())
+    with pytest.raises(Exception, match="no column records"):
+        g.select_grid_place("columns")
 
 
 def _replay(oracle, d, tab, n, seed, solar_mu, **params):
@@ -623,7 +638,7 @@ def test_fused_batches_equal_one_launch_per_batch():
     the batch of its photon in its Philox key, per-batch tally blocks in global memory) gives every batch exactly what a launch
     of its own gives it -- integer work counters identical, tallies equal to the order of the additions -- whatever the
     batch size (shorter than a wavefront, not a multiple of a chunk, one batch only), with absorption (volume tallies), a
-    reflecting surface, a slant sun, for the extinction grid in LDS, in global memory and in bricks."""
+    reflecting surface, a slant sun, for the extinction grid in LDS, in global memory, in bricks and as column records."""
     # (round 4) ... and for radiance problems: a local-estimate ray carries its batch, radiances go to the batch's block -- with
     # the roulette, hybrid tables and the contribution limit, through the event ring (several directions) and without it (one)
     rri = dict(useRussianRouletteForIntensity=True, zetaMin=0.3)
@@ -633,6 +648,8 @@ def test_fused_batches_equal_one_launch_per_batch():
                 ("step cloud, conservative", cases.step_cloud(nlayers=16), dict(), 1.0, [(30011, 12)]),
                 ("radar field (grid in global memory)", cases.radar_cloud(), dict(surfaceAlbedo=0.1), 0.9, [(20000, 5)]),
                 ("Landsat field (bricks), absorbing", cases.landsat_cloud(ssa=0.98), dict(), 0.5, [(15000, 3)]),
+                ("Landsat field (column records), absorbing", cases.landsat_cloud(ssa=0.98), dict(), 0.5, [(15000, 3)]),
+                ("Landsat field (column records), two radiances", cases.landsat_cloud(ssa=0.98), dict(rri, intensityMus=[0.8, 0.3], intensityPhis=[90.0, 225.0], surfaceAlbedo=0.2), 0.5, [(15000, 3)]),
                 ("step cloud, three radiances, hybrid tables, limit", cases.step_cloud(ssa=0.95, nlayers=8), full, 0.7, [(20000, 7), (50, 5), (777, 33)]),
                 ("step cloud, nadir radiance, plain local estimate", cases.step_cloud(ssa=0.95, nlayers=8), dict(intensityMus=[1.0], intensityPhis=[0.0], surfaceAlbedo=0.2), 0.7, [(20000, 7), (60, 9)]),
                 ("radar field, nadir radiance (one direction: no ring)", cases.radar_cloud(), dict(rri, intensityMus=[1.0], intensityPhis=[0.0], surfaceAlbedo=0.1), 0.9, [(20000, 5), (3000, 24)]),
@@ -641,6 +658,8 @@ def test_fused_batches_equal_one_launch_per_batch():
                 ("one column, nadir radiance, 8300 batches of 33 photons", cases.plane_parallel(optical_depth=2.0, ssa=0.9), dict(rri, intensityMus=[1.0], intensityPhis=[0.0], surfaceAlbedo=0.3), 0.6, [(33, 8300)])]
     for what, d, params, mu0, runs in problems:
         g = make_gpu(d, hg_table(), **params)
+        if "(bricks)" in what:
+            g.select_grid_place("bricks")   # (the scene has column records, which AUTO would read)
         rad = g if "intensityMus" in params else None
         for n, nb in runs:
             g.set_batch_fusion(0)

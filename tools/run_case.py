@@ -1,6 +1,6 @@
 """One launch of one benchmark workload (the program tools/pmc_profile.sh profiles): no torch, no oracle.
   python3 tools/run_case.py <workload> [photons]        workloads: tools/workloads.py (step16 radar64_nadir landsat36 ...)
-env: EVTHR= / LITHR= fixed event / service thresholds, BATCH= batch number of the seed (default 1), I3RC_LIB= another build of the library (A/B comparisons), REPEAT= launches"""
+env: GRID=auto|linear|bricks|columns where the extinction field is read from, EVTHR= / LITHR= fixed event / service thresholds, BATCH= batch number of the seed (default 1), I3RC_LIB= another build of the library (A/B comparisons), REPEAT= launches"""
 import os
 import sys
 
@@ -19,6 +19,8 @@ n = int(float(sys.argv[2])) if len(sys.argv) > 2 else PROFILE_PHOTONS[name]
 g, d = W.make_integrator(w)
 if os.environ.get("EVTHR") or os.environ.get("LITHR"):   # fixed phase thresholds instead of the per-wave adaptive ones
     g.set_tuning(evThreshold=int(os.environ.get("EVTHR", "0")), lightThreshold=int(os.environ.get("LITHR", "0")))
+if os.environ.get("GRID"):
+    g.select_grid_place(os.environ["GRID"])
 g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 0)), M.new_PhotonStream(w["mu0"], 0.0, 1))   # tables
 seed = int(os.environ.get("BATCH", "1"))
 for k in range(int(os.environ.get("REPEAT", "1"))):
