@@ -145,7 +145,7 @@ __device__ __forceinline__ void intensity_contribution(const PR &P, const Lds &L
     float con = 0.0f;
     for (;;) {
       cnt.shadow++;
-      if (trace_step<GRID>(P, L, r, stage != 0) == STEP_CONTINUE) continue;
+      if (trace_step_lazy<GRID>(P, L, r, stage != 0) == STEP_CONTINUE) continue;   // (lazy: only a second leg needs the arrival's position, see the service phase of photon_kernel)
       const float tauB = r.acc;
       const bool outTop = r.iz >= zIndexMax;
       if (stage == 0) con = tauB >= 0.0f ? (weight * normPF) * expf(-tauB) : 0.0f;
@@ -155,6 +155,7 @@ __device__ __forceinline__ void intensity_contribution(const PR &P, const Lds &L
       } else if (stage == 2) {
         if (outTop && tauB >= 0.0f) con = (weight * normPF) * expf(-tauB);
         else if (tauB >= 0.0f && r.iz >= 1) {   // second leg, up to the free path (not from below the grid: see the light phase)
+          finish_arrival(r);                     // (the first leg has arrived at tauMax inside the grid: nothing else gets here)
           r.acc = 0.0f; r.target = tauFree; stage = 3;
           cnt.calls++;
           continue;
@@ -823,6 +824,10 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
               else if (stage == 2) {
                 if (outTop) con = direct;
                 else if (tauB >= 0.0f && sr.iz >= 1) {                      // second leg, up to the free path (:1576-1587)
+                  // (the first leg has ARRIVED at tauMax inside the grid -- the only way to get here: an exit through the bottom has
+                  // iz < 1, a failed trace tauB = -2 -- and its last advance is still to be made: trace_step_lazy.  Every other ray
+                  // that ends at its target contributes nothing, wherever it stands: stages 1 and 3 count only through the top.)
+                  finish_arrival(sr);
                   sr.acc = 0.0f; sr.target = sTauFree; sInfo |= 1 << 16; rst = R_TRACE; secondLeg = true;   // (stage 2 -> 3)
                 }
                 // (a first leg that left through the BOTTOM -- a downward radiance direction -- gets no second leg: the
@@ -896,7 +901,10 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
             wc.shadow += nTracing;
             PROF_BEGIN();
             if (tracing) {   // a failed shadow ray contributes nothing (:1531-1535: its optical path is -2)
-              if (trace_step<GRID>(P, L, sr, ((sInfo >> 16) & 3) != 0) != STEP_CONTINUE) rst = R_ENDED;
+              // (an arrival: see the service phase.  The ray's own stage says whether it has a target: the wave-uniform P.useRRI says the
+              // same, and as a run-time flag in this loop it came out as a lane mask made under another loop's exec mask -- GridPlace's trap,
+              // caught by tests/test_build_isa.py)
+              if (trace_step_lazy<GRID>(P, L, sr, ((sInfo >> 16) & 3) != 0) != STEP_CONTINUE) rst = R_ENDED;
             }
             PROF_END(PH_RAYSTEP, nTracing);
           };
@@ -957,6 +965,12 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
       if constexpr (BATCHED) laneBlk = lane_block(rng.batch);
       const Tally<ColdProblem, BATCHED> tally{Pe, L, laneBlk};
       PROF_BEGIN();
+      // a photon that has arrived at its optical depth makes the last advance of its trace here (trace_step_lazy / finish_arrival):
+      // once per event instead of a division at every voxel step
+      if (wantEvent && st == ST_EVENT && arrival_pending(r)) finish_arrival(r);
+      // ... and one that has left the grid gets its height (finish_exit).  (The general kernels do that where the step ends: here it
+      // cost them nine spilled vector registers -- and with max cross-section the layer index says nothing about the height.)
+      if (!GENERAL && wantEvent && (st == ST_EVENT || st == ST_EXIT)) finish_exit(Pe, r);
       // ---- part A: endings that need no random number -- tracer drop, exit through the top, arrival at a black
       //      surface -- are tallied first so that the lanes can be given their next photon before the wave
       //      generates its random block (part C), which then serves old and new photons in one go.
@@ -1280,7 +1294,8 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
       PROF_BEGIN();
       if (tracing) {
         if constexpr (LANE_COUNTS) accSteps++;
-        const StepResult s = trace_step<GRID, !INTENSITY>(P, L, r, true);
+        const StepResult s = trace_step_lazy<GRID, !INTENSITY>(P, L, r, true);   // (an arrival is finished by the event phase)
+        if (GENERAL && s == STEP_EXIT) finish_exit(P, r);
         // (an exit through the top, or onto a black surface, ends the photon: such lanes wait for the turnover quorum)
         if (s != STEP_CONTINUE)
           st = s == STEP_DONE ? ST_EVENT : (s == STEP_ERROR ? ST_DROPPED : ((r.iz >= 1 || blackSurface) ? ST_EXIT : ST_EVENT));

@@ -334,8 +334,18 @@ __device__ __forceinline__ float cell_extinction(const PR &P, const Lds &L, int 
 // escapes): on a 64-lane wavefront the lanes take the reference's if/else arms in every combination at every step,
 // so branches would execute both arms anyway and add exec-mask bookkeeping on top.  The arithmetic of each arm is
 // exactly the reference's (checked bit for bit against the oracle by the tracer tests).
+//
+// LAZY ARRIVAL (round 4).  The step in which the optical path reaches its target (:1721-1731) ends the trace inside the cell:
+// the reference advances the position by (target - path so far) / extinction -- a division by a value that changes from cell to
+// cell: a reciprocal (quarter rate), its refinement and the five operations of exact_div, nine vector instructions that every
+// lane of every step paid for although a trace arrives once.  trace_step_lazy leaves the position where it is and returns
+// STEP_DONE with   r.acc = target - path so far,   r.target = -extinction   (negative: the mark of an arrival not yet finished;
+// a reached cell has extinction > 0, and targets are never negative); finish_arrival does the division and the advance -- the
+// same operations on the same values -- where the arrival is dealt with: the event phase for photons, the service phase for
+// a local-estimate ray that goes on to its second leg (a ray that ends at its target needs no position at all).
+// trace_step is the two together (nested local estimate, the tracer test hook).
 template <int GRID, bool CLEARMAP = false, class PR>
-__device__ __forceinline__ StepResult trace_step(const PR &P, const Lds &L, Ray &r, bool hasTarget) {
+__device__ __forceinline__ StepResult trace_step_lazy(const PR &P, const Lds &L, Ray &r, bool hasTarget) {
   // the extinction of the current cell is requested first: its latency (LDS, or L2 / HBM for grids that do not fit
   // in LDS) is covered by the three face-distance divisions below
   const float ext = cell_extinction<GRID, CLEARMAP>(P, L, r.ix, r.iy, r.iz);
@@ -360,14 +370,11 @@ __device__ __forceinline__ StepResult trace_step(const PR &P, const Lds &L, Ray 
 
   const float tauCell = step * ext;
   bool reach = false;
-  float adv = step;
-  if (hasTarget) {                                                     // :1721-1731
-    reach = r.acc + tauCell > r.target;
-    float part = exact_div(r.target - r.acc, ext, refined_rcp(ext));
-    if (__builtin_expect(reach && ext < 1e-20f, 0)) part = (r.target - r.acc) / ext;
-    adv = reach ? part : step;
-  }
-  r.acc = reach ? r.target : r.acc + tauCell;
+  if (hasTarget) reach = r.acc + tauCell > r.target;                  // :1721-1731
+  const float adv = reach ? 0.0f : step;                               // (an arrival stays where it is: finish_arrival)
+  const float rest = r.target - r.acc;
+  r.target = reach ? -ext : r.target;
+  r.acc = reach ? rest : r.acc + tauCell;
 
   const float ax = r.x + adv * r.dx, ay = r.y + adv * r.dy, az = r.z + adv * r.dz;
   const bool hx = !reach && stx <= step, hy = !reach && sty <= step, hz = !reach && stz <= step;   // face reached
@@ -391,9 +398,34 @@ __device__ __forceinline__ StepResult trace_step(const PR &P, const Lds &L, Ray 
     r.iy = yLo ? P.ny : (yHi ? 1 : r.iy);
   }
 
-  const bool top = r.iz > P.nz, bottom = r.iz < 1;                     // :1793-1804
-  r.z = top ? P.zMax + two_spacingf(P.zMax) : (bottom ? P.z0 : r.z);
+  // :1793-1804: a ray that has left through the top or the bottom stands at zMax + 2 spacing(zMax) or at z0 -- also LAZY: the
+  // trace is over, and the height is put there by whoever needs it (finish_exit: the event phase for photons; a local-estimate
+  // ray's end only asks for its layer index)
+  const bool top = r.iz > P.nz, bottom = r.iz < 1;
   return reach ? STEP_DONE : ((top || bottom) ? STEP_EXIT : STEP_CONTINUE);
+}
+// the height of a ray that has left the grid :1793-1804 (a ray inside keeps its own)
+template <class PR>
+__device__ __forceinline__ void finish_exit(const PR &P, Ray &r) {
+  r.z = r.iz > P.nz ? P.zMax + two_spacingf(P.zMax) : (r.iz < 1 ? P.z0 : r.z);
+}
+// has the trace arrived at its target without its last advance (trace_step_lazy)?
+__device__ __forceinline__ bool arrival_pending(const Ray &r) { return r.target < 0.0f; }
+// the advance of the arriving step :1724-1731, :1736-1738 (the position ends inside the cell: no face, no index, no wrap)
+__device__ __forceinline__ void finish_arrival(Ray &r) {
+  const float ext = -r.target, rest = r.acc;
+  float part = exact_div(rest, ext, refined_rcp(ext));
+  if (__builtin_expect(ext < 1e-20f, 0)) part = rest / ext;
+  r.x = r.x + part * r.dx; r.y = r.y + part * r.dy; r.z = r.z + part * r.dz;
+}
+// the reference's step: an arrival finished at once, the optical path at its target
+template <int GRID, bool CLEARMAP = false, class PR>
+__device__ __forceinline__ StepResult trace_step(const PR &P, const Lds &L, Ray &r, bool hasTarget) {
+  const float target = r.target;
+  const StepResult s = trace_step_lazy<GRID, CLEARMAP>(P, L, r, hasTarget);
+  if (s == STEP_DONE) { finish_arrival(r); r.acc = target; r.target = target; }
+  if (s == STEP_EXIT) finish_exit(P, r);
+  return s;
 }
 
 // findXYIndicies :1353-1374, findZIndex :1376-1388
