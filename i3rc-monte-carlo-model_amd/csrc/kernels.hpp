@@ -627,8 +627,14 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
     if (adaptLight) {
       raysSeen += raysStarted; raysStarted = 0u;
       if (raysSeen > 0u && wc.shadow > 0u) {
-        const int t = (int)(70.0f * __builtin_amdgcn_rsqf((float)wc.shadow * __builtin_amdgcn_rcpf((float)raysSeen)));
-        liThr = __builtin_amdgcn_readfirstlane(t < 16 ? 16 : (t > 32 ? 32 : t));
+#ifndef I3RC_LITHR_COEF
+#define I3RC_LITHR_COEF 70.0f
+#endif
+#ifndef I3RC_LITHR_MIN
+#define I3RC_LITHR_MIN 16
+#endif
+        const int t = (int)(I3RC_LITHR_COEF * __builtin_amdgcn_rsqf((float)wc.shadow * __builtin_amdgcn_rcpf((float)raysSeen)));
+        liThr = __builtin_amdgcn_readfirstlane(t < I3RC_LITHR_MIN ? I3RC_LITHR_MIN : (t > 32 ? 32 : t));
       }
     }
   };
