@@ -1209,10 +1209,11 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
     kern = direct_rays(h) ? direct[place] : ring[place];
   } else {
     static const bool tblOn = !(std::getenv("I3RC_TABLE_LDS") && std::atoi(std::getenv("I3RC_TABLE_LDS")) == 0);
-    static const int tblPlaces = std::getenv("I3RC_FUSED_TABLE_LDS_PLACES") ? std::atoi(std::getenv("I3RC_FUSED_TABLE_LDS_PLACES")) : 3;   // (measured: Landsat-36 +13 %, radar 640 +12 %, step cloud +1.5 ... 3 % in the kernels' own time)
+    static const int tblPlaces = std::getenv("I3RC_FUSED_TABLE_LDS_PLACES") ? std::atoi(std::getenv("I3RC_FUSED_TABLE_LDS_PLACES")) : 11;   // (measured: Landsat-36 +13 %, radar 640 +12 %, step cloud +1.5 ... 3 % in the kernels' own time; on column records +1 ... 2.5 %)
     if (tblOn && ((tblPlaces >> place) & 1) && place != GRID_BRICKS && (plan.P.uniformPf >= 1 || h->nInvEntries[0] == 1) &&
         plan.ldsBytes + sizeof(float) * (size_t)plan.P.comp0.nInv <= 79 * 1024) {
-      static const Kernel tbl[2] = {photon_kernel<PhiloxBatchStream, false, false, GRID_LDS, true>, photon_kernel<PhiloxBatchStream, false, false, GRID_GLOBAL, true>};
+      static const Kernel tbl[4] = {photon_kernel<PhiloxBatchStream, false, false, GRID_LDS, true>, photon_kernel<PhiloxBatchStream, false, false, GRID_GLOBAL, true>,
+                                    nullptr, photon_kernel<PhiloxBatchStream, false, false, GRID_COLUMNS, true>};
       kern = tbl[place];
       threads = 1024;
       ldsBytes = (plan.ldsBytes + sizeof(float) * (size_t)plan.P.comp0.nInv + 15) & ~(size_t)15;

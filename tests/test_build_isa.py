@@ -71,8 +71,8 @@ def test_production_kernels_keep_their_state_in_registers():
     # (round 4: ... and the radiance kernels without an event ring, "one direction")
     # (... and one of each for fields with column records, GRID_COLUMNS)
     assert len(rows) == 28 and sum("table in LDS" in r["name"] for r in rows) == 4 and sum("one direction" in r["name"] for r in rows) == 8, [r["name"] for r in rows]
-    fused = [r for r in everything if r["name"].startswith("photon_kernel<PhiloxBatchStream")]   # the fused multi-batch kernels: six flux, eight radiance (round 4)
-    assert len(fused) == 14 and sum(r["name"].startswith("photon_kernel<PhiloxBatchStream, true") for r in fused) == 8, [r["name"] for r in fused]
+    fused = [r for r in everything if r["name"].startswith("photon_kernel<PhiloxBatchStream")]   # the fused multi-batch kernels: seven flux, eight radiance (round 4)
+    assert len(fused) == 15 and sum(r["name"].startswith("photon_kernel<PhiloxBatchStream, true") for r in fused) == 8, [r["name"] for r in fused]
     for r in rows + fused:
         if r in fused and "table in LDS" in r["name"]:
             # the fused kernels want 66 vector registers; their table-in-LDS instantiations (1024 threads, two workgroups per CU: eight
