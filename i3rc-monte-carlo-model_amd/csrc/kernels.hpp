@@ -145,7 +145,7 @@ __device__ __forceinline__ void intensity_contribution(const PR &P, const Lds &L
     float con = 0.0f;
     for (;;) {
       cnt.shadow++;
-      if (trace_step_lazy<GRID>(P, L, r, stage != 0) == STEP_CONTINUE) continue;   // (lazy: only a second leg needs the arrival's position, see the service phase of photon_kernel)
+      if (trace_step_lazy<GRID, false, true>(P, L, r, stage != 0) == STEP_CONTINUE) continue;   // (lazy: only a second leg needs the arrival's position, see the service phase of photon_kernel)
       const float tauB = r.acc;
       const bool outTop = r.iz >= zIndexMax;
       if (stage == 0) con = tauB >= 0.0f ? (weight * normPF) * expf(-tauB) : 0.0f;
@@ -910,7 +910,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
               // (an arrival: see the service phase.  The ray's own stage says whether it has a target: the wave-uniform P.useRRI says the
               // same, and as a run-time flag in this loop it came out as a lane mask made under another loop's exec mask -- GridPlace's trap,
               // caught by tests/test_build_isa.py)
-              if (trace_step_lazy<GRID>(P, L, sr, ((sInfo >> 16) & 3) != 0) != STEP_CONTINUE) rst = R_ENDED;
+              if (trace_step_lazy<GRID, false, GENERAL>(P, L, sr, ((sInfo >> 16) & 3) != 0) != STEP_CONTINUE) rst = R_ENDED;
             }
             PROF_END(PH_RAYSTEP, nTracing);
           };
@@ -1300,7 +1300,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
       PROF_BEGIN();
       if (tracing) {
         if constexpr (LANE_COUNTS) accSteps++;
-        const StepResult s = trace_step_lazy<GRID, !INTENSITY>(P, L, r, true);   // (an arrival is finished by the event phase)
+        const StepResult s = trace_step_lazy<GRID, !INTENSITY, GENERAL>(P, L, r, true);   // (an arrival is finished by the event phase)
         if (GENERAL && s == STEP_EXIT) finish_exit(P, r);
         // (an exit through the top, or onto a black surface, ends the photon: such lanes wait for the turnover quorum)
         if (s != STEP_CONTINUE)

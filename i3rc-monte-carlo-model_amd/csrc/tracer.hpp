@@ -344,7 +344,9 @@ __device__ __forceinline__ float cell_extinction(const PR &P, const Lds &L, int 
 // same operations on the same values -- where the arrival is dealt with: the event phase for photons, the service phase for
 // a local-estimate ray that goes on to its second leg (a ray that ends at its target needs no position at all).
 // trace_step is the two together (nested local estimate, the tracer test hook).
-template <int GRID, bool CLEARMAP = false, class PR>
+// (BRANCHY: the general kernels keep the guarded division in a branch of its own -- the form below cost their radiance instantiations,
+// which sit at the 168 registers of three waves per SIMD, four spilled vector registers)
+template <int GRID, bool CLEARMAP = false, bool BRANCHY = false, class PR>
 __device__ __forceinline__ StepResult trace_step_lazy(const PR &P, const Lds &L, Ray &r, bool hasTarget) {
   // the extinction of the current cell is requested first: its latency (LDS, or L2 / HBM for grids that do not fit
   // in LDS) is covered by the three face-distance divisions below
@@ -352,14 +354,36 @@ __device__ __forceinline__ StepResult trace_step_lazy(const PR &P, const Lds &L,
   const int cx = r.cx, cy = r.cy, cz = r.cz;
   const float ex = lds_read(r.ex + (r.ix << 2)), ey = lds_read(r.ey + (r.iy << 2)), ez = lds_read(r.ez + (r.iz << 2));
   float stx, sty, stz;
-  if (__builtin_expect(r.slow, 0)) {   // a direction cosine of (almost) zero: the reference's guarded division
-    stx = fabsf(r.dx) >= 2.0f * kTiny ? (ex - r.x) / r.dx : kHuge;
-    sty = fabsf(r.dy) >= 2.0f * kTiny ? (ey - r.y) / r.dy : kHuge;
-    stz = fabsf(r.dz) >= 2.0f * kTiny ? (ez - r.z) / r.dz : kHuge;
+  if (BRANCHY) {
+    if (__builtin_expect(r.slow, 0)) {   // a direction cosine of (almost) zero: the reference's guarded division
+      stx = fabsf(r.dx) >= 2.0f * kTiny ? (ex - r.x) / r.dx : kHuge;
+      sty = fabsf(r.dy) >= 2.0f * kTiny ? (ey - r.y) / r.dy : kHuge;
+      stz = fabsf(r.dz) >= 2.0f * kTiny ? (ez - r.z) / r.dz : kHuge;
+    } else {
+      stx = exact_div(ex - r.x, r.dx, r.rx);
+      sty = exact_div(ey - r.y, r.dy, r.ry);
+      stz = exact_div(ez - r.z, r.dz, r.rz);
+    }
   } else {
-    stx = exact_div(ex - r.x, r.dx, r.rx);
-    sty = exact_div(ey - r.y, r.dy, r.ry);
-    stz = exact_div(ez - r.z, r.dz, r.rz);
+  // (every lane, every axis: on an axis whose cosine is below 1e-20 the quotient is rubbish and is replaced below)
+  stx = exact_div(ex - r.x, r.dx, r.rx); sty = exact_div(ey - r.y, r.dy, r.ry); stz = exact_div(ez - r.z, r.dz, r.rz);
+  // A direction cosine of (almost) zero: the reference's guarded division (:1697-1704: a face is never reached along an axis whose
+  // |cosine| is below 2 tiny).  Such lanes are the rule, not the exception -- a sun at the zenith gives every photon dx = dy = 0
+  // until its first scattering, a nadir radiance direction every ray of it -- so that in nine voxel-step phases of ten SOME lane
+  // of the wave is one: a branch of its own for them (three guarded IEEE divisions behind three exec masks, then the fast path
+  // for the others) was twenty vector and as many scalar instructions on top of every such phase.  Now: one uniform test, three
+  // selects for the lanes concerned; only cosines between 2 tiny and 1e-20 (none in practice) still take the IEEE division.
+  if (__ballot(r.slow != 0) != 0ull) {
+    const float adx = fabsf(r.dx), ady = fabsf(r.dy), adz = fabsf(r.dz);
+    const bool tx = adx < 1e-20f, ty = ady < 1e-20f, tz = adz < 1e-20f;
+    stx = tx ? kHuge : stx; sty = ty ? kHuge : sty; stz = tz ? kHuge : stz;
+    const bool mx = tx && adx >= 2.0f * kTiny, my = ty && ady >= 2.0f * kTiny, mz = tz && adz >= 2.0f * kTiny;
+    if (__builtin_expect(__ballot(mx || my || mz) != 0ull, 0)) {
+      if (mx) stx = (ex - r.x) / r.dx;
+      if (my) sty = (ey - r.y) / r.dy;
+      if (mz) stz = (ez - r.z) / r.dz;
+    }
+  }
   }
   float step = stx;
   step = sty < step ? sty : step;
@@ -422,7 +446,7 @@ __device__ __forceinline__ void finish_arrival(Ray &r) {
 template <int GRID, bool CLEARMAP = false, class PR>
 __device__ __forceinline__ StepResult trace_step(const PR &P, const Lds &L, Ray &r, bool hasTarget) {
   const float target = r.target;
-  const StepResult s = trace_step_lazy<GRID, CLEARMAP>(P, L, r, hasTarget);
+  const StepResult s = trace_step_lazy<GRID, CLEARMAP, false>(P, L, r, hasTarget);
   if (s == STEP_DONE) { finish_arrival(r); r.acc = target; r.target = target; }
   if (s == STEP_EXIT) finish_exit(P, r);
   return s;

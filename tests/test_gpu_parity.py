@@ -722,7 +722,9 @@ def test_looking_ahead_in_fused_groups_never_changes_a_batch():
         a = plain.computeRadiativeTransfer(M.new_RandomNumberSequence(seed), M.new_PhotonStream(mu0, az, n))
         b = ahead.computeRadiativeTransferLookingAhead(M.new_RandomNumberSequence(seed), M.new_PhotonStream(mu0, az, n), lookAhead=look)
         assert a["counters"] == b["counters"], (seed, n)
-        assert np.allclose(a["raw"], b["raw"], rtol=1e-5, atol=1e-6)
+        # (the plain launch gathers a workgroup's absorption in float32 in LDS, some 1e4 additions per column: against the fused
+        # launch's float64 atomics that is a few 1e-6 of a column's sum, and up to 1e-5 now and then -- the order of the additions)
+        assert np.allclose(a["raw"], b["raw"], rtol=1e-4, atol=1e-6)
 
     both((7, 0), 1)                                     # the drivers' one-photon warm-up
     for b in range(1, 40):
