@@ -378,25 +378,9 @@ int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int n
     for (size_t c = 0; c < map.size(); ++c) map[c] = lo[c] | (hi[c] << 16);
     CCHK(h->dClearMap.upload(map.data(), sizeof(uint32_t) * map.size()));
   }
-  if (nz <= 65534) {
-    // Column records (DevProblem::colRec): possible when the cells with extinction of every column are one run of layers that
-    // hold one value (compared bit by bit; "no extinction" is the bit pattern of +0, what the record gives outside its run).
-    const size_t ncol = (size_t)nx * ny;
-    std::vector<uint32_t> rec(2 * ncol, 0u);
-    bool ok = true;
-    for (size_t c = 0; c < ncol && ok; ++c) {
-      uint32_t val = 0u; int first = 0, last = 0;   // 1-based layers of the run
-      for (int k = 0; k < nz && ok; ++k) {
-        uint32_t bits; std::memcpy(&bits, &totalExt[(size_t)k * ncol + c], sizeof(bits));
-        if (bits == 0u) continue;
-        if (first == 0) { val = bits; first = last = k + 1; }
-        else if (bits == val && last == k) last = k + 1;
-        else ok = false;
-      }
-      rec[2 * c] = val;
-      rec[2 * c + 1] = first == 0 ? 1u : ((uint32_t)first | ((uint32_t)(last - first) << 16));
-    }
-    if (ok) CCHK(h->dColRec.upload(rec.data(), sizeof(uint32_t) * rec.size()));
+  {
+    std::vector<uint32_t> rec(2 * (size_t)nx * ny);
+    if (i3rc_hip_column_records(nx, ny, nz, totalExt, rec.data()) == 1) CCHK(h->dColRec.upload(rec.data(), sizeof(uint32_t) * rec.size()));
   }
   CCHK(h->dCum.upload(cumExt, sizeof(float) * ncell * ncomp));
   CCHK(h->dSsa.upload(ssa, sizeof(float) * ncell * ncomp));
@@ -657,6 +641,31 @@ int i3rc_hip_select_grid_place(i3rc_hip_integrator *h, int place) {
 }
 
 int i3rc_hip_has_column_records(const i3rc_hip_integrator *h) { return h && h->dColRec.p ? 1 : 0; }
+
+/* Column records (DevProblem::colRec) of a field [nz][ny][nx]: possible when the cells with extinction of every column are ONE run
+ * of layers that hold ONE value -- compared bit by bit; "no extinction" is the bit pattern of +0, which is what a record gives
+ * outside its run (a -0, a NaN or a negative value is "something there" and must be the run's value like any other).  Host code
+ * only.  records (may be NULL): [ny * nx][2] words -- the value's bits; first layer (1-based) | (run length - 1) << 16; a clear
+ * column is the value 0 in layer 1.  Returns 1 when the field has the form, 0 when it has not (or has more than 65534 layers). */
+int i3rc_hip_column_records(int nx, int ny, int nz, const float *totalExt, uint32_t *records) {
+  if (nx < 1 || ny < 1 || nz < 1 || !totalExt || nz > 65534) return 0;
+  const size_t ncol = (size_t)nx * ny;
+  for (size_t c = 0; c < ncol; ++c) {
+    uint32_t val = 0u; int first = 0, last = 0;   // 1-based layers of the run
+    for (int k = 0; k < nz; ++k) {
+      uint32_t bits; std::memcpy(&bits, &totalExt[(size_t)k * ncol + c], sizeof(bits));
+      if (bits == 0u) continue;
+      if (first == 0) { val = bits; first = last = k + 1; }
+      else if (bits == val && last == k) last = k + 1;
+      else return 0;
+    }
+    if (records) {
+      records[2 * c] = val;
+      records[2 * c + 1] = first == 0 ? 1u : ((uint32_t)first | ((uint32_t)(last - first) << 16));
+    }
+  }
+  return 1;
+}
 
 int i3rc_hip_set_batch_fusion(i3rc_hip_integrator *h, int mode) {
   if (!h) return 1;

@@ -327,6 +327,10 @@ enum { I3RC_GRID_AUTO = 0, I3RC_GRID_LINEAR = 1, I3RC_GRID_BRICKS = 2, I3RC_GRID
 int i3rc_hip_select_grid_place(i3rc_hip_integrator *h, int place);
 /* 1 when the field has column records, else 0 */
 int i3rc_hip_has_column_records(const i3rc_hip_integrator *h);
+/* The test i3rc_hip_create applies, as host code of its own (no device needed): does the field totalExt [nz][ny][nx] have the form --
+ * in every column the cells whose extinction is not +0 are one run of layers holding one value, bit for bit?  Returns 1 / 0 and,
+ * when records is not NULL, writes [ny * nx][2] words: the value's bits; first layer (1-based) | (run length - 1) << 16. */
+int i3rc_hip_column_records(int nx, int ny, int nz, const float *totalExt, uint32_t *records);
 
 /* Test hook: the raw Philox4x32-10 blocks (out[n][blocksPerPhoton][4]) of photons firstPhoton..+n-1 and the
  * float32 deviates the photon streams derive from them (outf, same shape). */

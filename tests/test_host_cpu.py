@@ -35,6 +35,44 @@ def test_cabi_library_exports_every_declared_symbol():
         assert hasattr(comm, name), name
 
 
+def test_column_records_of_a_field():
+    """i3rc_hip_column_records (host code of the C ABI: the test i3rc_hip_create applies before it keeps a field as 8 bytes per
+    column): one run of one value per column, compared bit by bit -- the I3RC fields as data, and the cases that must say no."""
+    from tests import cases
+    L = M.binding.load()
+
+    def records(ext):
+        ext = np.ascontiguousarray(ext, np.float32)
+        nz, ny, nx = ext.shape
+        rec = np.zeros((ny * nx, 2), np.uint32)
+        ok = L.i3rc_hip_column_records(nx, ny, nz, ext.ctypes.data_as(M.binding.fp), rec.ctypes.data_as(M.binding.up))
+        assert ok == L.i3rc_hip_column_records(nx, ny, nz, ext.ctypes.data_as(M.binding.fp), None)
+        return ok, rec
+
+    for d, want in ((cases.landsat_cloud(), 1), (cases.landsat_cloud(nlayers=36), 1), (cases.step_cloud(), 1), (cases.column_clouds(), 1),
+                    (cases.radar_cloud_64(), 0), (cases.radar_cloud(), 0), (cases.irregular_domain(), 0)):
+        ok, rec = records(d["ext"])
+        assert ok == want
+        if ok:   # the records give back the field, bit for bit
+            ext = d["ext"]; nz, ny, nx = ext.shape
+            val = rec[:, 0].view(np.float32).reshape(ny, nx)
+            first, span = (rec[:, 1] & 0xFFFF).reshape(ny, nx).astype(np.int64), (rec[:, 1] >> 16).reshape(ny, nx).astype(np.int64)
+            k = np.arange(1, nz + 1)[:, None, None]
+            back = np.where((k >= first) & (k <= first + span), val[None], np.float32(0))
+            assert np.array_equal(back.view(np.uint32), ext.view(np.uint32))
+    one = np.zeros((6, 1, 2), np.float32)
+    one[1:4, 0, 0] = 0.5
+    assert records(one)[0] == 1
+    two_runs = one.copy(); two_runs[5, 0, 0] = 0.5
+    two_values = one.copy(); two_values[2, 0, 0] = 0.25
+    minus_zero = one.copy(); minus_zero[4, 0, 1] = -0.0; minus_zero[0, 0, 1] = 1.0
+    assert records(two_runs)[0] == 0 and records(two_values)[0] == 0 and records(minus_zero)[0] == 0
+    nan_run = one.copy(); nan_run[1:4, 0, 0] = np.nan                    # (one bit pattern: a run like any other)
+    assert records(nan_run)[0] == 1
+    assert records(np.ones((65535, 1, 1), np.float32))[0] == 0            # layer numbers are 16 bits
+    assert records(np.ones((65534, 1, 1), np.float32))[0] == 1
+
+
 def test_philox_known_answers():
     # Random123 kat_vectors, philox4x32 10 rounds
     assert philox4x32_10((0, 0, 0, 0), (0, 0)) == (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)
