@@ -605,8 +605,8 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
 
   // Thresholds: fixed when the caller asks for them (> 0), else adapted by every wave to its own photons at every
   // reservoir refill.  Event phase: the longer the photons' own traces (voxel steps per event), the more a
-  // lane loses by waiting for others, so the threshold falls as 64 / sqrt(steps per event) (measured optima: 40 at
-  // 2.5 steps per event, 32 at 3.5, 24 at 9, 16 at 14 ... 16).  Ray mode's service phase: likewise with the length of
+  // lane loses by waiting for others, so the threshold falls with the steps per event: 44 - 2 steps per event for the flux
+  // kernels, 44 - 1.2 steps per event for the radiance kernels, within 12 ... 44 (adapt_thresholds; until round 4 58 / sqrt(steps per event)).  Ray mode's service phase: likewise with the length of
   // the shadow rays, 70 / sqrt(steps per ray) within 16..32.  Thresholds only schedule work: no photon path depends on them.
   int evThr = evThreshold > 0 ? evThreshold : -evThreshold;
   int liThr = lightThreshold > 0 ? lightThreshold : -lightThreshold;
@@ -620,7 +620,16 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
     if (adaptEvent) {
       const float events = (float)(wc.scat + wc.photons + wc.surf), steps = (float)wc.steps;
       if (events > 0.0f && steps > 0.0f) {
-        const int t = (int)(58.0f * __builtin_amdgcn_rsqf(steps * __builtin_amdgcn_rcpf(events)));
+        // (round 4, the step phase a third cheaper than it was: 44 - slope * steps per event fits the measured optima -- step cloud 36 ... 40
+        // at 2.5 steps per event, Landsat-36 28 at 9.5, Landsat-119 18 ... 20 at 15 -- where 58 / sqrt(steps per event) sat below them on
+        // the long traces; radiance kernels, whose photons share the wave's time with their rays, want the flatter slope)
+#ifndef I3RC_EVTHR_SLOPE_FLUX
+#define I3RC_EVTHR_SLOPE_FLUX 2.0f
+#endif
+#ifndef I3RC_EVTHR_SLOPE_RADIANCE
+#define I3RC_EVTHR_SLOPE_RADIANCE 1.2f
+#endif
+        const int t = (int)(44.0f - (INTENSITY ? I3RC_EVTHR_SLOPE_RADIANCE : I3RC_EVTHR_SLOPE_FLUX) * (steps * __builtin_amdgcn_rcpf(events)));
         evThr = __builtin_amdgcn_readfirstlane(t < 12 ? 12 : (t > 44 ? 44 : t));
       }
     }

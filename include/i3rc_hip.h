@@ -285,8 +285,8 @@ int64_t i3rc_hip_timed_launch_count(const i3rc_hip_integrator *h);
 const char *i3rc_hip_last_kernel_name(const i3rc_hip_integrator *h);
 
 /* Experiment knobs (not part of the reference API): lanes that must be waiting before a wavefront runs its
- * event phase (1..64; 0 = default: every wave adapts it to its photons' voxel steps per event, 64 / sqrt(steps per
- * event) within 12..44) and workgroups per CU (0 = occupancy query). */
+ * event phase (1..64; 0 = default: every wave adapts it to its photons' voxel steps per event, 44 - 2 steps per event
+ * -- radiance kernels 44 - 1.2 steps per event -- within 12..44) and workgroups per CU (0 = occupancy query). */
 int i3rc_hip_set_tuning(i3rc_hip_integrator *h, int evThreshold, int blocksPerCU);
 /* ... and lanes whose local-estimate (shadow) ray has ended before the wavefront runs its light phase (1..64;
  * 0 = default: adapted to the length of the rays, 70 / sqrt(steps per ray) within 16..32; radiance runs only). */
