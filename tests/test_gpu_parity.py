@@ -99,9 +99,14 @@ def _random_rays(rng, d, n, oracle_integ):
     dirs[:50] = [0, 0, -1]
     dirs[50:100] = [0, 0, 1]
     dirs[120:140, 2] = f32(1e-7)   # grazing rays (always given a finite optical path below)
+    # direction cosines the reference still divides by (2 tiny <= |cosine|: :1697-1704) although the kernels' reciprocal-based
+    # division does not reach down there (< 1e-20: the guarded IEEE division behind its own uniform test), and one below 2 tiny
+    dirs[140:150, 0] = f32(1e-25)
+    dirs[150:160, 1] = f32(-3e-30)
+    dirs[160:170, 0] = f32(1e-39)
     idx = np.stack([ix, iy, iz], axis=1).astype(np.int32)
     target = np.where(rng.random(n) < 0.7, -np.log(np.maximum(rng.random(n), 1e-12)), -1.0).astype(np.float32)
-    target[120:140] = f32(0.5)
+    target[120:170] = f32(0.5)
     return dirs, pos, idx, target
 
 
