@@ -124,6 +124,21 @@ def loop_rows():
 
 bench_rows(); config_rows(); phase_rows(); loop_rows()
 lines = open(os.path.join(ROOT, "DESIGN.md")).read().split("\n")
+# the Fortran drivers end to end: two runs in the file; the row quotes both and carries the smaller one as its value
+dt = text("driver_timing.txt")
+own = [int(x) for x in re.findall(r"i3rcDriver 1000 batches x 1e6 photons: (\d+) ms wall", dt)]
+ref = [int(x) for x in re.findall(r"reference driver \(unchanged\) 1000 batches: (\d+) ms wall", dt)]
+steady = re.findall(r"i3rcDriver ([\d.]+) ms per batch .*?unchanged reference driver ([\d.]+) ms per batch", dt)
+drv = {
+    "| unchanged reference driver, 1000 batches, wall ms": "| unchanged reference driver, 1000 batches, wall ms (the two runs: %s) | %d | `profiles/%s_driver_timing.txt` |" % (", ".join(map(str, ref)), min(ref), TAG),
+    "| `i3rcDriver` (device moments), 1000 batches, wall ms": "| `i3rcDriver` (device moments), 1000 batches, wall ms (%s) | %d | `profiles/%s_driver_timing.txt` |" % (", ".join(map(str, own)), min(own), TAG),
+    "| steady state of the batch loop (1000 − 10 batches): unchanged reference driver": "| steady state of the batch loop (1000 − 10 batches): unchanged reference driver, ms per batch (%s) | %s | `profiles/%s_driver_timing.txt` |" % (", ".join(x[1] for x in steady), min(x[1] for x in steady), TAG),
+    "| … `i3rcDriver`, ms per batch": "| … `i3rcDriver`, ms per batch (%s; process start and file output are in these figures, which scatter by 0.05 from run to run) | %s | `profiles/%s_driver_timing.txt` |" % (", ".join(x[0] for x in steady), min(x[0] for x in steady), TAG),
+}
+for i, line in enumerate(lines):
+    for k, v in drv.items():
+        if line.startswith(k) and line != v:
+            print(line, "\n ->", v); lines[i] = v
 seen = {}
 changed = 0
 for i, line in enumerate(lines):
