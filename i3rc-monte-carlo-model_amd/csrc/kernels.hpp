@@ -919,7 +919,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
               // (an arrival: see the service phase.  The ray's own stage says whether it has a target: the wave-uniform P.useRRI says the
               // same, and as a run-time flag in this loop it came out as a lane mask made under another loop's exec mask -- GridPlace's trap,
               // caught by tests/test_build_isa.py)
-              if (trace_step_lazy<GRID, false, GENERAL>(P, L, sr, ((sInfo >> 16) & 3) != 0) != STEP_CONTINUE) rst = R_ENDED;
+              if (trace_step_lazy<GRID, false, GENERAL, !DIRECT>(P, L, sr, ((sInfo >> 16) & 3) != 0) != STEP_CONTINUE) rst = R_ENDED;   // (ring kernels: the short form, see trace_step_lazy)
             }
             PROF_END(PH_RAYSTEP, nTracing);
           };

@@ -346,7 +346,9 @@ __device__ __forceinline__ float cell_extinction(const PR &P, const Lds &L, int 
 // trace_step is the two together (nested local estimate, the tracer test hook).
 // (BRANCHY: the general kernels keep the guarded division in a branch of its own -- the form below cost their radiance instantiations,
 // which sit at the 168 registers of three waves per SIMD, four spilled vector registers)
-template <int GRID, bool CLEARMAP = false, bool BRANCHY = false, class PR>
+// (SHORT: the three proximity tests behind exec masks of their own -- see below; the photon steps of the ring kernels, whose 96 registers
+// the other form overran by two)
+template <int GRID, bool CLEARMAP = false, bool BRANCHY = false, bool SHORT = false, class PR>
 __device__ __forceinline__ StepResult trace_step_lazy(const PR &P, const Lds &L, Ray &r, bool hasTarget) {
   // the extinction of the current cell is requested first: its latency (LDS, or L2 / HBM for grids that do not fit
   // in LDS) is covered by the three face-distance divisions below
@@ -404,16 +406,28 @@ __device__ __forceinline__ StepResult trace_step_lazy(const PR &P, const Lds &L,
   const bool hx = !reach && stx <= step, hy = !reach && sty <= step, hz = !reach && stz <= step;   // face reached
   // :1744-1769 the face position itself when the face is reached, else the advanced position; the index moves on
   // when the face is reached or the position ends within 2 spacing() of it
-  const bool bx = hx || (!reach && fabsf(ex - ax) <= two_spacingf(ax));
-  const bool by = hy || (!reach && fabsf(ey - ay) <= two_spacingf(ay));
-  const bool bz = hz || (!reach && fabsf(ez - az) <= two_spacingf(az));
+  bool bx, by, bz;
+  if (SHORT) {   // (the three tests behind exec masks of their own, as before round 4)
+    bx = hx || (!reach && fabsf(ex - ax) <= two_spacingf(ax));
+    by = hy || (!reach && fabsf(ey - ay) <= two_spacingf(ay));
+    bz = hz || (!reach && fabsf(ez - az) <= two_spacingf(az));
+  } else {
+  // (bitwise, not short-circuit: every lane of the step makes the three comparisons -- nearly every lane needs two of them anyway --
+  // instead of three exec-mask regions of four scalar instructions each: the scalar unit, one per compute unit, issues 0.6 ... 0.7
+  // instructions per cycle in these kernels and is as busy as the vector units)
+  const bool nx_ = fabsf(ex - ax) <= two_spacingf(ax), ny_ = fabsf(ey - ay) <= two_spacingf(ay), nz_ = fabsf(ez - az) <= two_spacingf(az);
+  bx = hx | (!reach & nx_); by = hy | (!reach & ny_); bz = hz | (!reach & nz_);
+  }
   r.x = hx ? ex : ax; r.y = hy ? ey : ay; r.z = hz ? ez : az;
   r.ix += bx ? cx : 0; r.iy += by ? cy : 0; r.iz += bz ? cz : 0;
 
   // periodic wrap :1774-1788 (y uses x's sign, as the reference does).  Few steps cross the domain's side walls: the
   // wrap is skipped by the whole wave when no lane needs it (a uniform branch on a ballot: two scalar instructions)
-  const bool xLo = r.ix <= 0, xHi = r.ix >= P.nx + 1, yLo = r.iy <= 0, yHi = r.iy >= P.ny + 1;
-  if (__ballot(xLo || xHi || yLo || yHi) != 0ull) {
+  // (the wave-uniform test as two compares whose lane masks are OR-ed in scalar registers: a ballot of the four conditions below
+  // came out as four compares, a select of 0 / 1 and a fifth compare)
+  if ((__builtin_amdgcn_uicmp((unsigned)(r.ix - 1), (unsigned)P.nx, 35 /* unsigned >= */) |
+       __builtin_amdgcn_uicmp((unsigned)(r.iy - 1), (unsigned)P.ny, 35)) != 0ull) {
+    const bool xLo = r.ix <= 0, xHi = r.ix >= P.nx + 1, yLo = r.iy <= 0, yHi = r.iy >= P.ny + 1;
     const float nudge = r.nudge;   // 2 cellIncrement(1) as a float: the nudges are +- 2 spacing()
     const float sxp = copysignf(two_spacingf(r.x), nudge), syp = copysignf(two_spacingf(r.y), nudge);
     r.x = xLo ? P.xMax + sxp : (xHi ? P.x0 + sxp : r.x);
@@ -446,7 +460,7 @@ __device__ __forceinline__ void finish_arrival(Ray &r) {
 template <int GRID, bool CLEARMAP = false, class PR>
 __device__ __forceinline__ StepResult trace_step(const PR &P, const Lds &L, Ray &r, bool hasTarget) {
   const float target = r.target;
-  const StepResult s = trace_step_lazy<GRID, CLEARMAP, false>(P, L, r, hasTarget);
+  const StepResult s = trace_step_lazy<GRID, CLEARMAP, false, false>(P, L, r, hasTarget);
   if (s == STEP_DONE) { finish_arrival(r); r.acc = target; r.target = target; }
   if (s == STEP_EXIT) finish_exit(P, r);
   return s;
