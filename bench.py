@@ -490,6 +490,12 @@ def worker(a):
                                              "v_rcp / v_sqrt / v_log 8.2: the 2-cycle figure holds for the simplest class only, "
                                              "this kernel's mix is issued at its own pace",
                      "useful_lane_frac": rate / ISSUE_PEAK * pmc["lane_occupancy"]}
+            if "scalar_instr_per_photon" in pmc:   # the scalar unit (one per compute unit) is nearly as busy as the vector units
+                spp = pmc["scalar_instr_per_photon"]
+                issue["scalar"] = {"instr_per_photon": spp, "per_cycle_per_cu": spp * mine / (avg_ms * 1e-3) / (N_SIMD / 4 * 2.4e9),
+                                   "measured_peak_per_cycle_per_cu": 4.0 / 4.91,
+                                   "note": "SALU + branch + scalar-memory instructions; peak: s_add_u32 issues every 4.91 cycles per SIMD "
+                                           "(tools/microbench/issue_rate.hip), one scalar unit per compute unit of four SIMDs"}
         if cpu_baseline is not None:
             cpu_baseline["calibration"] = load_calibration(name)
         total_photons = float(total_per_step) * a.steps

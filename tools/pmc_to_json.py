@@ -49,6 +49,8 @@ def collect(dst, files):
         if "SQ_INSTS_VALU" in v:
             e["valu_instr_per_photon"] = v["SQ_INSTS_VALU"] / n
             e["salu_instr_per_photon"] = v.get("SQ_INSTS_SALU", 0) / n
+            # everything the one scalar unit of a compute unit issues: scalar ALU, branches, scalar memory
+            e["scalar_instr_per_photon"] = (v.get("SQ_INSTS_SALU", 0) + v.get("SQ_INSTS_BRANCH", 0) + v.get("SQ_INSTS_SMEM", 0)) / n
         if "SQ_THREAD_CYCLES_VALU" in v and "SQ_INSTS_VALU" in v:
             # thread-cycles per VALU wave-instruction / 64: the share of the 64 lanes that were switched on
             # (SQ_THREAD_CYCLES_VALU counts active lanes x 4 cycles... calibrated: a full wave gives 64 per instruction
