@@ -718,9 +718,14 @@ bool common_class(const i3rc_hip_integrator *h, int srcKind) {
 
 // One radiance direction (nadir views: BASELINE.json's radar case): the radiance kernels without an event ring (photon_kernel,
 // DIRECT).  I3RC_DIRECT=0 keeps the ring for them too.
+#ifdef I3RC_NESTED_BUILD   /* measurement build: radiance problems run the general kernels with the nested local estimate (kernels.hpp) */
+constexpr bool kNestedBuild = true;
+#else
+constexpr bool kNestedBuild = false;
+#endif
 bool direct_rays(const i3rc_hip_integrator *h) {
   static const bool on = !(std::getenv("I3RC_DIRECT") && std::atoi(std::getenv("I3RC_DIRECT")) == 0);
-  return on && h->nDir == 1 && h->kernelVariant != I3RC_KERNEL_RING;
+  return on && h->nDir == 1 && h->kernelVariant != I3RC_KERNEL_RING && !kNestedBuild;
 }
 
 size_t ncell_bytes(const i3rc_hip_integrator *h) { return sizeof(float) * (size_t)h->nx * h->ny * h->nz; }
@@ -853,7 +858,7 @@ int upload_source(i3rc_hip_integrator *h, const i3rc_source *src, int64_t n, Run
 template <class Rng>
 int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, bool timeIt) {
   // fast specialisations when the problem is in the common class (see photon_kernel), else the general kernel
-  const bool simple = !Rng::kReplay && common_class(h, A.srcKind) && h->kernelVariant != I3RC_KERNEL_GENERAL;
+  const bool simple = !Rng::kReplay && common_class(h, A.srcKind) && h->kernelVariant != I3RC_KERNEL_GENERAL && !(kNestedBuild && plan.intensity);
   // the specialised kernels exist once per place of the extinction grid (LDS / global / global in bricks)
   using Kernel = void (*)(DevProblem, RunArgs, int, int);
   const int place = plan.place;
@@ -1108,7 +1113,7 @@ bool fusable(const i3rc_hip_integrator *h, int64_t nPhotons) {
   // (a batch's tally block beyond 256 MiB -- 3e7 cells -- would make a slot's pinned copy and its blocks unreasonably large: such
   // domains keep one launch per batch, whose tail is a small part of a launch that long anyway)
   static const bool radianceOff = std::getenv("I3RC_FUSED_RADIANCE") && std::atoi(std::getenv("I3RC_FUSED_RADIANCE")) == 0;
-  if (h->nDir > 0 && radianceOff) return false;
+  if (h->nDir > 0 && (radianceOff || kNestedBuild)) return false;
   return common_class(h, 0) && h->kernelVariant != I3RC_KERNEL_GENERAL && nPhotons < ((int64_t)1 << 31) &&
          h->layout.total * (int64_t)sizeof(double) <= ((int64_t)256 << 20);
 }

@@ -548,7 +548,16 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
   // hardware log / exp / reciprocal (2 ulp): these are weights of a Monte Carlo estimate, not trajectories.
   // The replay build and max cross-section keep the reference's nested order (intensity_contribution).
   constexpr bool DEFER = INTENSITY && !Rng::kReplay;
-  const bool defer = DEFER && rayTracing;            // max cross-section moves the photon inside the event: nested order there
+  // (max cross-section moves the photon inside the event: nested order there)
+#ifdef I3RC_NESTED_BUILD
+  // measurement build (tools/variant_bench.py build nested="-DI3RC_NESTED_BUILD"): the GENERAL kernels keep the reference's nested order
+  // -- every ray traced where its event happens, the roulette played after the trace, libm in the weights -- with the production random
+  // streams: a second implementation of :1419-1611 on the device to hold the ray queue against (profiles/r04_parity_xl.txt).  As a
+  // run-time switch it cost the general radiance kernels nine spilled vector registers.
+  const bool defer = DEFER && rayTracing && !GENERAL;
+#else
+  const bool defer = DEFER && rayTracing;
+#endif
   enum { R_EMPTY = 0, R_TRACE = 1, R_ENDED = 2 };
 #ifndef I3RC_STEP_AHEAD
 #define I3RC_STEP_AHEAD 2

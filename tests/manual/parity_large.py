@@ -3,7 +3,7 @@ oracle on all host cores, the oracle's sample produced by a child program while 
 workload, the domain means with their standard errors, the z score of every difference (GPU - oracle, in units of the
 combined standard error), the share of columns within 3 sigma and the largest column |z|.  The tests do the same at
 1e6-2e6 photons (tests/test_gpu_baseline_configs.py); this is the long version, run by hand on the GPU box:
-    python tests/manual/parity_large.py [workload ...] > gpurun_out/parity_large.txt
+    python tests/manual/parity_large.py [workload ...] > gpurun_out/parity_large.txt      (PARITY_SCALE=4: four times the sample)
 (test infrastructure: the only place the oracle is used is as the checker.)"""
 import os
 import subprocess
@@ -48,8 +48,10 @@ def main():
     names = sys.argv[1:] or list(PLAN)
     cores = min(16, len(os.sched_getaffinity(0)))
     worst = 0.0
+    scale = int(os.environ.get("PARITY_SCALE", "1"))   # PARITY_SCALE=4: four times the batches on both sides (half the standard errors)
     for name in names:
         nb, n, per_core, n_ref = PLAN[name]
+        nb, per_core = nb * scale, per_core * scale
         _, w = W.get(name)
         out = os.path.join(tempfile.mkdtemp(), f"oracle_{name}.npz")
         t0 = time.perf_counter()
@@ -90,7 +92,7 @@ def main():
         print(f"   per photon: dropped GPU {dg:.3e} oracle {do:.3e}; scatterings {kg:.4f} / {ko:.4f}; tracer steps {sg:.2f} / "
               f"{z['cellSteps'].sum() / n_o:.2f} (GPU leaves out rays whose roulette is lost before the trace: "
               f"{sum(r['counters']['raysSkipped'] for r in rs) / n_g:.3f} per photon)", flush=True)
-    if "landsat119_7dir" in names:
+    if "landsat119_7dir" in names and scale == 1:
         fixture_columns(M)
     print(f"largest |z| of a domain mean: {worst:.2f}")
 

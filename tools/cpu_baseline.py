@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--photons", type=int, default=0, help="photons per batch (0 = the workload's bounded sample)")
     ap.add_argument("--nlayers", type=int, default=0, help="step cloud only: 16 = BASELINE.json label, 32 = reference generator")
     ap.add_argument("--mu0", type=float, default=None)
+    ap.add_argument("--first-batch", type=int, default=1, help="batch number (second seed word) of the first batch: other numbers, another sample")
     ap.add_argument("--save-columns", action="store_true", help="with --save: per-column fields whatever the size of the domain")
     ap.add_argument("--save", default="", help="write per-batch results to this .npz: domain means of every batch, per-column fields of small domains")
     a = ap.parse_args()
@@ -82,7 +83,7 @@ def main():
         name, w = W.get("step32")
     photons = a.photons or w["cpu_photons"]
     cores = a.cores or min(16, len(os.sched_getaffinity(0)))
-    jobs = [(1 + i * a.batches_per_core, a.batches_per_core, photons, name, a.nlayers, a.mu0, a.save_columns) for i in range(cores)]
+    jobs = [(a.first_batch + i * a.batches_per_core, a.batches_per_core, photons, name, a.nlayers, a.mu0, a.save_columns) for i in range(cores)]
     t0 = time.perf_counter()
     with ProcessPoolExecutor(max_workers=cores) as ex:
         res = list(ex.map(_worker, jobs))
