@@ -35,3 +35,14 @@ for k, n in enumerate(names):
     worst = max(worst, abs(zq), abs(zn), abs(zqn))
     print(f"{n:11s} oracle {mo[k]:.6f} ({so[k]:.1e}) | GPU queue {mq[k]:.6f} ({sq[k]:.1e}) z {zq:+.2f} | GPU nested {mn[k]:.6f} ({sn[k]:.1e}) z {zn:+.2f} | queue - nested z {zqn:+.2f}")
 print(f"largest |z|: {worst:.2f}")
+
+# ---- radar-64 + nadir (config 2): three implementations of the local estimate on the device, per-batch means of 10^6 photons each in
+# profiles/r04_parity_xl_radar64_means.npz (columns fluxUp, fluxDown, nadir radiance): direct = the production kernels without an event
+# ring (4e9 photons, seeds (391, b)), ring = the same problem through the event ring (I3RC_DIRECT=0; 4e9, (491, b)), nested = the
+# measurement build -DI3RC_NESTED_BUILD (3e9, (591, b))
+r = np.load(os.path.join(ROOT, "profiles", "r04_parity_xl_radar64_means.npz"))
+print("radar-64 + nadir: " + ", ".join(f"{k} {len(r[k])} x 1e6" for k in ("direct", "ring", "nested")))
+for k, n in enumerate(("fluxUp", "fluxDown", "nadir radiance")):
+    m = {key: (r[key][:, k].astype(np.float64).mean(), r[key][:, k].astype(np.float64).std(ddof=1) / np.sqrt(len(r[key]))) for key in ("direct", "ring", "nested")}
+    zs = {f"{a} - {b}": (m[a][0] - m[b][0]) / np.hypot(m[a][1], m[b][1]) for a, b in (("direct", "nested"), ("ring", "nested"), ("direct", "ring"))}
+    print(f"{n:15s} " + " | ".join(f"{key} {v[0]:.6f} ({v[1]:.1e})" for key, v in m.items()) + " | " + ", ".join(f"{key} z {v:+.2f}" for key, v in zs.items()))
