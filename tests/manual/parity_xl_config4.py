@@ -4,7 +4,7 @@ kept in profiles/r04_parity_xl_config4_means.npz, and the table made from them (
   oracle_local  tools/cpu_baseline.py --config landsat119_7dir --cores 7 --batches-per-core 586 --photons 40000 --first-batch 100001 --save ...
                 (the build container's cores, 52 minutes: 1.64e8 photons)
   oracle_box    the same on the GPU box's 16 cores, --batches-per-core 128 --first-batch 200001 (8.2e7 photons)
-  gpu_queue     tools/scratch/gpu_means.py landsat119_7dir 1600 1e6 (the production kernels: ray queue, lazy roulette; seeds (191, b))
+  gpu_queue     tools/gpu_means.py landsat119_7dir 1600 1e6 (the production kernels: ray queue, lazy roulette; seeds (191, b))
   gpu_nested    the same program, 600 batches, on the measurement build -DI3RC_NESTED_BUILD: the general kernels with the local estimate
                 in the reference's nested order (every ray traced, roulette after the trace, libm in the weights), production random
                 streams; seeds (291, b)
