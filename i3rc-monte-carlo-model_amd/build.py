@@ -54,5 +54,24 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def variant_lib(name):
+    return os.path.join(CSRC, f"libi3rc_hip_var_{name}.so")
+
+
+def build_variant(name, flags, force=False):
+    """A side build of the library with extra -D flags (measurement knobs, tools/variant_bench.py; the nested-order build of
+    tests/test_gpu_features.py): csrc/libi3rc_hip_var_<name>.so, rebuilt when a source is newer."""
+    lib = variant_lib(name)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [HEADER]
+    if not force and os.path.exists(lib) and all(os.path.getmtime(d) <= os.path.getmtime(lib) for d in deps):
+        return lib
+    subprocess.check_call([hipcc()] + HIPCC_FLAGS + list(flags) + ["-o", lib, os.path.join(CSRC, "i3rc_hip.hip")], cwd=CSRC)
+    return lib
+
+
+# the measurement build in which the general kernels keep the reference's nested local estimate (kernels.hpp, I3RC_NESTED_BUILD)
+NESTED_FLAGS = ["-DI3RC_NESTED_BUILD"]
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

@@ -596,6 +596,52 @@ def test_the_same_photons_wherever_the_field_is_read_from():
         np.testing.assert_allclose(a["fluxUp"], b["fluxUp"], rtol=3e-6, atol=1e-9)
 
 
+def test_ray_queue_against_the_reference_nested_order_on_the_device():
+    """Two implementations of computeIntensityContribution (:1419-1611) on the device, production random streams in both: the kernels'
+    ray queue -- a ray's roulette played before its trace, hardware log / exp in its weights, rays traced apart from the events that
+    made them -- and the side build -DI3RC_NESTED_BUILD, whose general kernels keep the reference's nested order (every ray traced
+    where its event happens, the roulette after the trace, libm in the weights: the code the replay tests hold against the oracle
+    photon by photon).  Domain means of fluxes and radiances within 4 combined standard errors (4e6 photons a side; by hand at
+    3 - 4e9: profiles/r04_parity_xl.txt)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    nested = M.build.build_variant("nested", M.build.NESTED_FLAGS)
+    prog = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+import numpy as np
+import i3rc_monte_carlo_model_amd as M
+if os.environ.get("I3RC_LIB"):
+    M.build.LIB = os.environ["I3RC_LIB"]; M.build.needs_build = lambda: False
+from tests import cases
+seed0 = int(sys.argv[1])
+rri = dict(useRussianRouletteForIntensity=True, zetaMin=0.3)
+out = []
+for d, hg, kw, mu0, nb, n in ((cases.step_cloud(ssa=0.95, nlayers=8), 64, dict(rri, intensityMus=[1.0, 0.4, 0.7], intensityPhis=[0.0, 80.0, 250.0], surfaceAlbedo=0.3), 0.7, 40, 100000),
+                              (cases.radar_cloud_64(), 299, dict(rri, intensityMus=[1.0], intensityPhis=[0.0], surfaceAlbedo=0.0), 1.0, 20, 200000)):
+    dom = M.new_Domain(d["xe"], d["ye"], d["ze"]); dom.addOpticalComponent("c", d["ext"], d["ssa"], d["pf"], M.PhaseFunctionTable([M.henyey_greenstein(0.85, hg)]))
+    g = M.new_Integrator(dom); g.specifyParameters(**kw)
+    rows = []
+    for b in range(1, nb + 1):
+        r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((seed0, b)), M.new_PhotonStream(mu0, 0.0, n))
+        rows.append([float(r["fluxUp"].mean(dtype=np.float64)), float(r["fluxDown"].mean(dtype=np.float64))] + [float(v) for v in r["intensity"].mean(axis=(1, 2), dtype=np.float64)])
+    out.append([g.kernel_name(), rows])
+print(json.dumps(out))
+""" % root
+    res = {}
+    for which, env, seed0 in (("queue", {}, 811), ("nested", {"I3RC_LIB": nested}, 812)):
+        p = subprocess.run([sys.executable, "-c", prog, str(seed0)], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        res[which] = json.loads(p.stdout.strip().splitlines()[-1])
+    for (kq, q), (kn, nst) in zip(res["queue"], res["nested"]):
+        assert "true, false" in kq and "true, true" in kn, (kq, kn)      # specialised (queue) against general (nested order)
+        q, nst = np.array(q), np.array(nst)
+        se = np.sqrt(q.var(0, ddof=1) / len(q) + nst.var(0, ddof=1) / len(nst))
+        z = (q.mean(0) - nst.mean(0)) / np.maximum(se, 1e-12)
+        assert np.all(np.abs(z) < 4.0), (kq, z.tolist(), q.mean(0).tolist(), nst.mean(0).tolist())
+        assert np.all(q.mean(0)[2:] > 0.01)                                  # (radiances there at all)
+
+
 # ---- limits the reference does not have -----------------------------------------------------------------------------------
 def test_twelve_components(oracle):
     """Code/opticalProperties.f95:133-230 takes any number of components: twelve here (the handle's tables are sized by the
