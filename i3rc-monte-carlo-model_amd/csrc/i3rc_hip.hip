@@ -667,6 +667,18 @@ int i3rc_hip_column_records(int nx, int ny, int nz, const float *totalExt, uint3
   return 1;
 }
 
+int i3rc_hip_lds_plan(const int32_t *q, int32_t *out) {
+  if (!q || !out) return 1;
+  DevProblem P;
+  std::memset(&P, 0, sizeof(P));
+  P.nx = q[0]; P.ny = q[1]; P.nz = q[2]; P.ncomp = q[3]; P.nDir = q[4]; P.ldsTallies = q[5]; P.ldsIntensity = q[6];
+  P.rayQueueCap = q[7]; P.clearNx = q[8]; P.clearShift = q[9];
+  const LdsPlan lp = lds_plan(P, q[10] != 0, q[11] != 0, q[12], q[13] != 0, q[14], q[15]);
+  const int v[11] = {lp.xE, lp.yE, lp.zE, lp.tallies, lp.dirCos, lp.dirTab, lp.queue, lp.tInt, lp.ext, lp.cosTab, lp.end};
+  for (int k = 0; k < 11; ++k) out[k] = v[k];
+  return 0;
+}
+
 int i3rc_hip_set_batch_fusion(i3rc_hip_integrator *h, int mode) {
   if (!h) return 1;
   drop_lookahead(h);
@@ -799,6 +811,7 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false) {
   P.rayQueueCap = h->nDir > 0 && !direct_rays(h) ? 64 : 0;   // (an event phase pushes at most 64 records; the rays go on to the ready buffer)
   if (h->nDir > 0) lds += sizeof(float) * 4 * (kRecWords * (size_t)P.rayQueueCap + kReadyWords * (size_t)(direct_rays(h) ? kDirectReady : kReadyRays));
   if (h->nDir > 0) lds += sizeof(float) * (16 * (size_t)h->nDir + 3);   // per direction: what a ray derives from it (Lds::dirTab, 16-byte aligned)
+  // (`lds` steers the decisions below and is an upper bound; what a launch allocates is lds_plan's own end: lds_bytes)
   if (h->nDir > 0)
     for (int c = 0; c < h->ncomp; ++c)
       if (h->maxPfIndex[c] >= 65536) return h->fail("radiance runs take at most 65535 phase-function table entries per component");
@@ -819,6 +832,15 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false) {
   plan.intensity = h->nDir > 0;
   plan.place = P.ldsGrid ? GRID_LDS : (P.colRec ? GRID_COLUMNS : (P.extBrick ? GRID_BRICKS : GRID_GLOBAL));
   return 0;
+}
+
+// Dynamic LDS of one launch: the end of the kernel's own carve-up (lds_plan, tracer.hpp -- the function photon_kernel sets its
+// pointers from), for the instantiation that is about to run.
+template <class Rng>
+size_t lds_bytes(const i3rc_hip_integrator *h, const LaunchPlan &plan, bool tableInLds) {
+  const LdsPlan lp = lds_plan(plan.P, plan.intensity && !Rng::kReplay, direct_rays(h), plan.place, plan.intensity, tableInLds ? 16 : 4,
+                              tableInLds ? plan.P.comp0.nInv : 0);
+  return (sizeof(float) * (size_t)lp.end + 15) & ~(size_t)15;
 }
 
 int upload_source(i3rc_hip_integrator *h, const i3rc_source *src, int64_t n, RunArgs &A) {
@@ -884,7 +906,7 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
   // Step cloud 29.75 -> 29.29 ms per 1e8 photons (+1.6 %), radar 640 +2 %, Landsat-36 87.0 -> 71.0 ms (+22 %).
   // I3RC_TABLE_LDS=0 switches it off.
   int threads = 256;
-  size_t ldsBytes = plan.ldsBytes;
+  size_t ldsBytes = lds_bytes<Rng>(h, plan, false);
   if constexpr (!Rng::kReplay) {
     static const bool tblOn = !(std::getenv("I3RC_TABLE_LDS") && std::atoi(std::getenv("I3RC_TABLE_LDS")) == 0);
     // (grid places as a bit mask: LDS and global memory.  Bricked fields: Landsat-119 -2.5 %, the scene tiled 2 x 2 +10 %: left out)
@@ -895,9 +917,10 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
                                     photon_kernel<Rng, false, false, GRID_BRICKS, true>, photon_kernel<Rng, false, false, GRID_COLUMNS, true>};
       kern = tbl[place];
       threads = 1024;
-      ldsBytes = (plan.ldsBytes + sizeof(float) * (size_t)plan.P.comp0.nInv + 15) & ~(size_t)15;
+      ldsBytes = lds_bytes<Rng>(h, plan, true);
     }
   }
+  if (ldsBytes > 160 * 1024 - 256) return h->fail("the launch needs more LDS than a compute unit has");
   const void *fn = (const void *)kern;
   {
     static const char *const placeName[4] = {"GRID_LDS", "GRID_GLOBAL", "GRID_BRICKS", "GRID_COLUMNS"};
@@ -1214,7 +1237,7 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
   // waves per SIMD -- two workgroups per compute unit -- and pay for it with two vector registers in scratch)
   Kernel kern = kernels[place];
   int threads = 256;
-  size_t ldsBytes = plan.ldsBytes;
+  size_t ldsBytes = lds_bytes<PhiloxBatchStream>(h, plan, false);
   if (plan.intensity) {   // radiance problems: through the event ring, or (one direction) without it -- as in launch()
     static const Kernel ring[4] = {photon_kernel<PhiloxBatchStream, true, false, GRID_LDS>, photon_kernel<PhiloxBatchStream, true, false, GRID_GLOBAL>,
                                    photon_kernel<PhiloxBatchStream, true, false, GRID_BRICKS>, photon_kernel<PhiloxBatchStream, true, false, GRID_COLUMNS>};
@@ -1230,9 +1253,10 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
                                     nullptr, photon_kernel<PhiloxBatchStream, false, false, GRID_COLUMNS, true>};
       kern = tbl[place];
       threads = 1024;
-      ldsBytes = (plan.ldsBytes + sizeof(float) * (size_t)plan.P.comp0.nInv + 15) & ~(size_t)15;
+      ldsBytes = lds_bytes<PhiloxBatchStream>(h, plan, true);
     }
   }
+  if (ldsBytes > 160 * 1024 - 256) return h->fail("the launch needs more LDS than a compute unit has");
   const void *fn = (const void *)kern;
   {
     static const char *const placeName[4] = {"GRID_LDS", "GRID_GLOBAL", "GRID_BRICKS", "GRID_COLUMNS"};

@@ -366,25 +366,14 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   {
-    lds_float *p = (lds_float *)smem;
-    L.xE = p; p += P.nx + 1;
-    L.yE = p; p += P.ny + 1;
-    L.zE = p; p += P.nz + 1;
+    // (one carve-up for the kernel and for the host's allocation: lds_plan, tracer.hpp)
+    const LdsPlan lp = lds_plan(P, INTENSITY && !Rng::kReplay, DIRECT, GRID, INTENSITY, TBL ? 16 : 4, 0);
+    lds_float *const base = (lds_float *)smem;
     const int ncol = P.nx * P.ny;
-    L.tUp = p; L.tDown = p + ncol; L.tAbs = p + 2 * ncol;
-    if (P.ldsTallies) p += 3 * ncol;
-    L.dirCos = p; p += 3 * P.nDir;
-    p += (4 - (int)((p - (lds_float *)smem) & 3)) & 3;   // (16-byte alignment for the 128-bit reads of dirTab)
-    L.dirTab = p;
-    if (INTENSITY && !Rng::kReplay) p += 16 * P.nDir;
-    L.queue = p;
-    if (INTENSITY && !Rng::kReplay) p += 4 * (kRecWords * P.rayQueueCap + kReadyWords * (DIRECT ? kDirectReady : kReadyRays));
-    L.tInt = p;
-    if (P.ldsIntensity) p += (P.ncomp + 1) * P.nDir * ncol;
-    L.ext = p;
-    if (GRID == GRID_LDS) p += P.nx * P.ny * P.nz;
-    if (GRID == GRID_BRICKS && !INTENSITY) p += P.clearNx * (((P.ny - 1) >> P.clearShift) + 1);   // (the clear-air map lives at L.ext)
-    L.cosTab = p;
+    L.xE = base + lp.xE; L.yE = base + lp.yE; L.zE = base + lp.zE;
+    L.tUp = base + lp.tallies; L.tDown = L.tUp + ncol; L.tAbs = L.tUp + 2 * ncol;
+    L.dirCos = base + lp.dirCos; L.dirTab = base + lp.dirTab; L.queue = base + lp.queue;
+    L.tInt = base + lp.tInt; L.ext = base + lp.ext; L.cosTab = base + lp.cosTab;
   }
   for (int i = threadIdx.x; i < 3 * P.nDir; i += blockDim.x) L.dirCos[i] = P.dirCos[i];
   // coalesced staging of the edge vectors (and the extinction grid when it fits)

@@ -139,6 +139,40 @@ constexpr int kReadyRays = 64;
 constexpr int kDirectReady = I3RC_DIRECT_READY;   // ... of the one-direction radiance kernels, which have no event ring (photon_kernel, DIRECT): a power of two >= 128
 constexpr int kCounterReplicas = 64;   // fused multi-batch launches: copies of a batch's counter block (RunArgs::counterBlocks)
 
+// The carve-up of a workgroup's dynamic LDS, in WORDS from its start -- ONE function for both sides: photon_kernel sets its
+// pointers (Lds) from it, the host sizes the launch's allocation from it (i3rc_hip.hip, lds_bytes).  (Round 4 kept two copies of
+// this arithmetic and the advisor found them three floats apart: a 5 x 5 x 5 grid in LDS ended one word past its allocation.)
+//   queues        radiance kernels with ray queues (INTENSITY && !Rng::kReplay): dirTab (16-byte aligned) and the waves' rings / ready stores
+//   direct        ... of the one-direction form (photon_kernel, DIRECT)
+//   grid          GridPlace of the instantiation;  intensity: its INTENSITY (a bricked field's clear-air map: flux kernels only)
+//   waves         waves per workgroup;  tableWords: the inverse table's cosines behind everything else (TBL), else 0
+struct LdsPlan { int xE, yE, zE, tallies, dirCos, dirTab, queue, tInt, ext, cosTab, end; };
+template <class PR>
+__host__ __device__ inline LdsPlan lds_plan(const PR &P, bool queues, bool direct, int grid, bool intensity, int waves, int tableWords) {
+  LdsPlan o;
+  int p = 0;
+  o.xE = p; p += P.nx + 1;
+  o.yE = p; p += P.ny + 1;
+  o.zE = p; p += P.nz + 1;
+  const int ncol = P.nx * P.ny;
+  o.tallies = p;                               // fluxUp | fluxDown | fluxAbsorbed, ncol words each (valid when ldsTallies)
+  if (P.ldsTallies) p += 3 * ncol;
+  o.dirCos = p; p += 3 * P.nDir;
+  if (queues) p = (p + 3) & ~3;                // (the 128-bit reads of dirTab)
+  o.dirTab = p;
+  if (queues) p += 16 * P.nDir;
+  o.queue = p;
+  if (queues) p += waves * (kRecWords * P.rayQueueCap + kReadyWords * (direct ? kDirectReady : kReadyRays));
+  o.tInt = p;
+  if (P.ldsIntensity) p += (P.ncomp + 1) * P.nDir * ncol;
+  o.ext = p;
+  if (grid == 0 /* GRID_LDS */) p += ncol * P.nz;
+  if (grid == 2 /* GRID_BRICKS */ && !intensity) p += P.clearNx * (((P.ny - 1) >> P.clearShift) + 1);   // (the clear-air map lives at Lds::ext)
+  o.cosTab = p; p += tableWords;
+  o.end = p;
+  return o;
+}
+
 // Fortran SPACING() for real(4)
 __device__ __forceinline__ float spacingf(float x) {
   const uint32_t e = __float_as_uint(x) & 0x7f800000u;

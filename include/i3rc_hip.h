@@ -332,6 +332,15 @@ int i3rc_hip_has_column_records(const i3rc_hip_integrator *h);
  * when records is not NULL, writes [ny * nx][2] words: the value's bits; first layer (1-based) | (run length - 1) << 16. */
 int i3rc_hip_column_records(int nx, int ny, int nz, const float *totalExt, uint32_t *records);
 
+/* Test hook, host code only (no device needed): the carve-up of a workgroup's dynamic LDS that photon_kernel makes -- the very
+ * function the kernel sets its pointers from and the launch sizes its allocation from (csrc/tracer.hpp, lds_plan).
+ *   q[0..15]  = nx, ny, nz, ncomp, nDir, ldsTallies, ldsIntensity, rayQueueCap, clearNx, clearShift,
+ *               queues (radiance kernel with ray queues), direct (its one-direction form), grid place (0 LDS, 1 global, 2 bricks,
+ *               3 column records), intensity (radiance kernel), waves per workgroup, words of the inverse table kept in LDS
+ *   out[0..10] = word offsets of: x edges, y edges, z edges, flux tallies, directions, per-direction ray constants, ray queues,
+ *               radiance tallies, extinction grid / clear-air map, inverse table; and the end (= words a launch allocates). */
+int i3rc_hip_lds_plan(const int32_t *q, int32_t *out);
+
 /* Test hook: the raw Philox4x32-10 blocks (out[n][blocksPerPhoton][4]) of photons firstPhoton..+n-1 and the
  * float32 deviates the photon streams derive from them (outf, same shape). */
 int i3rc_hip_philox_blocks(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int64_t firstPhoton, int64_t n,
