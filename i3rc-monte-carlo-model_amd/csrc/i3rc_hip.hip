@@ -1871,6 +1871,43 @@ int i3rc_hip_arith_check(i3rc_hip_integrator *h, int64_t n, const float *num, co
   return 0;
 }
 
+/* Test hook: findIndex (Code/numericUtilities.f95:195-248) on the device, as the kernels evaluate it. */
+int i3rc_hip_find_index(i3rc_hip_integrator *h, int n, const float *table, int64_t m, const float *values, const int32_t *firstGuess,
+                        int32_t *out) {
+  if (!h) return 1;
+  if (n < 1 || m < 1 || !table || !values || !out) return h->fail("i3rc_hip_find_index: bad arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  DevBuf dt, dv, dg, dout;
+  HIPCHK(h, dt.upload(table, sizeof(float) * (size_t)n)); HIPCHK(h, dv.upload(values, sizeof(float) * (size_t)m));
+  if (firstGuess) HIPCHK(h, dg.upload(firstGuess, sizeof(int32_t) * (size_t)m));
+  HIPCHK(h, dout.alloc(sizeof(int32_t) * (size_t)m));
+  hipLaunchKernelGGL(find_index_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, n, (const float *)dt.p, (long long)m,
+                     (const float *)dv.p, firstGuess ? (const int32_t *)dg.p : nullptr, (int32_t *)dout.p);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(out, dout.p, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+/* Test hook: computeSurfaceReflectance (Code/surfaceProperties.f95:121-162) on the device for the surface of i3rc_hip_set_surface. */
+int i3rc_hip_surface_reflectance(i3rc_hip_integrator *h, int64_t m, const float *x, const float *y, float *out) {
+  if (!h) return 1;
+  if (m < 1 || !x || !y || !out) return h->fail("i3rc_hip_surface_reflectance: bad arguments");
+  if (!h->dBrdf.p) return h->fail("i3rc_hip_surface_reflectance: no surface description set");
+  HIPCHK(h, hipSetDevice(h->device));
+  DevBuf dx, dy, dout;
+  HIPCHK(h, dx.upload(x, sizeof(float) * (size_t)m)); HIPCHK(h, dy.upload(y, sizeof(float) * (size_t)m));
+  HIPCHK(h, dout.alloc(sizeof(float) * (size_t)m));
+  SurfaceOnly S;
+  S.xsE = (const float *)h->dXs.p; S.ysE = (const float *)h->dYs.p; S.brdf = (const float *)h->dBrdf.p; S.nxs = h->nxs; S.nys = h->nys;
+  hipLaunchKernelGGL(surface_reflectance_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, S, (long long)m,
+                     (const float *)dx.p, (const float *)dy.p, (float *)dout.p);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(out, dout.p, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int i3rc_hip_synchronize(i3rc_hip_integrator *h) {
   if (!h) return 1;
   HIPCHK(h, hipSetDevice(h->device));

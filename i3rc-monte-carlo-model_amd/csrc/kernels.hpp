@@ -1420,6 +1420,20 @@ __global__ void arith_check_kernel(long long n, const float *num, const float *d
   if (__float_as_uint(exact_sqrt(x)) != __float_as_uint(sqrtf(x))) atomicAdd(&mismatch[1], 1ull);
 }
 
+// Test hooks: findIndex and computeSurfaceReflectance as the photon kernels evaluate them (tracer.hpp find_index, surface_reflectance),
+// one thread per value -- held against the reference's own routines (tests/golden/ref_numerics.npz) by tests/test_gpu_ref_numerics.py.
+__global__ void find_index_kernel(int n, const float *table, long long m, const float *values, const int32_t *firstGuess, int32_t *out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  out[i] = find_index(values[i], [table](int k) { return table[k - 1]; }, n, firstGuess ? firstGuess[i] : 0);
+}
+struct SurfaceOnly { const float *xsE, *ysE, *brdf; int nxs, nys; };   // (what surface_reflectance reads of a DevProblem)
+__global__ void surface_reflectance_kernel(const SurfaceOnly S, long long m, const float *x, const float *y, float *out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  out[i] = surface_reflectance(S, x[i], y[i]);
+}
+
 // Test hook: raw Philox blocks as the photon streams see them.
 __global__ void philox_kernel(uint32_t seed0, uint32_t seed1, long long firstPhoton, long long n, int blocksPerPhoton,
                               uint32_t *out, float *outf) {

@@ -111,35 +111,49 @@ contains
     deallocate(root, previous, d1, d2, moving, P)
   end subroutine computeLobattoTerms
 
-  ! n-point Gauss-Legendre abscissas and weights on (-1, 1): zeros of P_n by Newton iteration.
+  ! n-point Gauss-Legendre abscissas and weights on (-1, 1): zeros of P_n by Newton iteration, the same scheme as the
+  ! Lobatto nodes above (a node stops moving once a step is within 2 spacing() of it; the weight uses the derivative
+  ! of the node's last step).  Held bit for bit against the reference's own routine: tests/test_ref_numerics.py.
   pure subroutine computeGaussLegendreTerms(mus, weights)
     real, dimension(:), intent(out) :: mus, weights
+    integer, parameter :: newtonLimit = 25
+    real,    parameter :: tolerance = 2.
     integer :: n, half, k, sweep
     real    :: pi
     real, dimension(:),    allocatable :: root, previous, deriv
     real, dimension(:, :), allocatable :: P
+    logical, dimension(:), allocatable :: moving
 
     n = min(size(mus), size(weights))
     pi = acos(-1.)
     half = (n + 1) / 2
-    allocate(root(half), previous(half), deriv(half), P(0:n, half))
-    root(:) = cos(pi * ((/ (real(k), k = 1, half) /) - 0.25) / (n + 0.5))
-    do sweep = 1, 25
+    allocate(root(half), previous(half), deriv(half), moving(half), P(0:n, half))
+    root(:) = cos(pi * ((/ (real(k), k = 1, half) /) - .25) / (n + .5))
+    moving(:) = .true.
+    sweep = 0
+    do
       P(:, :) = computeLegendrePolynomials(n, root)
-      deriv = n * (root * P(n, :) - P(n - 1, :)) / (root**2 - 1.)
-      previous = root
-      root = root - P(n, :) / deriv
-      if(all(abs(root - previous) <= 3. * spacing(root))) exit
+      where(moving)
+        deriv = n * (root * P(n, :) - P(n - 1, :)) / (root**2 - 1.)
+        previous = root
+        root = root - P(n, :) / deriv
+      end where
+      moving(:) = abs(root - previous) > tolerance * spacing(root)
+      if(.not. any(moving)) exit
+      sweep = sweep + 1
+      if(sweep > newtonLimit + 1) exit
     end do
-    P(:, :) = computeLegendrePolynomials(n, root)
-    deriv = n * (root * P(n, :) - P(n - 1, :)) / (root**2 - 1.)
+
     mus(:) = 0.; weights(:) = 0.
     do k = 1, half
-      mus(n + 1 - k)     = root(k)
-      weights(n + 1 - k) = 2. / ((1. - root(k)**2) * deriv(k)**2)
-      mus(k)             = -root(k)
-      weights(k)         = weights(n + 1 - k)
+      mus(k)     = -root(k)
+      weights(k) = 2. / ((1. - root(k)**2) * deriv(k)**2)
     end do
-    deallocate(root, previous, deriv, P)
+    do k = 1, n / 2            ! mirror the negative half onto the positive one
+      mus(n + 1 - k)     = -mus(k)
+      weights(n + 1 - k) = weights(k)
+    end do
+    if(mod(n, 2) == 1) mus(half) = -mus(half)   ! (the middle node mirrors onto itself: its sign flips, as the reference's does)
+    deallocate(root, previous, deriv, moving, P)
   end subroutine computeGaussLegendreTerms
 end module numericUtilities

@@ -556,6 +556,22 @@ class Integrator:
         self._check(self._lib.i3rc_hip_arith_check(self._h, len(num), pf(num), pf(den), C.byref(a), C.byref(b)), "arith_check")
         return a.value, b.value
 
+    def find_index(self, values, table, firstGuess=None):
+        """Test hook: findIndex on the device, as the kernels evaluate it (i3rc_hip_find_index)."""
+        values, table = f32(values), f32(table)
+        g = None if firstGuess is None else np.ascontiguousarray(firstGuess, np.int32)
+        out = np.zeros(len(values), np.int32)
+        self._check(self._lib.i3rc_hip_find_index(self._h, len(table), pf(table), len(values), pf(values),
+                                                  None if g is None else g.ctypes.data_as(B.ip), out.ctypes.data_as(B.ip)), "find_index")
+        return out
+
+    def surface_reflectance(self, x, y):
+        """Test hook: computeSurfaceReflectance on the device for the surface of specifyParameters(surfaceBDRF=) (i3rc_hip_surface_reflectance)."""
+        x, y = f32(x), f32(y)
+        out = np.zeros(len(x), np.float32)
+        self._check(self._lib.i3rc_hip_surface_reflectance(self._h, len(x), pf(x), pf(y), pf(out)), "surface_reflectance")
+        return out
+
     def philox_blocks(self, seed, firstPhoton, n, blocks):
         out = np.zeros((n, blocks, 4), np.uint32)
         outf = np.zeros((n, blocks, 4), np.float32)

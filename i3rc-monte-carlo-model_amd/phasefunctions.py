@@ -8,11 +8,20 @@ Mirrors, for the hot path only,
 Arithmetic is float32 in the reference's operator order; numpy's float32 sin/cos/acos may differ from the
 Fortran run-time's by an ulp, so tables agree with the reference to ~1e-6, not bitwise (tests state this).
 """
+import ctypes
+import ctypes.util
+
 import numpy as np
 
 f32 = np.float32
 PI_SPF = f32(3.141592654)          # scatteringPhaseFunctions.f95:26
 PI_MCRT = f32(3.14159265358979312)  # monteCarloRadiativeTransfer.f95:43
+
+
+_libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+_libm.sinf.restype = ctypes.c_float
+_libm.sinf.argtypes = [ctypes.c_float]
+_sinf = _libm.sinf
 
 
 def spacing(x):
@@ -70,7 +79,11 @@ def lobatto(n):
     m = mid - 1
     c1 = f32(1.0) if n % 2 == 1 else f32(0.5)
     i = np.arange(1, m + 1, dtype=np.float32)
-    trial = np.sin(pi * (i - c1) / (f32(n) - f32(1.0) + f32(0.5))).astype(np.float32)
+    # (libm's sinf, the routine the reference's `sin` ends in: numpy's float32 sine is a SIMD routine of its own and the correctly
+    # rounded sine is a third answer -- glibc's sinf is faithful, not correctly rounded -- and a first guess one ulp away let the
+    # 128-point rule settle on two other float32 roots; tests/test_ref_numerics.py holds this function against the reference's own)
+    arg = (pi * (i - c1) / (f32(n) - f32(1.0) + f32(0.5))).astype(np.float32)
+    trial = np.array([_sinf(float(a)) for a in arg], np.float32)
     last = trial.copy()
 
     def update(mask):

@@ -351,6 +351,14 @@ int i3rc_hip_philox_blocks(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed
 int i3rc_hip_arith_check(i3rc_hip_integrator *h, int64_t n, const float *num, const float *den, int64_t *divMismatch,
                          int64_t *sqrtMismatch);
 
+/* Test hooks: findIndex (Code/numericUtilities.f95:195-248) and computeSurfaceReflectance (Code/surfaceProperties.f95:121-162) as the
+ * photon kernels evaluate them (csrc/tracer.hpp find_index, surface_reflectance), one thread per value: out[i] = findIndex(values[i],
+ * table(1:n), firstGuess[i]) (firstGuess NULL, or an entry <= 0: the argument is absent); out[i] = the reflectance at (x[i], y[i]) of
+ * the surface set by i3rc_hip_set_surface.  tests/test_gpu_ref_numerics.py holds both against the reference's own routines. */
+int i3rc_hip_find_index(i3rc_hip_integrator *h, int n, const float *table, int64_t m, const float *values, const int32_t *firstGuess,
+                        int32_t *out);
+int i3rc_hip_surface_reflectance(i3rc_hip_integrator *h, int64_t m, const float *x, const float *y, float *out);
+
 /* Library / device probe that needs no GPU work: returns the number of HIP devices (or -1). */
 int i3rc_hip_device_count(void);
 const char *i3rc_hip_version(void);

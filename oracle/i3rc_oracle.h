@@ -48,6 +48,8 @@ float   orc_mt_real(orc_mt *t);                                      /* :292-299
 float orc_spacing(float x);                                          /* Fortran SPACING() for real(4) */
 int   orc_find_index(float value, const float *table, int n, int firstGuess); /* :195-248, 1-based; firstGuess<=0: absent */
 void  orc_lobatto(int n, float *mus, float *weights);                /* :15-102 */
+void  orc_gauss_legendre(int n, float *mus, float *weights);         /* :104-173 */
+void  orc_legendre_polynomials(int maxL, const float *mus, int m, float *P);   /* :175-193, P[j * (maxL + 1) + l] */
 
 /* ---- Code/scatteringPhaseFunctions.f95, Code/inversePhaseFunctions.f95 ----------------------------- */
 /* Legendre phase function: coefficients l=1..nCoef (P0=1 implicit), values at angles (radians). :486-496 */
@@ -122,6 +124,9 @@ int64_t orc_compute_rt(const orc_problem *p, orc_mt *rng, int64_t n,
 
 /* The normalisation of computeRadiativeTransfer :327-395 applied in place to raw tallies. */
 void orc_normalise(const orc_problem *p, int64_t numPhotonsProcessed, orc_tallies *t);
+/* computeSurfaceReflectance, Code/surfaceProperties.f95:121-162, for m points (brdf [nys][nxs], x fastest) */
+void orc_surface_reflectance(int nxs, int nys, const float *xsEdges, const float *ysEdges, const float *brdf, int m,
+                             const float *x, const float *y, float *out);
 
 /* Single tracer call, exported for bit-exact kernel tests. :1654-1807.  hasTarget=0 -> trace to boundary. */
 float orc_trace(const orc_problem *p, const float dir[3], float pos[3], int idx[3], int hasTarget, float target,

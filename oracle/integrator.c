@@ -207,6 +207,16 @@ static float surface_reflectance(const orc_problem *p, float xPos, float yPos) {
   return p->brdf[(size_t)(iy - 1) * p->nxs + (ix - 1)];
 }
 
+/* ... for m points of a surface given by its arrays: what the loop's own look-up (above) answers, callable from the tests
+ * (tests/test_ref_numerics.py holds it against the reference's computeSurfaceReflectance, oracle/_ref) */
+void orc_surface_reflectance(int nxs, int nys, const float *xsEdges, const float *ysEdges, const float *brdf, int m,
+                             const float *x, const float *y, float *out) {
+  orc_problem p;
+  memset(&p, 0, sizeof(p));
+  p.nxs = nxs; p.nys = nys; p.xsEdges = xsEdges; p.ysEdges = ysEdges; p.brdf = brdf;
+  for (int i = 0; i < m; i++) out[i] = surface_reflectance(&p, x[i], y[i]);
+}
+
 /* computeIntensityContribution :1419-1611 */
 static void intensity_contribution(const ctx_t *c, orc_tallies *t, float weight, const float posI[3], const int idxI[3],
                                    const float dirCos[3], int component, orc_mt *rng, int order,

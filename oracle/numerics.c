@@ -203,6 +203,61 @@ void orc_lobatto(int n, float *mus, float *weights) {
   free(trial); free(last); free(P);
 }
 
+/* computeGaussLegendreTerms :104-173 (no caller in the reference; restated because the module exports it and
+ * oracle/_ref pins it) */
+void orc_gauss_legendre(int n, float *mus, float *weights) {
+  const float relAcc = 2.0f;
+  const int maxIter = 25;
+  float pi = acosf(-1.0f);
+  int mid = (n + 1) / 2;
+  float *trial = calloc(mid, sizeof(float)), *last = calloc(mid, sizeof(float)), *deriv = calloc(mid, sizeof(float));
+  float *P = calloc((size_t)mid * (n + 1), sizeof(float)); /* P[j*(n+1) + l], l = 0..n */
+  for (int j = 0; j < mid; j++) trial[j] = cosf(pi * ((float)(j + 1) - 0.25f) / ((float)n + 0.5f));
+
+#define NEWTON_UPDATE(j)                                                                   \
+  do {                                                                                     \
+    float mu = trial[j];                                                                   \
+    const float *Pj = P + (size_t)(j) * (n + 1);                                           \
+    deriv[j] = ((float)n * (mu * Pj[n] - Pj[n - 1])) / (mu * mu - 1.0f);                   \
+    last[j] = mu;                                                                          \
+    trial[j] = mu - Pj[n] / deriv[j];                                                      \
+  } while (0)
+
+  for (int j = 0; j < mid; j++) legendre_p(n, trial[j], P + (size_t)j * (n + 1));
+  for (int j = 0; j < mid; j++) NEWTON_UPDATE(j);
+  int it = 0;
+  for (;;) {
+    int done = 1;
+    for (int j = 0; j < mid; j++)
+      if (!(fabsf(trial[j] - last[j]) <= relAcc * orc_spacing(trial[j]))) done = 0;
+    if (done) break;
+    for (int j = 0; j < mid; j++) legendre_p(n, trial[j], P + (size_t)j * (n + 1));
+    for (int j = 0; j < mid; j++)
+      if (fabsf(trial[j] - last[j]) > relAcc * orc_spacing(trial[j])) NEWTON_UPDATE(j);
+    it++;
+    if (it > maxIter) break;
+  }
+#undef NEWTON_UPDATE
+  for (int j = 0; j < mid; j++) {   /* mus(:mid) = -trial; weights(:mid) = 2 / ((1 - trial**2) * deriv**2) */
+    mus[j] = -trial[j];
+    weights[j] = 2.0f / ((1.0f - trial[j] * trial[j]) * (deriv[j] * deriv[j]));
+  }
+  if (n % 2 == 0) {
+    for (int k = 0; k < mid; k++) { mus[mid + k] = -mus[mid - 1 - k]; weights[mid + k] = weights[mid - 1 - k]; }
+  } else {   /* mus(mid:n) = -mus(mid:1:-1): the right-hand side is evaluated before the assignment */
+    float *tm = malloc(sizeof(float) * mid), *tw = malloc(sizeof(float) * mid);
+    for (int k = 0; k < mid; k++) { tm[k] = -mus[mid - 1 - k]; tw[k] = weights[mid - 1 - k]; }
+    for (int k = 0; k < mid; k++) { mus[mid - 1 + k] = tm[k]; weights[mid - 1 + k] = tw[k]; }
+    free(tm); free(tw);
+  }
+  free(trial); free(last); free(deriv); free(P);
+}
+
+/* computeLegendrePolynomials :175-193 for m values of mu: P[j * (maxL + 1) + l] */
+void orc_legendre_polynomials(int maxL, const float *mus, int m, float *P) {
+  for (int j = 0; j < m; j++) legendre_p(maxL, mus[j], P + (size_t)j * (maxL + 1));
+}
+
 /* ===================================================================================================
  * Code/scatteringPhaseFunctions.f95 : getPhaseFunctionValues
  * =================================================================================================== */

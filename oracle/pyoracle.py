@@ -199,6 +199,34 @@ def lobatto(n):
     return mus, w
 
 
+def gauss_legendre(n):
+    mus = np.zeros(n, np.float32)
+    w = np.zeros(n, np.float32)
+    lib().orc_gauss_legendre(n, _pf(mus), _pf(w))
+    return mus, w
+
+
+def legendre_polynomials(max_l, mus):
+    """P[mu][l], l = 0 .. max_l (computeLegendrePolynomials, Code/numericUtilities.f95:175-193)"""
+    mus = _f(mus)
+    P = np.zeros((len(mus), max_l + 1), np.float32)
+    lib().orc_legendre_polynomials(max_l, _pf(mus), len(mus), _pf(P))
+    return P
+
+
+def find_index(value, table, first_guess=0):
+    table = _f(table)
+    return int(lib().orc_find_index(C.c_float(value), _pf(table), len(table), int(first_guess)))
+
+
+def surface_reflectance(xs_edges, ys_edges, brdf, x, y):
+    """computeSurfaceReflectance (Code/surfaceProperties.f95:121-162) at the points (x, y); brdf [nys][nxs]"""
+    xs, ys, b, x, y = _f(xs_edges), _f(ys_edges), _f(brdf), _f(x), _f(y)
+    out = np.zeros(len(x), np.float32)
+    lib().orc_surface_reflectance(len(xs) - 1, len(ys) - 1, _pf(xs), _pf(ys), _pf(b), len(x), _pf(x), _pf(y), _pf(out))
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------
 # Integrator
 # ---------------------------------------------------------------------------------------------------------

@@ -18,7 +18,8 @@ def bits(a):
 def _near(values):
     """every value, its two float32 neighbours"""
     v = np.asarray(values, dtype=F)
-    return np.concatenate([v, np.nextafter(v, F(np.inf)), np.nextafter(v, F(-np.inf))]).astype(F)
+    with np.errstate(over="ignore"):   # (the neighbour above huge is infinity: wanted)
+        return np.concatenate([v, np.nextafter(v, F(np.inf)), np.nextafter(v, F(-np.inf))]).astype(F)
 
 
 def cases():
