@@ -82,6 +82,7 @@ struct i3rc_hip_integrator {
   DevBuf dComp;
   DevBuf dXs, dYs, dBrdf;
   int nxs = 0, nys = 0;
+  bool ldsTalliesOn = true;   // i3rc_hip_set_lds_tallies
   float brdf0 = 0.f;          // reflectance of the first surface cell (a 1 x 1 surface grid is a plain Lambertian albedo)
   DevBuf dDir;
   int nDir = 0;
@@ -667,6 +668,13 @@ int i3rc_hip_column_records(int nx, int ny, int nz, const float *totalExt, uint3
   return 1;
 }
 
+int i3rc_hip_set_lds_tallies(i3rc_hip_integrator *h, int on) {
+  if (!h) return 1;
+  drop_lookahead(h);
+  h->ldsTalliesOn = on != 0;
+  return 0;
+}
+
 int i3rc_hip_lds_plan(const int32_t *q, int32_t *out) {
   if (!q || !out) return 1;
   DevProblem P;
@@ -819,11 +827,15 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false) {
   const size_t budget = kLdsBudget;
   P.ldsTallies = 0;
   // (a fused multi-batch launch tallies per batch, straight into global memory: no partial sums in LDS)
-  if (!fused && lds + 3 * ncol * sizeof(float) <= kLdsBudget / 2) { P.ldsTallies = 1; lds += 3 * ncol * sizeof(float); }
+  // (float64 partial sums: tracer.hpp, tally_t; + 4: their 8-byte alignment.  I3RC_LDS_TALLIES=0 / i3rc_hip_set_lds_tallies(h, 0): every
+  // tally straight to the float64 buffer in global memory -- a measurement knob, and one more order of the same float64 additions)
+  static const bool ldsTalliesEnv = !(std::getenv("I3RC_LDS_TALLIES") && std::atoi(std::getenv("I3RC_LDS_TALLIES")) == 0);
+  const bool privatise = !fused && ldsTalliesEnv && h->ldsTalliesOn;
+  if (privatise && lds + 3 * ncol * sizeof(tally_t) + 4 <= kLdsBudget / 2) { P.ldsTallies = 1; lds += 3 * ncol * sizeof(tally_t) + 4; }
   P.ldsIntensity = 0;
   {
-    const size_t nInt = (size_t)(h->ncomp + 1) * h->nDir * ncol * sizeof(float);
-    if (!fused && h->nDir > 0 && nInt <= 16 * 1024 && lds + nInt <= kLdsBudget) { P.ldsIntensity = 1; lds += nInt; }
+    const size_t nInt = (size_t)(h->ncomp + 1) * h->nDir * ncol * sizeof(tally_t) + 4;
+    if (privatise && h->nDir > 0 && nInt <= 16 * 1024 && lds + nInt <= kLdsBudget) { P.ldsIntensity = 1; lds += nInt; }
   }
   P.ldsGrid = 0;
   if (h->gridPlace == I3RC_GRID_AUTO && lds + ncell * sizeof(float) <= budget) { P.ldsGrid = 1; lds += ncell * sizeof(float); P.colRec = nullptr; P.extBrick = nullptr; }   // (never when the edges alone are beyond the budget)

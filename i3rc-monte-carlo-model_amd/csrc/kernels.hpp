@@ -22,7 +22,7 @@
 //   * cell edges (and, when they fit, the extinction grid) are staged in LDS with coalesced loads; a field whose columns
 //     each hold one run of one value (the I3RC Landsat scene) is read as one 8-byte record per column; other grids beyond an
 //     XCD's L2 are read from a copy in 32-cell bricks; flux and radiance tallies are privatised per workgroup in LDS
-//     (ds_add_f32) and flushed once with float64 atomics; large domains tally straight to HBM with float64 atomics;
+//     (ds_add_f64) and flushed once with float64 atomics; large domains tally straight to HBM with float64 atomics;
 //   * per-photon Philox4x32-10 streams keyed by (seed, batch) make a photon's path independent of the launch
 //     geometry, of every scheduling threshold and of the number of GPUs;
 //   * work counters live in scalar registers (advanced by s_bcnt1 of ballots in uniform control flow).
@@ -56,6 +56,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 __device__ __forceinline__ void add_global(double *p, float v) { unsafeAtomicAdd(p, (double)v); }
+__device__ __forceinline__ void add_global(double *p, double v) { unsafeAtomicAdd(p, v); }
 
 // Kernel arguments that are only needed now and then -- the reservoir refill, the counter hand-over, the epilogue --
 // are read from the kernarg segment where they are used (scalar loads) instead of living in scalar registers through
@@ -371,9 +372,9 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
     lds_float *const base = (lds_float *)smem;
     const int ncol = P.nx * P.ny;
     L.xE = base + lp.xE; L.yE = base + lp.yE; L.zE = base + lp.zE;
-    L.tUp = base + lp.tallies; L.tDown = L.tUp + ncol; L.tAbs = L.tUp + 2 * ncol;
+    L.tUp = (lds_tally *)(base + lp.tallies); L.tDown = L.tUp + ncol; L.tAbs = L.tUp + 2 * ncol;
     L.dirCos = base + lp.dirCos; L.dirTab = base + lp.dirTab; L.queue = base + lp.queue;
-    L.tInt = base + lp.tInt; L.ext = base + lp.ext; L.cosTab = base + lp.cosTab;
+    L.tInt = (lds_tally *)(base + lp.tInt); L.ext = base + lp.ext; L.cosTab = base + lp.cosTab;
   }
   for (int i = threadIdx.x; i < 3 * P.nDir; i += blockDim.x) L.dirCos[i] = P.dirCos[i];
   // coalesced staging of the edge vectors (and the extinction grid when it fits)
@@ -381,7 +382,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
   for (int i = threadIdx.x; i <= P.ny; i += blockDim.x) L.yE[i] = P.yE[i];
   for (int i = threadIdx.x; i <= P.nz; i += blockDim.x) L.zE[i] = P.zE[i];
   if (P.ldsTallies)
-    for (int i = threadIdx.x; i < 3 * P.nx * P.ny; i += blockDim.x) L.tUp[i] = 0.0f;
+    for (int i = threadIdx.x; i < 3 * P.nx * P.ny; i += blockDim.x) L.tUp[i] = (tally_t)0;
   if (GRID == GRID_LDS) {
     const int ncell = P.nx * P.ny * P.nz;
     for (int i = threadIdx.x; i < ncell; i += blockDim.x) L.ext[i] = P.totalExt[i];
@@ -391,7 +392,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
     for (int i = threadIdx.x; i < nWords; i += blockDim.x) L.ext[i] = __uint_as_float(P.clearMap[i]);
   }
   if (P.ldsIntensity)
-    for (int i = threadIdx.x; i < (P.ncomp + 1) * P.nDir * P.nx * P.ny; i += blockDim.x) L.tInt[i] = 0.0f;
+    for (int i = threadIdx.x; i < (P.ncomp + 1) * P.nDir * P.nx * P.ny; i += blockDim.x) L.tInt[i] = (tally_t)0;
   if (TBL) {
     const float *src = P.comp0.invCos + (size_t)(P.uniformPf >= 1 ? P.uniformPf - 1 : 0) * P.comp0.nInv;   // (else the table has one entry)
     for (int i = threadIdx.x; i < P.comp0.nInv; i += blockDim.x) L.cosTab[i] = src[i];
@@ -1345,18 +1346,18 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
       const int ncol = ka->P.nx * ka->P.ny;
       const int oUp = ka->P.oUp, oDown = ka->P.oDown, oAbs = ka->P.oAbs;
       for (int i = threadIdx.x; i < ncol; i += blockDim.x) {
-        const float u = L.tUp[i], d = L.tDown[i], a = L.tAbs[i];
-        if (u != 0.0f) add_global(out + oUp + i, u);
-        if (d != 0.0f) add_global(out + oDown + i, d);
-        if (a != 0.0f) add_global(out + oAbs + i, a);
+        const tally_t u = L.tUp[i], d = L.tDown[i], a = L.tAbs[i];
+        if (u != (tally_t)0) add_global(out + oUp + i, u);
+        if (d != (tally_t)0) add_global(out + oDown + i, d);
+        if (a != (tally_t)0) add_global(out + oAbs + i, a);
       }
     }
     if (ka->P.ldsIntensity) {
       const int nInt = (ka->P.ncomp + 1) * ka->P.nDir * ka->P.nx * ka->P.ny;
       const int oInt = ka->P.oInt;
       for (int i = threadIdx.x; i < nInt; i += blockDim.x) {
-        const float v = L.tInt[i];
-        if (v != 0.0f) add_global(out + oInt + i, v);
+        const tally_t v = L.tInt[i];
+        if (v != (tally_t)0) add_global(out + oInt + i, v);
       }
     }
     // nested local-estimate work and the deviate count are per lane; everything else is already per wave
@@ -1382,7 +1383,7 @@ __global__ void __launch_bounds__(256) trace_rays_kernel(const DevProblem P, lon
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   L.xE = (lds_float *)smem; L.yE = L.xE + P.nx + 1; L.zE = L.yE + P.ny + 1;
-  L.tUp = L.tDown = L.tAbs = L.dirCos = nullptr;
+  L.tUp = L.tDown = L.tAbs = nullptr; L.dirCos = nullptr;
   L.ext = L.zE + P.nz + 1;   // the clear-air map of the bricked field
   if (GRID == GRID_BRICKS && CLEARMAP)
     for (int i = threadIdx.x; i < P.clearNx * (((P.ny - 1) >> P.clearShift) + 1); i += blockDim.x) L.ext[i] = __uint_as_float(P.clearMap[i]);

@@ -117,17 +117,29 @@ struct RunArgs {
 // access is a ds_* instruction even where the same value may come from LDS or from global memory (a generic pointer
 // there ends in a flat_load of a selected address).
 typedef __attribute__((address_space(3))) float lds_float;
+// A workgroup's partial tally sums in LDS are FLOAT64 (round 5: ds_add_f64), as everything else a tally passes through: whichever
+// way a batch is launched -- plain, fused, ahead of the calls, sharded -- its tallies differ only by the ORDER of float64 additions
+// (1e-12 of a column's sum at most).  Until round 4 they were float32 and a plain launch differed from a fused one by up to 2e-5 of a
+// column's absorption (some 1e4 float32 additions per column and workgroup), which the tests had to allow for -- and which would
+// have hidden a small real difference.  -DI3RC_LDS_F32 is the old form (measurement knob, tools/README.md).
+#ifdef I3RC_LDS_F32
+typedef float tally_t;
+#else
+typedef double tally_t;
+#endif
+typedef __attribute__((address_space(3))) tally_t lds_tally;
+constexpr int kTallyWords = (int)(sizeof(tally_t) / sizeof(float));
 struct Lds {
   lds_float *xE, *yE, *zE;    // edges
-  lds_float *tUp, *tDown, *tAbs;  // privatised flux tallies (valid when ldsTallies)
+  lds_tally *tUp, *tDown, *tAbs;  // privatised flux tallies (valid when ldsTallies)
   lds_float *ext;             // totalExt copy (valid when ldsGrid); bricked fields: the clear-air map (DevProblem::clearMap) as words
   lds_float *dirCos;          // intensity directions
   lds_float *dirTab;          // ... and, per direction, what a ray of that direction derives from it (Ray::set_direction), 16 words: see photon_kernel
-  lds_float *tInt;            // privatised intensityByComponent (valid when ldsIntensity)
+  lds_tally *tInt;            // privatised intensityByComponent (valid when ldsIntensity)
   lds_float *cosTab;          // the inverse table's cosines (one entry) where a kernel keeps them in LDS (photon_kernel, TBL)
   lds_float *queue;           // [waves][kRecWords][rayQueueCap]: every wave's ring of local-estimate events (see kernels.hpp)
 };
-__device__ __forceinline__ void lds_add(lds_float *p, float v) { atomicAdd((float *)p, v); }
+__device__ __forceinline__ void lds_add(lds_tally *p, float v) { (void)__hip_atomic_fetch_add(p, (tally_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // ds_add_f64 (ds_add_f32 with I3RC_LDS_F32)
 // One record of a wave's ray queue: what the D local-estimate (shadow) rays of one scattering / reflection event need.
 constexpr int kRecWords = 14;   // x y z | ix iy iz | weight | incoming direction (3) | info | photon id (2) | Philox block
 // ... and one ready-made shadow ray of the wave's ready buffer (kReadyRays of them, one expand phase's worth)
@@ -155,16 +167,18 @@ __host__ __device__ inline LdsPlan lds_plan(const PR &P, bool queues, bool direc
   o.yE = p; p += P.ny + 1;
   o.zE = p; p += P.nz + 1;
   const int ncol = P.nx * P.ny;
-  o.tallies = p;                               // fluxUp | fluxDown | fluxAbsorbed, ncol words each (valid when ldsTallies)
-  if (P.ldsTallies) p += 3 * ncol;
+  if (P.ldsTallies) p = (p + kTallyWords - 1) & ~(kTallyWords - 1);
+  o.tallies = p;                               // fluxUp | fluxDown | fluxAbsorbed, ncol tally_t each (valid when ldsTallies)
+  if (P.ldsTallies) p += 3 * ncol * kTallyWords;
   o.dirCos = p; p += 3 * P.nDir;
   if (queues) p = (p + 3) & ~3;                // (the 128-bit reads of dirTab)
   o.dirTab = p;
   if (queues) p += 16 * P.nDir;
   o.queue = p;
   if (queues) p += waves * (kRecWords * P.rayQueueCap + kReadyWords * (direct ? kDirectReady : kReadyRays));
+  if (P.ldsIntensity) p = (p + kTallyWords - 1) & ~(kTallyWords - 1);
   o.tInt = p;
-  if (P.ldsIntensity) p += (P.ncomp + 1) * P.nDir * ncol;
+  if (P.ldsIntensity) p += (P.ncomp + 1) * P.nDir * ncol * kTallyWords;
   o.ext = p;
   if (grid == 0 /* GRID_LDS */) p += ncol * P.nz;
   if (grid == 2 /* GRID_BRICKS */ && !intensity) p += P.clearNx * (((P.ny - 1) >> P.clearShift) + 1);   // (the clear-air map lives at Lds::ext)

@@ -466,6 +466,10 @@ class Integrator:
         problem allows (i3rc_hip_set_batch_fusion)."""
         self._check(self._lib.i3rc_hip_set_batch_fusion(self._h, int(mode)), "set_batch_fusion")
 
+    def set_lds_tallies(self, on):
+        """False: a plain launch adds every tally straight to the float64 buffer in global memory (i3rc_hip_set_lds_tallies)."""
+        self._check(self._lib.i3rc_hip_set_lds_tallies(self._h, 1 if on else 0), "set_lds_tallies")
+
     def kernel_ms(self):
         ms = C.c_float(0)
         self._check(self._lib.i3rc_hip_last_kernel_ms(self._h, C.byref(ms)), "kernel_ms")

@@ -332,6 +332,11 @@ int i3rc_hip_has_column_records(const i3rc_hip_integrator *h);
  * when records is not NULL, writes [ny * nx][2] words: the value's bits; first layer (1-based) | (run length - 1) << 16. */
 int i3rc_hip_column_records(int nx, int ny, int nz, const float *totalExt, uint32_t *records);
 
+/* Test / tuning knob: 0 = a plain launch adds every tally straight to the float64 buffer in global memory instead of gathering a
+ * workgroup's partial sums (float64 as well) in LDS first: the same float64 additions in one more order.  Default 1.
+ * Environment: I3RC_LDS_TALLIES=0 for the whole process. */
+int i3rc_hip_set_lds_tallies(i3rc_hip_integrator *h, int on);
+
 /* Test hook, host code only (no device needed): the carve-up of a workgroup's dynamic LDS that photon_kernel makes -- the very
  * function the kernel sets its pointers from and the launch sizes its allocation from (csrc/tracer.hpp, lds_plan).
  *   q[0..15]  = nx, ny, nz, ncomp, nDir, ldsTallies, ldsIntensity, rayQueueCap, clearNx, clearShift,

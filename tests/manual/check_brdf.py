@@ -2,7 +2,7 @@ import os, sys; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(
 import numpy as np
 import i3rc_monte_carlo_model_amd as M
 from oracle import pyoracle as O
-from tests import cases
+from tools import cases
 from tests.test_gpu_parity import make_gpu, make_oracle, hg_table, _batches_gpu, _batches_oracle
 d = cases.step_cloud(ssa=1.0, nlayers=8)
 xs = np.array([0.0, 100.0, 350.0, 500.0], np.float32); ys = np.array([0.0, 500.0], np.float32)

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch  # noqa: F401  (first: one HIP runtime per process, see tests/conftest.py)
 import i3rc_monte_carlo_model_amd as M
 from oracle import pyoracle as O
-from tests import cases
+from tools import cases
 from tests.test_gpu_features import _intensity_pair, _replay_pair, hg_table
 
 O.build()

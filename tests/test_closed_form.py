@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 import i3rc_monte_carlo_model_amd as M
-from tests import cases
+from tools import cases
 
 f32 = np.float32
 SIGMAS = 4.5   # per-column bounds over ~100 cells and quantities: false alarm of a correct code < 1e-3

@@ -96,9 +96,9 @@ def test_netcdf_classic_files_are_readable_by_an_independent_reader(shell_built,
 
 
 def _write_i3rc_data_files(directory):
-    """The I3RC phase-1 input data (tests/golden/i3rc_phase1_inputs.npz) as text files in the case definition's own
+    """The I3RC phase-1 input data (tools/data/i3rc_phase1_inputs.npz) as text files in the case definition's own
     formats, for the Fortran case generators."""
-    inp = np.load(os.path.join(ROOT, "tests", "golden", "i3rc_phase1_inputs.npz"))
+    inp = np.load(os.path.join(ROOT, "tools", "data", "i3rc_phase1_inputs.npz"))
     with open(os.path.join(directory, "mmcr_tau_32km_020898"), "w") as f:
         for row in inp["mmcr_tau"]:
             f.write("".join("%8.3f" % v for v in row) + "\n")
@@ -117,9 +117,9 @@ def _write_i3rc_data_files(directory):
 
 def test_i3rc_case_generators_write_the_case_definitions(shell_built, tmp_path):
     # Fortran tools: radar and Landsat domains from the I3RC data files, compared with the
-    # numpy recipes the GPU parity tests use (tests/cases.py) -- two independent statements of the same recipe
+    # numpy recipes the GPU parity tests use (tools/cases.py) -- two independent statements of the same recipe
     from scipy.io import netcdf_file
-    from tests import cases
+    from tools import cases
 
     inp = _write_i3rc_data_files(str(tmp_path))
     dom = str(tmp_path / "radar.dom")
@@ -386,7 +386,7 @@ def test_generated_case_domains_run_through_the_driver_on_gpu(tmp_path):
     # case generator -> domain file -> read_Domain -> i3rcDriver on the GPU, against the Python host path on the numpy
     # statement of the same case (Landsat scene re-binned to 36 layers: clear cells carry phase function index 0)
     import i3rc_monte_carlo_model_amd as M
-    from tests import cases
+    from tools import cases
 
     gen, drv = _need(os.path.join(BUILD, "makeLandsatCloudDomain")), _need(os.path.join(BUILD, "i3rcDriver"))
     _write_i3rc_data_files(str(tmp_path))

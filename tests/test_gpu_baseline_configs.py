@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import i3rc_monte_carlo_model_amd as M
-from tests import cases
+from tools import cases
 from tests.test_gpu_parity import _batches_gpu, _batches_oracle, hg_table, make_gpu, make_oracle
 
 pytestmark = pytest.mark.gpu

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import i3rc_monte_carlo_model_amd as M
-from tests import cases
+from tools import cases
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
 import ref_numerics_io as io   # noqa: E402

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import i3rc_monte_carlo_model_amd as M
-from tests import cases
+from tools import cases
 from tests.conftest import record_stage1_miss
 from tests.test_gpu_parity import _assert_3sigma, hg_table, make_gpu, make_oracle
 

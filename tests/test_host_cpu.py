@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import i3rc_monte_carlo_model_amd as M
-from tests import cases
+from tools import cases
 from tests.philox_ref import philox4x32_10
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,7 +38,7 @@ def test_cabi_library_exports_every_declared_symbol():
 def test_column_records_of_a_field():
     """i3rc_hip_column_records (host code of the C ABI: the test i3rc_hip_create applies before it keeps a field as 8 bytes per
     column): one run of one value per column, compared bit by bit -- the I3RC fields as data, and the cases that must say no."""
-    from tests import cases
+    from tools import cases
     L = M.binding.load()
 
     def records(ext):
@@ -194,3 +194,49 @@ def test_no_gpu_fails_loudly():
     dom.addOpticalComponent("cloud", d["ext"], d["ssa"], d["pf"], M.PhaseFunctionTable([M.henyey_greenstein(0.85, 8)]))
     with pytest.raises(M.I3RCError, match="no HIP device"):
         M.new_Integrator(dom)
+
+
+def test_lds_carve_up_regions_do_not_overlap_and_are_aligned():
+    """csrc/tracer.hpp lds_plan -- the one function photon_kernel sets its LDS pointers from and the host sizes the launch's
+    allocation from (round 4's advisor found two copies of that arithmetic three floats apart: a 5 x 5 x 5 grid in LDS ended one word
+    past its allocation).  Shapes whose region sizes are odd and not multiples of four: every region lies inside [0, end), none
+    overlaps its neighbour, the float64 tallies are 8-byte aligned and the per-direction ray constants 16-byte aligned."""
+    from i3rc_monte_carlo_model_amd import binding as B
+
+    lib = B.load()
+    rng = np.random.default_rng(5)
+    shapes = [(5, 5, 5), (1, 1, 1), (32, 1, 16), (7, 3, 9), (33, 2, 13), (3, 11, 6)]
+    shapes += [tuple(int(v) for v in rng.integers(1, 40, 3)) for _ in range(60)]
+    for nx, ny, nz in shapes:
+        for ndir in (0, 1, 2, 7):
+            for place in (0, 1, 2, 3):
+                for tallies in (0, 1):
+                    for table in (0, 10001):
+                        intensity = 1 if ndir else 0
+                        direct = 1 if ndir == 1 else 0
+                        ncomp, cap, clear_nx, clear_shift = 1, (0 if direct or not ndir else 64), (nx + 3) // 4, 2
+                        if table and intensity:
+                            continue   # (the table-in-LDS instantiations are flux kernels)
+                        q = np.array([nx, ny, nz, ncomp, ndir, tallies, 1 if (ndir and tallies) else 0, cap, clear_nx, clear_shift,
+                                      intensity, direct, place, intensity, 16 if table else 4, table], np.int32)
+                        out = np.zeros(11, np.int32)
+                        assert lib.i3rc_hip_lds_plan(q.ctypes.data_as(B.ip), out.ctypes.data_as(B.ip)) == 0
+                        xE, yE, zE, tal, dirs, dirtab, queue, tint, ext, costab, end = (int(v) for v in out)
+                        ncol = nx * ny
+                        waves = 16 if table else 4
+                        sizes = [(xE, nx + 1), (yE, ny + 1), (zE, nz + 1), (tal, 6 * ncol if tallies else 0), (dirs, 3 * ndir),
+                                 (dirtab, 16 * ndir if intensity else 0),
+                                 (queue, waves * (14 * cap + 12 * (128 if direct else 64)) if intensity else 0),
+                                 (tint, 2 * (ncomp + 1) * ndir * ncol if (ndir and tallies) else 0),
+                                 (ext, ncol * nz if place == 0 else ((clear_nx * (((ny - 1) >> clear_shift) + 1)) if place == 2 and not intensity else 0)),
+                                 (costab, table)]
+                        at = 0
+                        for off, size in sizes:
+                            assert off >= at, (q.tolist(), out.tolist())      # no overlap with the region before
+                            at = off + size
+                        assert at <= end, (q.tolist(), out.tolist())         # ... and the last one ends inside the allocation
+                        assert end - at < 4                                   # nothing wasted beyond alignment
+                        if tallies:
+                            assert tal % 2 == 0 and (tint % 2 == 0 or not ndir)
+                        if intensity:
+                            assert dirtab % 4 == 0

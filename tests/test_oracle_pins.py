@@ -4,7 +4,7 @@ MT19937 known answers.  CPU only."""
 import numpy as np
 import pytest
 
-from tests import cases
+from tools import cases
 
 f32 = np.float32
 

@@ -29,7 +29,7 @@ import numpy as np
 import pytest
 
 import i3rc_monte_carlo_model_amd as M
-from tests import cases
+from tools import cases
 from tests.plane_parallel_solver import solve
 from tests.test_closed_form import runner   # noqa: F401  (the oracle / GPU fixture of the closed-form pins)
 

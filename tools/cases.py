@@ -1,4 +1,5 @@
-"""Synthetic domains used by tests, smoke and bench: the I3RC phase-1 recipes restated from
+"""Workload recipes -- the domains bench.py, the tools, smoke() and the tests run (moved out of tests/ in round 5: the bench no
+longer imports the tests package).  Synthetic domains: the I3RC phase-1 recipes restated from
 I3RC-Examples/i3rcStepCloud.f95:27-75 and Example-Drivers/planeParallel.f95:299-379 (float32 arithmetic
 in the reference's operator order).  Pure numpy; no oracle or product code imported here."""
 import numpy as np
@@ -85,10 +86,10 @@ def column_clouds(seed=11, nx=9, ny=6, nz=12, ssa=0.97):
     return dict(xe=xe, ye=ye, ze=ze, ext=ext, ssa=s, pf=pf)
 
 
-# ---- I3RC phase-1 fields (data fixture made by tests/golden/make_i3rc_inputs.py) ---------------------------
+# ---- I3RC phase-1 fields (input data: tools/data/i3rc_phase1_inputs.npz, made by tools/data/make_i3rc_inputs.py) ---------------------------
 import os as _os
 
-_GOLDEN = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "i3rc_phase1_inputs.npz")
+_GOLDEN = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "data", "i3rc_phase1_inputs.npz")
 
 
 def _inputs():

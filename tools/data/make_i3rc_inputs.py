@@ -1,4 +1,4 @@
-"""Generates tests/golden/i3rc_phase1_inputs.npz from the I3RC phase-1 DATA files shipped with the reference
+"""Generates tools/data/i3rc_phase1_inputs.npz from the I3RC phase-1 DATA files shipped with the reference
 (I3RC-Examples/Data/: radar optical depths, Landsat optical depth / thickness fields, C1 phase function).
 Data only -- no reference source text is copied.  Run in the build container (needs /root/reference)."""
 import os

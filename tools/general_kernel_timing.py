@@ -5,7 +5,7 @@ import numpy as np
 import i3rc_monte_carlo_model_amd as M
 if os.environ.get("I3RC_LIB"):
     M.build.LIB = os.path.abspath(os.environ["I3RC_LIB"]); M.build.needs_build = lambda: False
-from tests import cases
+from tools import cases
 from tests.test_gpu_parity import hg_table, make_gpu
 rad = dict(intensityMus=[1.0, 0.5], intensityPhis=[0.0, 40.0], useRussianRouletteForIntensity=True, zetaMin=0.3)
 t2 = [M.PhaseFunctionTable([M.henyey_greenstein(0.85, 32), M.henyey_greenstein(0.6, 16)]),

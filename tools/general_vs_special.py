@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import i3rc_monte_carlo_model_amd as M
-from tests import cases
+from tools import cases
 from tests.test_gpu_parity import hg_table, make_gpu
 rad = dict(intensityMus=[1.0, 0.5], intensityPhis=[0.0, 40.0], useRussianRouletteForIntensity=True, zetaMin=0.3)
 for name, d, tab, n, params in (("step cloud flux", cases.step_cloud(), hg_table(), 50000000, {}),

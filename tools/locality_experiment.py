@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 if len(sys.argv) > 1 and sys.argv[1] == "one":
     import numpy as np
     import i3rc_monte_carlo_model_amd as M
-    from tests import cases
+    from tools import cases
     lib, nl, n = sys.argv[2], int(sys.argv[3]), int(float(sys.argv[4]))
     first, rows = int(sys.argv[5]), int(sys.argv[6])
     if lib != "default":

@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import i3rc_monte_carlo_model_amd as M
-from tests import cases
+from tools import cases
 from tools.workloads import DIRS7
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
 nd = int(sys.argv[2]) if len(sys.argv) > 2 else 0

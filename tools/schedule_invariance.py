@@ -4,7 +4,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import i3rc_monte_carlo_model_amd as M
-from tests import cases
+from tools import cases
 from tests.test_gpu_parity import hg_table, make_gpu
 
 CASES = {"landsat": lambda: cases.landsat_cloud(ssa=0.99), "radar": cases.radar_cloud, "step": lambda: cases.step_cloud(ssa=0.99, nlayers=8)}

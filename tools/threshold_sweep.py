@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import i3rc_monte_carlo_model_amd as M
-from tests import cases
+from tools import cases
 
 hg64 = lambda: M.PhaseFunctionTable([M.henyey_greenstein(0.85, 64)])
 hg299 = lambda: M.PhaseFunctionTable([M.henyey_greenstein(0.85, 299)])

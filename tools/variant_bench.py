@@ -23,7 +23,7 @@ else:
     name = sys.argv[2]
     M = import_module("i3rc_monte_carlo_model_amd")
     M.build.LIB = lib(name) if name != "default" else M.build.LIB
-    from tests import cases
+    from tools import cases
     for nl in (16, 32):
         d = cases.step_cloud(nlayers=nl)
         dom = M.new_Domain(d["xe"], d["ye"], d["ze"]); dom.addOpticalComponent("c", d["ext"], d["ssa"], d["pf"], M.PhaseFunctionTable([M.henyey_greenstein(0.85, 64)]))

@@ -78,7 +78,7 @@ def get(name):
 
 
 def domain(w):
-    from tests import cases
+    from tools import cases
 
     fn, kw = w["domain"]
     return getattr(cases, fn)(**kw)
