@@ -27,7 +27,7 @@ SYMBOLS = [
     "i3rc_hip_get_tally_layout", "i3rc_hip_bind_tally_buffer", "i3rc_hip_set_stream", "i3rc_hip_use_own_stream", "i3rc_hip_zero_tallies",
     "i3rc_hip_launch_batch", "i3rc_hip_run_batches", "i3rc_hip_run_batches_moments", "i3rc_hip_get_moments_layout", "i3rc_hip_compute_batch", "i3rc_hip_expect_batches", "i3rc_hip_run_replay", "i3rc_hip_trace_rays", "i3rc_hip_synchronize",
     "i3rc_hip_fetch_tallies", "i3rc_hip_normalise", "i3rc_hip_last_kernel_ms", "i3rc_hip_kernel_ms_history", "i3rc_hip_set_tuning", "i3rc_hip_force_general_kernel", "i3rc_hip_select_kernel", "i3rc_hip_set_light_threshold", "i3rc_hip_set_launch_limit",
-    "i3rc_hip_set_batch_fusion", "i3rc_hip_select_grid_place", "i3rc_hip_has_column_records", "i3rc_hip_column_records", "i3rc_hip_lds_plan", "i3rc_hip_set_lds_tallies", "i3rc_hip_last_kernel_name", "i3rc_hip_timed_launch_count", "i3rc_hip_philox_blocks", "i3rc_hip_arith_check", "i3rc_hip_find_index", "i3rc_hip_surface_reflectance", "i3rc_hip_device_count", "i3rc_hip_version",
+    "i3rc_hip_set_batch_fusion", "i3rc_hip_select_grid_place", "i3rc_hip_has_column_records", "i3rc_hip_column_records", "i3rc_hip_column_records_base", "i3rc_hip_lds_plan", "i3rc_hip_set_lds_tallies", "i3rc_hip_last_kernel_name", "i3rc_hip_timed_launch_count", "i3rc_hip_philox_blocks", "i3rc_hip_arith_check", "i3rc_hip_find_index", "i3rc_hip_surface_reflectance", "i3rc_hip_device_count", "i3rc_hip_version",
 ]
 
 
@@ -125,6 +125,8 @@ def load():
         L.i3rc_hip_select_grid_place.argtypes = [H, C.c_int]
         L.i3rc_hip_has_column_records.argtypes = [H]
         L.i3rc_hip_column_records.argtypes = [C.c_int, C.c_int, C.c_int, fp, up]
+    if hasattr(L, "i3rc_hip_column_records_base"):
+        L.i3rc_hip_column_records_base.argtypes = [C.c_int, C.c_int, C.c_int, fp, up, fp]
     if hasattr(L, "i3rc_hip_lds_plan"):
         L.i3rc_hip_lds_plan.argtypes = [ip, ip]
         L.i3rc_hip_set_lds_tallies.argtypes = [H, C.c_int]

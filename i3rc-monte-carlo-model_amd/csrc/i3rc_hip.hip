@@ -73,6 +73,7 @@ struct i3rc_hip_integrator {
   DevBuf dClearMap;              // ... and its clear-air map (DevProblem::clearMap)
   int clearShift = 0, clearNx = 1, clearWords = 1;
   DevBuf dColRec;                // one record per column where every column is one run of one value (DevProblem::colRec); else empty
+  DevBuf dColBase;               // ... over a base profile (DevProblem::colBase, nz floats): the records then hold what lies ON the profile
   int gridPlace = I3RC_GRID_AUTO;   // test / tuning knob (i3rc_hip_select_grid_place)
   bool compDirty = true;         // comp[] changed since its device copy (dComp) was made
   int bsx = 0, bsy = 0, bsz = 0, nbx = 0, nby = 0, nbz = 0;
@@ -381,7 +382,12 @@ int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int n
   }
   {
     std::vector<uint32_t> rec(2 * (size_t)nx * ny);
+    std::vector<float> base((size_t)nz);
     if (i3rc_hip_column_records(nx, ny, nz, totalExt, rec.data()) == 1) CCHK(h->dColRec.upload(rec.data(), sizeof(uint32_t) * rec.size()));
+    else if (i3rc_hip_column_records_base(nx, ny, nz, totalExt, rec.data(), base.data()) == 1) {   // the same over a value per layer (a uniform gas under / around the clouds)
+      CCHK(h->dColRec.upload(rec.data(), sizeof(uint32_t) * rec.size()));
+      CCHK(h->dColBase.upload(base.data(), sizeof(float) * base.size()));
+    }
   }
   CCHK(h->dCum.upload(cumExt, sizeof(float) * ncell * ncomp));
   CCHK(h->dSsa.upload(ssa, sizeof(float) * ncell * ncomp));
@@ -668,6 +674,56 @@ int i3rc_hip_column_records(int nx, int ny, int nz, const float *totalExt, uint3
   return 1;
 }
 
+/* Column records OVER A BASE PROFILE (DevProblem::colBase): the field is base(z) + (z within the column's run ? value(x, y) : 0) in
+ * float32 arithmetic -- what a cloud scene of one run of one value per column and a horizontally uniform second component add up to.
+ * base(z) is the smallest value of the layer (some column must be outside its run there); a column's run is where it differs from
+ * the base, and its value is looked for among the float32 numbers around (first differing value - base): the one whose float32 sum
+ * with the base gives the field's value in EVERY layer of the run, bit by bit.  Host code only.  Returns 1 / 0; records as
+ * i3rc_hip_column_records, base[nz]. */
+int i3rc_hip_column_records_base(int nx, int ny, int nz, const float *totalExt, uint32_t *records, float *base) {
+  if (nx < 1 || ny < 1 || nz < 1 || !totalExt || !base || nz > 65534) return 0;
+  const size_t ncol = (size_t)nx * ny;
+  auto bits_of = [](float v) { uint32_t b; std::memcpy(&b, &v, sizeof(b)); return b; };
+  for (int k = 0; k < nz; ++k) {
+    float b = totalExt[(size_t)k * ncol];
+    for (size_t c = 1; c < ncol; ++c) b = std::min(b, totalExt[(size_t)k * ncol + c]);
+    if (!(b >= 0.0f) || !std::isfinite(b)) return 0;
+    base[k] = b;
+  }
+  for (size_t c = 0; c < ncol; ++c) {
+    int first = 0, last = 0;
+    for (int k = 0; k < nz; ++k) {
+      if (bits_of(totalExt[(size_t)k * ncol + c]) == bits_of(base[k])) continue;
+      if (first == 0) first = last = k + 1;
+      else if (last == k) last = k + 1;
+      else return 0;                       // a second run
+    }
+    uint32_t val = 0u;
+    if (first != 0) {
+      const float guess = totalExt[(size_t)(first - 1) * ncol + c] - base[first - 1];
+      bool found = false;
+      for (int step = 0; step <= 8 && !found; ++step) {   // the candidates: guess + j float32 steps, j = 0, +1, -1, +2, -2, ...
+        const int j = (step + 1) / 2 * (step % 2 ? 1 : -1);
+        float v = guess;
+        for (int t = 0; t < std::abs(j); ++t) v = std::nextafter(v, j > 0 ? INFINITY : -INFINITY);
+        if (!(v > 0.0f)) continue;
+        bool ok = true;
+        for (int k = first - 1; k < last && ok; ++k) {
+          volatile float sum = base[k] + v;   // (one float32 addition, as the host that summed the components made it)
+          ok = bits_of(sum) == bits_of(totalExt[(size_t)k * ncol + c]);
+        }
+        if (ok) { val = bits_of(v); found = true; }
+      }
+      if (!found) return 0;
+    }
+    if (records) {
+      records[2 * c] = val;
+      records[2 * c + 1] = first == 0 ? 1u : ((uint32_t)first | ((uint32_t)(last - first) << 16));
+    }
+  }
+  return 1;
+}
+
 int i3rc_hip_set_lds_tallies(i3rc_hip_integrator *h, int on) {
   if (!h) return 1;
   drop_lookahead(h);
@@ -735,6 +791,12 @@ bool common_class(const i3rc_hip_integrator *h, int srcKind) {
   const bool gridSurface = h->params.useSurfaceBDRF && !uniform_surface(h);
   return h->xyRegular && traced(h) && !gridSurface && h->ncomp == 1 && srcKind == 0;
 }
+// ... and the same class with several components (photon_kernel, MULTI; round 5).  I3RC_MULTI=0 leaves such domains to the general kernels.
+bool multi_class(const i3rc_hip_integrator *h, int srcKind) {
+  static const bool on = !(std::getenv("I3RC_MULTI") && std::atoi(std::getenv("I3RC_MULTI")) == 0);
+  const bool gridSurface = h->params.useSurfaceBDRF && !uniform_surface(h);
+  return on && h->xyRegular && traced(h) && !gridSurface && h->ncomp > 1 && srcKind == 0;
+}
 
 // One radiance direction (nadir views: BASELINE.json's radar case): the radiance kernels without an event ring (photon_kernel,
 // DIRECT).  I3RC_DIRECT=0 keeps the ring for them too.
@@ -750,7 +812,7 @@ bool direct_rays(const i3rc_hip_integrator *h) {
 
 size_t ncell_bytes(const i3rc_hip_integrator *h) { return sizeof(float) * (size_t)h->nx * h->ny * h->nz; }
 
-int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false) {
+int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false, bool replay = false) {
   DevProblem &P = plan.P;
   std::memset(&P, 0, sizeof(P));
   for (int c = 0; c < h->ncomp; ++c)
@@ -770,8 +832,13 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false) {
   // Column records where the field has them (and does not fit in LDS, below): the whole field in 8 bytes per column.  Measured:
   // I3RC_COLUMNS=0 switches them off for the process.
   static const bool columnsOn = !(std::getenv("I3RC_COLUMNS") && std::atoi(std::getenv("I3RC_COLUMNS")) == 0);
-  const bool columns = h->gridPlace == I3RC_GRID_COLUMNS || (h->gridPlace == I3RC_GRID_AUTO && columnsOn && h->dColRec.p != nullptr);
+  // (records over a base profile -- GRID_COLBASE -- are read by the kernels of domains with several components, the general and the
+  // several-components ones: the one-component specialisations and the replay build are not instantiated for them)
+  const bool baseForm = h->dColBase.p != nullptr;
+  const bool baseOk = h->ncomp > 1 && !replay;
+  const bool columns = (h->gridPlace == I3RC_GRID_COLUMNS || (h->gridPlace == I3RC_GRID_AUTO && columnsOn && h->dColRec.p != nullptr)) && (!baseForm || baseOk);
   P.colRec = columns ? (const uint2 *)h->dColRec.p : nullptr;
+  P.colBase = columns && baseForm ? (const float *)h->dColBase.p : nullptr;
   const bool bricks = h->gridPlace == I3RC_GRID_BRICKS || (h->gridPlace == I3RC_GRID_AUTO && !columns && ncell_bytes(h) > ((size_t)4 << 20) && h->nz <= 65534);
   P.extBrick = bricks ? (const float *)h->dExtBrick.p : nullptr;
   P.bsx = h->bsx; P.bsy = h->bsy; P.bsz = h->bsz; P.nbx = h->nbx; P.nbxy = h->nbx * h->nby;
@@ -838,11 +905,12 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false) {
     if (privatise && h->nDir > 0 && nInt <= 16 * 1024 && lds + nInt <= kLdsBudget) { P.ldsIntensity = 1; lds += nInt; }
   }
   P.ldsGrid = 0;
-  if (h->gridPlace == I3RC_GRID_AUTO && lds + ncell * sizeof(float) <= budget) { P.ldsGrid = 1; lds += ncell * sizeof(float); P.colRec = nullptr; P.extBrick = nullptr; }   // (never when the edges alone are beyond the budget)
+  if (h->gridPlace == I3RC_GRID_AUTO && lds + ncell * sizeof(float) <= budget) { P.ldsGrid = 1; lds += ncell * sizeof(float); P.colRec = nullptr; P.colBase = nullptr; P.extBrick = nullptr; }   // (never when the edges alone are beyond the budget)
   else if (P.extBrick && h->nDir == 0) lds += sizeof(uint32_t) * (size_t)h->clearWords;          // bricked field, flux kernels: its clear-air map
+  if (P.colBase) lds += sizeof(float) * (size_t)h->nz;                                            // column records over a base profile: the profile
   plan.ldsBytes = (lds + 15) & ~(size_t)15;
   plan.intensity = h->nDir > 0;
-  plan.place = P.ldsGrid ? GRID_LDS : (P.colRec ? GRID_COLUMNS : (P.extBrick ? GRID_BRICKS : GRID_GLOBAL));
+  plan.place = P.ldsGrid ? GRID_LDS : (P.colRec ? (P.colBase ? GRID_COLBASE : GRID_COLUMNS) : (P.extBrick ? GRID_BRICKS : GRID_GLOBAL));
   return 0;
 }
 
@@ -889,6 +957,12 @@ int upload_source(i3rc_hip_integrator *h, const i3rc_source *src, int64_t n, Run
   return 0;
 }
 
+template <class Rng, bool INTENSITY, bool GENERAL, bool DIRECT, bool MULTI>
+constexpr void (*colbase_kernel())(DevProblem, RunArgs, int, int) {
+  if constexpr (Rng::kReplay) return nullptr;
+  else return photon_kernel<Rng, INTENSITY, GENERAL, GRID_COLBASE, false, DIRECT, MULTI>;
+}
+
 template <class Rng>
 int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, bool timeIt) {
   // fast specialisations when the problem is in the common class (see photon_kernel), else the general kernel
@@ -896,19 +970,33 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
   // the specialised kernels exist once per place of the extinction grid (LDS / global / global in bricks)
   using Kernel = void (*)(DevProblem, RunArgs, int, int);
   const int place = plan.place;
-  static const Kernel general[2][4] = {
-      {photon_kernel<Rng, false, true, GRID_LDS>, photon_kernel<Rng, false, true, GRID_GLOBAL>, photon_kernel<Rng, false, true, GRID_BRICKS>, photon_kernel<Rng, false, true, GRID_COLUMNS>},
-      {photon_kernel<Rng, true, true, GRID_LDS>, photon_kernel<Rng, true, true, GRID_GLOBAL>, photon_kernel<Rng, true, true, GRID_BRICKS>, photon_kernel<Rng, true, true, GRID_COLUMNS>}};
+  // (GRID_COLBASE -- column records over a base profile -- exists for the kernels that run domains of several components: the general
+  // ones and the several-components ones; make_problem never plans it for anything else)
+  static const Kernel general[2][5] = {
+      {photon_kernel<Rng, false, true, GRID_LDS>, photon_kernel<Rng, false, true, GRID_GLOBAL>, photon_kernel<Rng, false, true, GRID_BRICKS>, photon_kernel<Rng, false, true, GRID_COLUMNS>, colbase_kernel<Rng, false, true, false, false>()},
+      {photon_kernel<Rng, true, true, GRID_LDS>, photon_kernel<Rng, true, true, GRID_GLOBAL>, photon_kernel<Rng, true, true, GRID_BRICKS>, photon_kernel<Rng, true, true, GRID_COLUMNS>, colbase_kernel<Rng, true, true, false, false>()}};
   Kernel kern = general[plan.intensity ? 1 : 0][place];
   if constexpr (!Rng::kReplay) {   // (the replay build always runs the general kernel)
-    static const Kernel special[2][4] = {
-        {photon_kernel<Rng, false, false, GRID_LDS>, photon_kernel<Rng, false, false, GRID_GLOBAL>, photon_kernel<Rng, false, false, GRID_BRICKS>, photon_kernel<Rng, false, false, GRID_COLUMNS>},
-        {photon_kernel<Rng, true, false, GRID_LDS>, photon_kernel<Rng, true, false, GRID_GLOBAL>, photon_kernel<Rng, true, false, GRID_BRICKS>, photon_kernel<Rng, true, false, GRID_COLUMNS>}};
+    static const Kernel special[2][5] = {
+        {photon_kernel<Rng, false, false, GRID_LDS>, photon_kernel<Rng, false, false, GRID_GLOBAL>, photon_kernel<Rng, false, false, GRID_BRICKS>, photon_kernel<Rng, false, false, GRID_COLUMNS>, nullptr},
+        {photon_kernel<Rng, true, false, GRID_LDS>, photon_kernel<Rng, true, false, GRID_GLOBAL>, photon_kernel<Rng, true, false, GRID_BRICKS>, photon_kernel<Rng, true, false, GRID_COLUMNS>, nullptr}};
     if (simple) kern = special[plan.intensity ? 1 : 0][place];
+    // several components, otherwise the common class: RADIANCE problems run photon_kernel<..., MULTI> (+20 % on the Landsat scene + gas
+    // with seven directions against the general radiance kernels' 166 registers and three waves per SIMD).  Flux problems stay with
+    // the general flux kernel: its several-components specialisation was built and measured -- 5.78 against 5.71e8 photons/s on
+    // Landsat-119 + gas, 9.13 against 9.08e8 on Landsat-36 + gas: the voxel steps are the same code, and a flux event's few extra
+    // reads do not show (profiles/r05_ab_experiments.txt) -- and is not in the tree.
+    const bool multi = !simple && plan.intensity && multi_class(h, A.srcKind) && h->kernelVariant != I3RC_KERNEL_GENERAL && !kNestedBuild;
+    if (multi) {
+      static const Kernel several[2][5] = {
+          {photon_kernel<Rng, true, false, GRID_LDS, false, false, true>, photon_kernel<Rng, true, false, GRID_GLOBAL, false, false, true>, photon_kernel<Rng, true, false, GRID_BRICKS, false, false, true>, photon_kernel<Rng, true, false, GRID_COLUMNS, false, false, true>, photon_kernel<Rng, true, false, GRID_COLBASE, false, false, true>},
+          {photon_kernel<Rng, true, false, GRID_LDS, false, true, true>, photon_kernel<Rng, true, false, GRID_GLOBAL, false, true, true>, photon_kernel<Rng, true, false, GRID_BRICKS, false, true, true>, photon_kernel<Rng, true, false, GRID_COLUMNS, false, true, true>, photon_kernel<Rng, true, false, GRID_COLBASE, false, true, true>}};
+      kern = several[direct_rays(h) ? 1 : 0][place];
+    } else
     if (plan.intensity && direct_rays(h)) {   // (the replay build keeps the nested local estimate: no queue at all)
-      static const Kernel direct[2][4] = {
-          {photon_kernel<Rng, true, true, GRID_LDS, false, true>, photon_kernel<Rng, true, true, GRID_GLOBAL, false, true>, photon_kernel<Rng, true, true, GRID_BRICKS, false, true>, photon_kernel<Rng, true, true, GRID_COLUMNS, false, true>},
-          {photon_kernel<Rng, true, false, GRID_LDS, false, true>, photon_kernel<Rng, true, false, GRID_GLOBAL, false, true>, photon_kernel<Rng, true, false, GRID_BRICKS, false, true>, photon_kernel<Rng, true, false, GRID_COLUMNS, false, true>}};
+      static const Kernel direct[2][5] = {
+          {photon_kernel<Rng, true, true, GRID_LDS, false, true>, photon_kernel<Rng, true, true, GRID_GLOBAL, false, true>, photon_kernel<Rng, true, true, GRID_BRICKS, false, true>, photon_kernel<Rng, true, true, GRID_COLUMNS, false, true>, colbase_kernel<Rng, true, true, true, false>()},
+          {photon_kernel<Rng, true, false, GRID_LDS, false, true>, photon_kernel<Rng, true, false, GRID_GLOBAL, false, true>, photon_kernel<Rng, true, false, GRID_BRICKS, false, true>, photon_kernel<Rng, true, false, GRID_COLUMNS, false, true>, nullptr}};
       kern = direct[simple ? 1 : 0][place];
     }
   }
@@ -923,7 +1011,7 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
     static const bool tblOn = !(std::getenv("I3RC_TABLE_LDS") && std::atoi(std::getenv("I3RC_TABLE_LDS")) == 0);
     // (grid places as a bit mask: LDS and global memory.  Bricked fields: Landsat-119 -2.5 %, the scene tiled 2 x 2 +10 %: left out)
     static const int tblPlaces = std::getenv("I3RC_TABLE_LDS_PLACES") ? std::atoi(std::getenv("I3RC_TABLE_LDS_PLACES")) : 11;
-    if (tblOn && simple && !plan.intensity && ((tblPlaces >> place) & 1) && (plan.P.uniformPf >= 1 || h->nInvEntries[0] == 1) && h->kernelVariant == I3RC_KERNEL_AUTO &&
+    if (tblOn && simple && !plan.intensity && place != GRID_COLBASE && ((tblPlaces >> place) & 1) && (plan.P.uniformPf >= 1 || h->nInvEntries[0] == 1) && h->kernelVariant == I3RC_KERNEL_AUTO &&
         plan.ldsBytes + sizeof(float) * (size_t)plan.P.comp0.nInv <= 79 * 1024) {
       static const Kernel tbl[4] = {photon_kernel<Rng, false, false, GRID_LDS, true>, photon_kernel<Rng, false, false, GRID_GLOBAL, true>,
                                     photon_kernel<Rng, false, false, GRID_BRICKS, true>, photon_kernel<Rng, false, false, GRID_COLUMNS, true>};
@@ -933,9 +1021,10 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
     }
   }
   if (ldsBytes > 160 * 1024 - 256) return h->fail("the launch needs more LDS than a compute unit has");
+  if (!kern) return h->fail("internal: no kernel for this problem at this place of the extinction field");
   const void *fn = (const void *)kern;
   {
-    static const char *const placeName[4] = {"GRID_LDS", "GRID_GLOBAL", "GRID_BRICKS", "GRID_COLUMNS"};
+    static const char *const placeName[5] = {"GRID_LDS", "GRID_GLOBAL", "GRID_BRICKS", "GRID_COLUMNS", "GRID_COLBASE"};
     static thread_local char name[96];
     std::snprintf(name, sizeof(name), "photon_kernel<%s, %s, %s, %s>", Rng::kReplay ? "ReplayStream" : "PhiloxStream",
                        plan.intensity ? "true" : "false", (simple ? "false" : "true"), placeName[place]);
@@ -943,6 +1032,11 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
     if (threads == 1024) { std::snprintf(name, sizeof(name), "photon_kernel<PhiloxStream, false, false, %s, table in LDS>", placeName[place]); h->lastKernelName = name; }
     if (!Rng::kReplay && plan.intensity && direct_rays(h)) {
       std::snprintf(name, sizeof(name), "photon_kernel<PhiloxStream, true, %s, %s, one direction>", (simple ? "false" : "true"), placeName[place]);
+      h->lastKernelName = name;
+    }
+    if (!Rng::kReplay && !simple && plan.intensity && multi_class(h, A.srcKind) && h->kernelVariant != I3RC_KERNEL_GENERAL && !kNestedBuild) {
+      std::snprintf(name, sizeof(name), "photon_kernel<PhiloxStream, %s, false, %s%s, several components>", plan.intensity ? "true" : "false", placeName[place],
+                    plan.intensity && direct_rays(h) ? ", one direction" : "");
       h->lastKernelName = name;
     }
   }
@@ -1271,7 +1365,7 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
   if (ldsBytes > 160 * 1024 - 256) return h->fail("the launch needs more LDS than a compute unit has");
   const void *fn = (const void *)kern;
   {
-    static const char *const placeName[4] = {"GRID_LDS", "GRID_GLOBAL", "GRID_BRICKS", "GRID_COLUMNS"};
+    static const char *const placeName[5] = {"GRID_LDS", "GRID_GLOBAL", "GRID_BRICKS", "GRID_COLUMNS", "GRID_COLBASE"};
     static thread_local char name[96];
     std::snprintf(name, sizeof(name), "photon_kernel<PhiloxBatchStream, %s, false, %s%s>", plan.intensity ? "true" : "false", placeName[place],
                   threads == 1024 ? ", table in LDS" : (plan.intensity && direct_rays(h) ? ", one direction" : ""));
@@ -1765,7 +1859,7 @@ int i3rc_hip_run_replay(i3rc_hip_integrator *h, int64_t nPhotons, const i3rc_sou
   if (!src || !randoms || !drawStart || nPhotons <= 0) return h->fail("i3rc_hip_run_replay: bad arguments");
   HIPCHK(h, hipSetDevice(h->device));
   LaunchPlan plan;
-  if (make_problem(h, plan)) return 1;
+  if (make_problem(h, plan, false, true)) return 1;
   RunArgs A;
   std::memset(&A, 0, sizeof(A));
   A.nPhotons = nPhotons;
@@ -1820,18 +1914,19 @@ int i3rc_hip_trace_rays(i3rc_hip_integrator *h, int64_t n, const float *dir, flo
   plan.P.ldsGrid = 0; plan.P.ldsTallies = 0;
   // the hook reads the bricked copy (its index is checked bit for bit) unless i3rc_hip_select_grid_place asked for the plain
   // field or the column records
-  const int hookPlace = h->gridPlace == I3RC_GRID_LINEAR ? GRID_GLOBAL : (h->gridPlace == I3RC_GRID_COLUMNS ? GRID_COLUMNS : GRID_BRICKS);
+  const int hookPlace = h->gridPlace == I3RC_GRID_LINEAR ? GRID_GLOBAL : (h->gridPlace == I3RC_GRID_COLUMNS ? (h->dColBase.p ? GRID_COLBASE : GRID_COLUMNS) : GRID_BRICKS);
   plan.P.extBrick = (const float *)h->dExtBrick.p;
   plan.P.colRec = (const uint2 *)h->dColRec.p;
+  plan.P.colBase = (const float *)h->dColBase.p;
   DevBuf dDir, dPos, dIdx, dTar, dTau, dSteps;
   HIPCHK(h, dDir.upload(dir, sizeof(float) * 3 * n)); HIPCHK(h, dPos.upload(pos, sizeof(float) * 3 * n));
   HIPCHK(h, dIdx.upload(idx, sizeof(int32_t) * 3 * n)); HIPCHK(h, dTar.upload(target, sizeof(float) * n));
   HIPCHK(h, dTau.alloc(sizeof(float) * n)); HIPCHK(h, dSteps.alloc(sizeof(int32_t) * n));
-  const size_t lds = sizeof(float) * ((h->nx + 1) + (h->ny + 1) + (h->nz + 1)) + sizeof(uint32_t) * (size_t)h->clearWords;
+  const size_t lds = sizeof(float) * ((h->nx + 1) + (h->ny + 1) + (h->nz + 1)) + sizeof(uint32_t) * std::max((size_t)h->clearWords, (size_t)h->nz);
   if (lds > 64 * 1024) return h->fail("i3rc_hip_trace_rays: domain edge vectors do not fit in LDS");
   // (more than 65534 layers: the clear-air map's 16-bit layer numbers do not reach the top -- the hook reads the bricks without it)
   auto *const hook = hookPlace == GRID_GLOBAL ? trace_rays_kernel<GRID_GLOBAL, false>
-                   : (hookPlace == GRID_COLUMNS ? trace_rays_kernel<GRID_COLUMNS, false>
+                   : (hookPlace == GRID_COLUMNS ? trace_rays_kernel<GRID_COLUMNS, false> : hookPlace == GRID_COLBASE ? trace_rays_kernel<GRID_COLBASE, false>
                                                 : (h->nz <= 65534 ? trace_rays_kernel<GRID_BRICKS, true> : trace_rays_kernel<GRID_BRICKS, false>));
   hipLaunchKernelGGL(hook, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, h->stream, plan.P, (long long)n,
                      (const float *)dDir.p, (float *)dPos.p, (int32_t *)dIdx.p, (const float *)dTar.p, (float *)dTau.p,

@@ -350,6 +350,11 @@ __global__ void __launch_bounds__(256) slab_fill_kernel(uint32_t seed0, uint32_t
 #ifndef I3RC_FUSED_WAVES
 #define I3RC_FUSED_WAVES 7
 #endif
+// (the radiance kernels for several components carry the stream's cursor and the component on top of the one-component kernels' 96
+// registers: planned for five waves per SIMD they keep 4 ... 14 of them in scratch; measured against four waves: DESIGN.md section 8)
+#ifndef I3RC_MULTI_WAVES
+#define I3RC_MULTI_WAVES 4
+#endif
 // GENERAL = false is the specialisation for the common problem class -- regular grid, ray tracing, one component,
 // Lambertian albedo (no BRDF grid), Directional source, production RNG: the rare paths (grid searches, periodic
 // re-wrapping loops, max-cross-section moves, BRDF lookups, component selection) are compiled out, which shrinks the
@@ -362,8 +367,14 @@ __global__ void __launch_bounds__(256) slab_fill_kernel(uint32_t seed0, uint32_t
 // roulette most rays end where they are made: the event phase itself turns its event into a ready ray (the EXPAND arithmetic, at
 // the event phase's lane count -- what EXPAND had with a ring that an event phase half fills), only the survivors go to LDS, and
 // the LDS the ring took pays for a ready store of two wavefronts: rays are traced when a wavefront of SURVIVORS has gathered.
-template <class Rng, bool INTENSITY, bool GENERAL, int GRID, bool TBL = false, bool DIRECT = false>
-__global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I3RC_RADIANCE_WAVES) : ((GENERAL || GRID == GRID_BRICKS) ? I3RC_MIN_WAVES : ((Rng::kBatched && !TBL) ? I3RC_FUSED_WAVES : I3RC_FLUX_WAVES))) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
+// MULTI (round 5; with GENERAL = false): the same specialisation for domains of SEVERAL components -- cloud + aerosol + gas is what
+// Tools/PhysicalPropertiesToDomain.f95 makes --: the component of a scattering by a compare chain over the cell's cumulative
+// extinctions (:637-638: the findIndex of (/0, cumulativeExt/), largest i with table(i) <= deviate), single-scattering albedo and
+// phase-function entry read per cell and component (:642, :684-686), tables per component.  Everything else -- regular grid, ray
+// tracing, no BRDF grid, Directional source -- as compiled out as in the one-component kernels; the deviates are drawn as the general
+// kernels draw them (the component's from the stream's cursor), so that a MULTI launch traces the general kernels' photons.
+template <class Rng, bool INTENSITY, bool GENERAL, int GRID, bool TBL = false, bool DIRECT = false, bool MULTI = false>
+__global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (MULTI ? I3RC_MULTI_WAVES : I3RC_RADIANCE_WAVES)) : ((GENERAL || GRID == GRID_BRICKS) ? I3RC_MIN_WAVES : ((Rng::kBatched && !TBL) ? I3RC_FUSED_WAVES : I3RC_FLUX_WAVES))) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   {
@@ -387,6 +398,8 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
     const int ncell = P.nx * P.ny * P.nz;
     for (int i = threadIdx.x; i < ncell; i += blockDim.x) L.ext[i] = P.totalExt[i];
   }
+  if (GRID == GRID_COLBASE)                 // the base profile of column records over a per-layer value (DevProblem::colBase)
+    for (int i = threadIdx.x; i < P.nz; i += blockDim.x) L.ext[i] = P.colBase[i];
   if (GRID == GRID_BRICKS && !INTENSITY) {   // the clear-air map of a bricked field (DevProblem::clearMap): flux kernels, see cell_extinction
     const int nWords = P.clearNx * (((P.ny - 1) >> P.clearShift) + 1);
     for (int i = threadIdx.x; i < nWords; i += blockDim.x) L.ext[i] = __uint_as_float(P.clearMap[i]);
@@ -411,6 +424,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
   constexpr bool REPLAY = Rng::kReplay;        // per-photon fates are recorded by i3rc_hip_run_replay only
   constexpr bool BATCHED = Rng::kBatched;      // fused multi-batch launch: every lane knows its photon's batch (rng.batch)
   static_assert(!BATCHED || !GENERAL, "fused multi-batch launches: specialised kernels");
+  static_assert(!MULTI || (INTENSITY && !GENERAL && !TBL && !BATCHED && !Rng::kReplay), "MULTI: a specialisation of the plain production radiance kernels");
   // Work counters of a fused launch.  Flux kernels: exact per batch, gathered per lane (below).  Radiance kernels have no
   // vector register to spare for that: their counters stay per WAVE and are handed to the batch whose photons the wave was
   // given last -- photons and dropped photons (what the normalisation needs) are exact per batch, the others over the group.
@@ -423,7 +437,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
   const size_t ncell = (size_t)P.nx * P.ny * P.nz;
   const bool rayTracing = GENERAL ? (P.useRayTracing != 0) : true;
   const bool useBDRF = GENERAL ? (P.useBDRF != 0) : false;
-  const bool multiComp = GENERAL ? (P.ncomp > 1) : false;
+  const bool multiComp = GENERAL ? (P.ncomp > 1) : MULTI;
   const bool directional = GENERAL ? (A.srcKind == 0) : true;
   // Directional photons all start at z = z0 + (1 - spacing(1)) (zMax - z0): their start layer is wave-uniform
   const float zStart = P.z0 + (1.0f - spacingf(1.0f)) * (P.zMax - P.z0);
@@ -692,9 +706,13 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
       float proj = 0.0f;
       proj += inX * L.dirCos[3 * dIdx]; proj += inY * L.dirCos[3 * dIdx + 1]; proj += inZ * uz;
       if (fabsf(proj) > 1.0f) proj = copysignf(1.0f, proj);
+#ifdef I3RC_FAST_ACOS
+      const float ang = fast_acos(proj);
+#else
       const float ang = acosf(proj);
+#endif
       const int pfi = (int)((unsigned)info >> 16);   // (table entries up to 65535: the record's upper half is unsigned)
-      const CompTables ct = GENERAL ? load_tables(Px.comp[comp - 1]) : load_tables(Px.comp0);
+      const CompTables ct = (GENERAL || MULTI) ? load_tables(Px.comp[comp - 1]) : load_tables(Px.comp0);
       const float *tab = ((info & 0x100) ? ct.fwdOrig : ct.fwd) + (size_t)(pfi - 1) * ct.nFwd;
       norm = fast_div(lookup_phase_fast(tab, ct.nFwd, ang), (4.0f * kPi) * fabsf(uz));
     }
@@ -1141,7 +1159,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
             tally.down(c2, w);
             if (REPLAY) { fateCol = c2; fateW = w; }
             float mu = exact_sqrt(rng.first());
-            while (!(fabsf(mu) > 2.0f * kTiny)) mu = exact_sqrt(GENERAL ? rng.next() : rng.fresh());   // :546-549
+            while (!(fabsf(mu) > 2.0f * kTiny)) mu = exact_sqrt((GENERAL || MULTI) ? rng.next() : rng.fresh());   // :546-549
             const float turn = rng.second();                               // phi = 2 pi turn (:550)
             if (useBDRF) w = w * surface_reflectance(Pe, r.x, r.y);
             else w = w * Pe.albedo;
@@ -1192,13 +1210,22 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
                 if (r.z - L.zE[r.iz - 1] <= 0.0f && r.dz > 0.0f) { r.z = r.z - spacingf(r.z); r.iz = r.iz - 1; }
               }
               // the cell's properties are read only where the domain does not share one value (see DevProblem)
-              const bool needCell = GENERAL || !(Pe.uniformSsa >= 0.0f) || Pe.uniformSsa < 1.0f || Pe.uniformPf < 1;
+              const bool needCell = GENERAL || MULTI || !(Pe.uniformSsa >= 0.0f) || Pe.uniformSsa < 1.0f || Pe.uniformPf < 1;
               if (needCell) cell = cell_index(Pe, r.ix, r.iy, r.iz);
               int comp = 1;                                               // :637-638
               if (multiComp || REPLAY) {
                 const float rc = rng.next();
                 if (multiComp) {
                   const float *cum = Pe.cumExt + cell;
+                  if constexpr (MULTI) {
+                    // findIndex without a first guess answers the largest i <= size(table) - 1 with table(i) <= value (its bisection starts
+                    // with upperBound = size(table) and never returns it: Code/numericUtilities.f95:234-247, pinned by
+                    // tests/golden/ref_numerics.npz): with table = (/0, cumulativeExt/) that is 1 + the number of the cell's first
+                    // ncomp - 1 cumulative extinctions at or below the deviate -- the last one is never looked at.  A compare chain: every
+                    // lane the same ncomp - 1 independent reads, where the bisection's reads depend on one another.
+                    const int nc = Pe.ncomp;
+                    for (int k = 0; k < nc - 1; ++k) comp += rc >= cum[(size_t)k * ncell] ? 1 : 0;
+                  } else
                   comp = find_index(rc, [cum, ncell](int k) { return k == 1 ? 0.0f : cum[(size_t)(k - 2) * ncell]; },
                                     Pe.ncomp + 1, 0);
                 }
@@ -1206,14 +1233,14 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
               // single-scattering albedo and phase-function entry of the cell; a value shared by the whole (one-component)
               // domain comes from the kernel arguments instead of two dependent memory reads
               float ssa;
-              if (!GENERAL && Pe.uniformSsa >= 0.0f) ssa = Pe.uniformSsa;
+              if (!GENERAL && !MULTI && Pe.uniformSsa >= 0.0f) ssa = Pe.uniformSsa;
               else ssa = Pe.ssa[(size_t)(comp - 1) * ncell + cell];
               if (ssa < 1.0f) {                                           // :642-649
                 tally.absorbed((r.iy - 1) * Pe.nx + (r.ix - 1), cell, w * (1.0f - ssa));
                 w = w * ssa;
               }
               int pfi;
-              if (!GENERAL && Pe.uniformPf >= 1) pfi = Pe.uniformPf;
+              if (!GENERAL && !MULTI && Pe.uniformPf >= 1) pfi = Pe.uniformPf;
               else pfi = max(Pe.pfIndex[(size_t)(comp - 1) * ncell + cell], 1);   // (index 0 marks clear cells: never a table offset of -1)
               if (defer) {                                                // :654-668: pushed after this event, traced in ray mode
                 pendingShadow = true; wI = w;
@@ -1227,7 +1254,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : I
               }
               if (w <= kTiny) { if (REPLAY) fate = 2; st = ST_NEW; }
               else {
-                const CompTables ct = GENERAL ? load_tables(Pe.comp[comp - 1]) : load_tables(Pe.comp0);
+                const CompTables ct = (GENERAL || MULTI) ? load_tables(Pe.comp[comp - 1]) : load_tables(Pe.comp0);
                 float cosS;
                 if constexpr (TBL) cosS = scattering_cosine<REPLAY>(rng.first(), (const lds_float *)L.cosTab, ct.nInv, refined_rcp((float)ct.nInv));
                 else cosS = scattering_cosine<REPLAY>(rng.first(), ct.invCos + (size_t)(pfi - 1) * ct.nInv, ct.nInv, refined_rcp((float)ct.nInv));
@@ -1387,6 +1414,8 @@ __global__ void __launch_bounds__(256) trace_rays_kernel(const DevProblem P, lon
   L.ext = L.zE + P.nz + 1;   // the clear-air map of the bricked field
   if (GRID == GRID_BRICKS && CLEARMAP)
     for (int i = threadIdx.x; i < P.clearNx * (((P.ny - 1) >> P.clearShift) + 1); i += blockDim.x) L.ext[i] = __uint_as_float(P.clearMap[i]);
+  if (GRID == GRID_COLBASE)
+    for (int i = threadIdx.x; i < P.nz; i += blockDim.x) L.ext[i] = P.colBase[i];
   for (int i = threadIdx.x; i <= P.nx; i += blockDim.x) L.xE[i] = P.xE[i];
   for (int i = threadIdx.x; i <= P.ny; i += blockDim.x) L.yE[i] = P.yE[i];
   for (int i = threadIdx.x; i <= P.nz; i += blockDim.x) L.zE[i] = P.zE[i];

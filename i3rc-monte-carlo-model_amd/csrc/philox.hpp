@@ -45,8 +45,23 @@ __device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, u
   return o;
 }
 
+// (measurement knob I3RC_UNIT_FLOAT, round 5 -- DESIGN.md section 8: 1 = the same float for every one of the 2^32 inputs without the
+// float64 multiply -- the quotient u / (2^32 - 1) = u (1 + 2^-32 + ...) lies strictly between u and u + 1, so it rounds as u does
+// except on a tie, which it breaks upwards: a sticky bit in the float64's last place says so to the float32 conversion, and the
+// scaling by 2^-32 is exact (checked over all 2^32 inputs on the host: tools/microbench/unit_float_check.c) --; 2 = RN(u) 2^-32, two
+// instructions, which rounds 2^25 of the 2^32 inputs -- the ties with an even mantissa -- one ulp down)
+#ifndef I3RC_UNIT_FLOAT
+#define I3RC_UNIT_FLOAT 0
+#endif
 __host__ __device__ inline float u32_to_unit_float(uint32_t u) {
+#if I3RC_UNIT_FLOAT == 1
+  const double d = (double)u;
+  return (float)__builtin_bit_cast(double, __builtin_bit_cast(uint64_t, d) | 1ull) * 2.3283064365386963e-10f;
+#elif I3RC_UNIT_FLOAT == 2
+  return (float)u * 2.3283064365386963e-10f;
+#else
   return (float)((double)u * (1.0 / 4294967295.0));
+#endif
 }
 
 // Per-lane stream.  begin_event() makes one Philox block (4 deviates) for the whole wavefront at ONE program point,

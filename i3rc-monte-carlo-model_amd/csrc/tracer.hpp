@@ -57,6 +57,11 @@ struct DevProblem {
   // in the vector L1), a cell's extinction is one load and three integer instructions, and what the field holds comes back bit
   // for bit.  null: the field has no such form (or i3rc_hip_select_grid_place asked for another place).
   const uint2 *colRec;
+  // ... OVER A BASE PROFILE (round 5, GRID_COLBASE): a field that is such a column field PLUS a value per layer -- a cloud scene over a
+  // horizontally uniform gas or aerosol: what a domain of several components adds up to -- totalExt(x, y, z) = base(z) + (z within the
+  // column's run ? value(x, y) : 0), the float32 addition the host made when it summed the components (checked bit by bit where the
+  // domain is handed over: i3rc_hip_column_records_base).  The records as above, base[nz] staged in LDS: the scene of 7.8 MB is 128 KB + 476 B.
+  const float *colBase;
   const float *cumExt, *ssa;          // [ncomp][nz][ny][nx]
   const int32_t *pfIndex;             // [ncomp][nz][ny][nx]
   const CompTables *comp;             // [ncomp] phase-function tables (device memory: indexed per lane)
@@ -132,7 +137,7 @@ constexpr int kTallyWords = (int)(sizeof(tally_t) / sizeof(float));
 struct Lds {
   lds_float *xE, *yE, *zE;    // edges
   lds_tally *tUp, *tDown, *tAbs;  // privatised flux tallies (valid when ldsTallies)
-  lds_float *ext;             // totalExt copy (valid when ldsGrid); bricked fields: the clear-air map (DevProblem::clearMap) as words
+  lds_float *ext;             // totalExt copy (valid when ldsGrid); bricked fields: the clear-air map (DevProblem::clearMap) as words; GRID_COLBASE: the base profile
   lds_float *dirCos;          // intensity directions
   lds_float *dirTab;          // ... and, per direction, what a ray of that direction derives from it (Ray::set_direction), 16 words: see photon_kernel
   lds_tally *tInt;            // privatised intensityByComponent (valid when ldsIntensity)
@@ -182,6 +187,7 @@ __host__ __device__ inline LdsPlan lds_plan(const PR &P, bool queues, bool direc
   o.ext = p;
   if (grid == 0 /* GRID_LDS */) p += ncol * P.nz;
   if (grid == 2 /* GRID_BRICKS */ && !intensity) p += P.clearNx * (((P.ny - 1) >> P.clearShift) + 1);   // (the clear-air map lives at Lds::ext)
+  if (grid == 4 /* GRID_COLBASE */) p += P.nz;                                                           // (the base profile of the column records, likewise)
   o.cosTab = p; p += tableWords;
   o.end = p;
   return o;
@@ -350,7 +356,7 @@ __device__ __forceinline__ int brick_index(const PR &P, int ix, int iy, int iz) 
 // reused it in the next loop, whose active lanes were not all active there: those lanes took the LDS branch on a
 // grid that lives in global memory and read zeros (found by the replay tests on the I3RC radar / Landsat fields;
 // tests/test_build_isa.py keeps the pattern out of the kernels).
-enum GridPlace { GRID_LDS = 0, GRID_GLOBAL = 1, GRID_BRICKS = 2, GRID_COLUMNS = 3 };
+enum GridPlace { GRID_LDS = 0, GRID_GLOBAL = 1, GRID_BRICKS = 2, GRID_COLUMNS = 3, GRID_COLBASE = 4 };
 // CLEARMAP: consult the clear-air map of a bricked field first (DevProblem::clearMap).  The flux kernels do -- Landsat-119 6.6 ->
 // 7.2e8 photons/s, the scene tiled 2 x 2 5.5 -> 6.0e8 --; the radiance kernels do not: the look-up is an LDS read in front of
 // every load, and with five waves per SIMD and no register to carry it a step ahead it cost them 11 %.
@@ -365,6 +371,13 @@ __device__ __forceinline__ float cell_extinction(const PR &P, const Lds &L, int 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P.colRec, 0, (P.nx * P.ny) << 3, 0x00020000);
     const u32x2 rec = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)((__umul24((unsigned)(iy - 1), (unsigned)P.nx) + (unsigned)(ix - 1)) << 3), 0, 0);
     return ((unsigned)iz - (rec.y & 0xffffu)) <= (rec.y >> 16) ? __uint_as_float(rec.x) : 0.0f;
+  }
+  if (GRID == GRID_COLBASE) {   // ... over a base profile (DevProblem::colBase, in LDS at Lds::ext): the host's own float32 addition
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P.colRec, 0, (P.nx * P.ny) << 3, 0x00020000);
+    const u32x2 rec = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)((__umul24((unsigned)(iy - 1), (unsigned)P.nx) + (unsigned)(ix - 1)) << 3), 0, 0);
+    const float base = L.ext[iz - 1];
+    return base + (((unsigned)iz - (rec.y & 0xffffu)) <= (rec.y >> 16) ? __uint_as_float(rec.x) : 0.0f);
   }
   if (GRID == GRID_BRICKS && CLEARMAP) {
     const uint32_t range = __float_as_uint(L.ext[__umul24((unsigned)(iy - 1) >> P.clearShift, (unsigned)P.clearNx) + ((unsigned)(ix - 1) >> P.clearShift)]);
@@ -598,6 +611,18 @@ __device__ __forceinline__ float lookup_phase(const float *tab, int n, float ang
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 __device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+// (measurement knob I3RC_FAST_ACOS, round 5: the local estimate's scattering angle (:1488-1490) from sqrt(1 - x) times a polynomial
+// of degree 7 -- Abramowitz & Stegun 4.4.46, |error| <= 2e-8 rad on [0, 1], mirrored for x < 0 -- instead of libm's acosf: the angle
+// only positions the look-up between two entries of the forward table, a ray's WEIGHT)
+__device__ __forceinline__ float fast_acos(float x) {
+  const float a = fabsf(x);
+  float p = -0.0012624911f;
+  p = __builtin_fmaf(p, a, 0.0066700901f); p = __builtin_fmaf(p, a, -0.0170881256f); p = __builtin_fmaf(p, a, 0.0308918810f);
+  p = __builtin_fmaf(p, a, -0.0501743046f); p = __builtin_fmaf(p, a, 0.0889789874f); p = __builtin_fmaf(p, a, -0.2145988016f);
+  p = __builtin_fmaf(p, a, 1.5707963050f);
+  const float r = __builtin_amdgcn_sqrtf(fmaxf(1.0f - a, 0.0f)) * p;
+  return x < 0.0f ? kPi - r : r;
+}
 // lookUpPhaseFuncValsFromTable :1613-1652 with the two divisions by the (uniform) table spacing as one reciprocal
 __device__ __forceinline__ float lookup_phase_fast(const float *tab, int n, float angle) {
   const float rcpDTheta = (float)(n - 1) * (1.0f / kPi);

@@ -331,6 +331,11 @@ int i3rc_hip_has_column_records(const i3rc_hip_integrator *h);
  * in every column the cells whose extinction is not +0 are one run of layers holding one value, bit for bit?  Returns 1 / 0 and,
  * when records is not NULL, writes [ny * nx][2] words: the value's bits; first layer (1-based) | (run length - 1) << 16. */
 int i3rc_hip_column_records(int nx, int ny, int nz, const float *totalExt, uint32_t *records);
+/* ... and the same OVER A BASE PROFILE: totalExt(x, y, z) = base(z) + (z within the column's run ? value(x, y) : 0) in float32 arithmetic --
+ * a cloud scene of one run of one value per column plus a horizontally uniform component (gas, aerosol): what several components add up to
+ * (getOpticalPropertiesByComponent, Code/opticalProperties.f95:523-537).  i3rc_hip_create keeps such a field as the records and base[nz]
+ * when the domain has several components.  Host code, no device needed; returns 1 / 0; records as above, base[nz] (must not be NULL). */
+int i3rc_hip_column_records_base(int nx, int ny, int nz, const float *totalExt, uint32_t *records, float *base);
 
 /* Test / tuning knob: 0 = a plain launch adds every tally straight to the float64 buffer in global memory instead of gathering a
  * workgroup's partial sums (float64 as well) in LDS first: the same float64 additions in one more order.  Default 1.

@@ -271,6 +271,43 @@ def test_config3_landsat36_column_by_column_with_absorption(tmp_path):
     assert abs(dg - do) < 3 * np.sqrt(do / n_g + do / (n_ref * len(z["nBad"]))) + 1e-5, (dg, do)
 
 
+def test_two_components_column_by_column_with_absorption(tmp_path):
+    """A domain of two components COLUMN BY COLUMN against the oracle: the Landsat 128 x 128 x 36 scene (omega = 0.99) plus a
+    horizontally uniform gas (omega = 0.9) -- two components, two phase-function tables, every cell optically active, omega and the
+    table entry read per cell and component (:637-649, :684-686) -- 4e6 photons a side: the per-column 3-sigma statistic on fluxUp,
+    fluxDown, fluxAbsorbed of the 16 384 columns and the absorbed profile layer by layer (where the gas absorbs above the clouds)."""
+    import os
+
+    from tests.test_gpu_parity import _assert_3sigma
+    cores = min(16, len(os.sched_getaffinity(0)))
+    per_core, n_ref = 2, 4_000_000 // (cores * 2)
+    child, out = _oracle_child(tmp_path, "landsat36_gas_absorbing", cores, per_core, n_ref, columns=True)
+    from tools import workloads as W
+
+    name, w = W.get("landsat36_gas_absorbing")
+    g, d = W.make_integrator(w)
+    gr = [g.computeRadiativeTransfer(M.new_RandomNumberSequence((77, b)), M.new_PhotonStream(1.0, 0.0, 125_000)) for b in range(1, 33)]
+    assert "false, true" in g.kernel_name(), g.kernel_name()   # (flux: the general flux kernel; the several-components kernels are radiance kernels)
+    g.finalize_Integrator()
+    for r in gr:
+        r["absorbedProfile"] = r["volumeAbsorption"].reshape(36, -1).mean(axis=1, dtype=np.float64)
+    so, se = child.communicate(timeout=900)
+    assert child.returncode == 0, so + se
+    z = np.load(out)
+    assert len(z["means"]) == cores * per_core and z["fluxAbsorbed"].shape[1:] == (128, 128)
+    orr = [dict(fluxUp=u, fluxDown=dn, fluxAbsorbed=a, absorbedProfile=p) for u, dn, a, p in zip(z["fluxUp"], z["fluxDown"], z["fluxAbsorbed"], z["absorbedProfile"])]
+    for key in ("fluxUp", "fluxDown", "fluxAbsorbed", "absorbedProfile"):
+        _assert_3sigma(gr, orr, key, floor=1e-7)
+    # the top layers hold gas only: what is absorbed there is the gas's (omega = 0.9), and it is not nothing
+    top = np.mean([r["absorbedProfile"][-3:].sum() for r in gr])
+    assert top > 0
+    n_g = 125_000 * len(gr)
+    dg, do = sum(r["counters"]["dropped"] for r in gr) / n_g, z["nBad"].sum() / (n_ref * len(z["nBad"]))
+    assert abs(dg - do) < 3 * np.sqrt(do / n_g + do / (n_ref * len(z["nBad"]))) + 1e-5, (dg, do)
+    kg = sum(r["counters"]["scatterings"] for r in gr) / n_g
+    assert abs(kg - z["scatterings"].sum() / (n_ref * len(z["nBad"]))) < 0.01 * kg
+
+
 def test_config4_column_by_column_against_the_oracles_fixture():
     """Config 4 (Landsat 128 x 128 x 119 + 7 radiance directions + the surface object) COLUMN BY COLUMN against a fixture the oracle
     wrote in the build container (tests/golden/make_config4_columns.py: 48 batches of 5e5 photons, 2.4e7 in all -- thirty photons

@@ -586,6 +586,29 @@ def test_the_same_photons_wherever_the_field_is_read_from():
                 if k in ref:
                     np.testing.assert_allclose(r[k], ref[k], rtol=1.1 * F32_ULP, atol=0, err_msg=f"{label}: {k} from {place}")
             assert_same_sums(r["raw"], ref["raw"], ref["counters"], directions=2, what=(label, place))
+    # (round 5) ... and OVER A BASE PROFILE: the Landsat scene plus a horizontally uniform gas -- two components; the field is their
+    # float32 sum, which i3rc_hip_create recognises as records + a value per layer (GRID_COLBASE): the general flux kernel, the
+    # several-components radiance kernels with and without a ring
+    from tools import workloads as W
+    for config, kw, n, want in (("landsat119_gas", dict(), 300_000, "false, true, GRID_COLBASE"),
+                                ("landsat119_gas", dict(rri, intensityMus=[0.8, 0.3], intensityPhis=[90.0, 225.0], surfaceAlbedo=0.2), 50_000, "true, false, GRID_COLBASE, several components"),
+                                ("landsat119_gas", dict(rri, intensityMus=[1.0], intensityPhis=[0.0], surfaceAlbedo=0.2), 80_000, "true, false, GRID_COLBASE, one direction, several components")):
+        out = {}
+        for place in ("auto", "linear", "bricks"):
+            g, _ = W.make_integrator(W.get(config)[1])
+            g.specifyParameters(**kw)
+            assert g.has_column_records(), config
+            g.select_grid_place(place)
+            r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((21, 4)), M.new_PhotonStream(0.7, 40.0, n))
+            out[place] = (r, g.kernel_name())
+            g.finalize_Integrator()
+        ref, name = out["auto"]
+        assert want in name, (config, name)
+        for place in ("linear", "bricks"):
+            r, other = out[place]
+            assert ("GRID_GLOBAL" if place == "linear" else "GRID_BRICKS") in other, (config, other)
+            assert r["counters"] == ref["counters"], (config, place, r["counters"], ref["counters"])
+            assert_same_sums(r["raw"], ref["raw"], ref["counters"], directions=2, what=(config, place))
     # AUTO takes the column records for a field beyond LDS that has them -- and fused batches read them too
     g = build(cases.landsat_cloud(nlayers=36), surfaceAlbedo=0.0)
     one = [g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 1 + b)), M.new_PhotonStream(1.0, 0.0, 50_000)) for b in range(3)]
@@ -672,7 +695,7 @@ def test_twelve_components(oracle):
     o = make_oracle(oracle, d, inv, fwd, fwd)
     o.specify(surfaceAlbedo=0.3, **dirs)
     gr, _ = _two_stage(oracle, g, o, 8, 20000, 0.7, ("fluxUp", "fluxDown", "fluxAbsorbed", "intensity"), per_direction=True)
-    assert "true, true" in g.kernel_name()   # the general radiance kernel
+    assert "true, false" in g.kernel_name() and "several components" in g.kernel_name()   # (round 5: the several-components radiance kernel; the general one: test_several_components_kernels_trace_the_general_kernels_photons)
     byc = np.stack([r["intensityByComponent"] for r in gr]).mean(0)
     assert byc.shape[0] == nc + 1 and np.all(byc.reshape(nc + 1, -1).sum(1) > 0)   # every component (and the surface) contributes
     g.finalize_Integrator()
@@ -788,4 +811,67 @@ def test_the_last_cells_of_a_grid_in_lds_lie_inside_the_allocation():
             a[ny - 1, nx - 1] = 0.0
             assert not a.any(), (nx, ny, nz, name)
             assert r["counters"]["scatterings"] > 0.5 * want * hit
+            g.finalize_Integrator()
+
+
+def _three_components_one_empty():
+    """a step cloud of three components: cloud, a component WITHOUT extinction anywhere (its cumulative extinction equals its
+    neighbour's: the findIndex of :637 must never pick it) and a thin absorbing gas"""
+    d = cases.step_cloud(ssa=0.97, nlayers=8)
+    gas = np.full_like(d["ext"], 4.0e-4)
+    empty = np.zeros_like(d["ext"])
+    return dict(xe=d["xe"], ye=d["ye"], ze=d["ze"], ext=[d["ext"], empty, gas], ssa=[d["ssa"], empty, np.full_like(gas, f32(0.8))],
+                pf=[d["pf"], np.zeros(empty.shape, np.int32), np.ones(gas.shape, np.int32)])
+
+
+def test_several_components_kernels_trace_the_general_kernels_photons():
+    """Round 5: domains of several components on a regular grid (cloud + aerosol + gas: what Tools/PhysicalPropertiesToDomain.f95
+    makes) no longer fall to the general kernels: photon_kernel<..., MULTI> picks the component by a compare chain where the general
+    kernels bisect (:637-638), reads omega and the table entry per cell and component, and draws its deviates as they do -- so the two
+    must trace the SAME photons: identical integer work counters, tallies (radiances by component among them) equal to the order of
+    the float64 additions.  Flux, several radiance directions (ring kernels, hybrid tables and the contribution limit), one direction
+    (no ring); two, three (one of them empty) and twelve components; grids in LDS and in global memory."""
+    t_cloud = M.PhaseFunctionTable([M.henyey_greenstein(0.85, 32), M.henyey_greenstein(0.6, 16)])
+    t_gas = M.PhaseFunctionTable([M.PhaseFunction(legendre=np.array([0.0, 0.1], np.float32))])
+    rng = np.random.default_rng(12)
+    nx, ny, nz, nc = 5, 4, 6, 12
+    twelve = dict(xe=f32(40.0) * np.arange(0, nx + 1, dtype=np.float32), ye=f32(50.0) * np.arange(0, ny + 1, dtype=np.float32),
+                  ze=f32(30.0) * np.arange(0, nz + 1, dtype=np.float32), ext=[], ssa=[], pf=[])
+    for c in range(nc):
+        e = rng.uniform(0.0, 0.006, (nz, ny, nx)).astype(np.float32)
+        e[rng.random(e.shape) < 0.25] = 0
+        twelve["ext"].append(e); twelve["ssa"].append(np.where(e > 0, f32(0.5 + 0.04 * c), f32(0.0)).astype(np.float32))
+        twelve["pf"].append(np.where(e > 0, 1, 0).astype(np.int32))
+    big = cases.landsat_cloud(nlayers=36)                       # 2.4 MB: the field stays in global memory
+    gas = np.broadcast_to(np.linspace(2.0e-5, 1.5e-5, 36, dtype=np.float32)[:, None, None], big["ext"].shape).copy()
+    big = dict(big, ext=[big["ext"], gas], ssa=[big["ssa"], np.full_like(gas, f32(0.9))], pf=[big["pf"], np.ones(gas.shape, np.int32)])
+    hg = M.PhaseFunctionTable([M.henyey_greenstein(0.85, 32)])
+    domains = [("two", cases.two_component(), [t_cloud, t_gas], 60_000), ("three, one empty", _three_components_one_empty(), [hg, hg, t_gas], 60_000),
+               ("twelve", twelve, [M.PhaseFunctionTable([M.henyey_greenstein([0.85, 0.6, 0.0][c % 3], 32)]) for c in range(nc)], 40_000),
+               ("Landsat-36 + gas", big, [hg, t_gas], 100_000)]
+    rri = dict(useRussianRouletteForIntensity=True, zetaMin=0.3)
+    problems = [dict(surfaceAlbedo=0.3),
+                dict(rri, surfaceAlbedo=0.3, intensityMus=[1.0, 0.4], intensityPhis=[0.0, 100.0], useHybridPhaseFunsForIntenCalcs=True, hybridPhaseFunWidth=7.0,
+                     numOrdersOrigPhaseFunIntenCalcs=1, limitIntensityContributions=True, maxIntensityContribution=0.5),
+                dict(rri, surfaceAlbedo=0.2, intensityMus=[0.8], intensityPhis=[200.0])]
+    for label, d, tabs, n in domains:
+        for params in problems:
+            g = make_gpu(d, tabs, **params)
+            nd = len(params.get("intensityMus", ()))
+            a = g.computeRadiativeTransfer(M.new_RandomNumberSequence((31, 2)), M.new_PhotonStream(0.7, 25.0, n))
+            name = g.kernel_name()
+            # (radiance problems: the several-components kernels; flux problems stay with the general flux kernel, which the
+            # specialisation did not beat -- csrc/i3rc_hip.hip, launch())
+            assert ("several components" in name) == (nd > 0) and (("one direction" in name) == (nd == 1)), (label, name)
+            g.set_tuning(kernel="general")
+            b = g.computeRadiativeTransfer(M.new_RandomNumberSequence((31, 2)), M.new_PhotonStream(0.7, 25.0, n))
+            assert ("true, true" if nd else "false, true") in g.kernel_name(), g.kernel_name()
+            assert a["counters"] == b["counters"], (label, params, a["counters"], b["counters"])
+            assert a["counters"]["scatterings"] > n and a["counters"]["photons"] == n
+            assert_same_sums(a["raw"], b["raw"], a["counters"], directions=nd, what=(label, nd))
+            if nd:   # every component that scatters at all contributes to the radiance by component
+                byc = a["intensityByComponent"].reshape(len(tabs) + 1, -1).sum(1)
+                assert (byc[1:] != 0).sum() >= (2 if label != "twelve" else 12), (label, byc)
+            if label == "three, one empty":
+                assert a["intensityByComponent"][2].sum() == 0 if nd else True
             g.finalize_Integrator()

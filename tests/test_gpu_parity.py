@@ -112,24 +112,32 @@ def _random_rays(rng, d, n, oracle_integ):
 
 
 @pytest.mark.parametrize("case,place", [("step", "auto"), ("irregular", "auto"), ("columns", "columns"), ("columns", "linear"),
-                                        ("columns", "auto"), ("step", "columns"), ("irregular", "linear")])
+                                        ("columns", "auto"), ("step", "columns"), ("irregular", "linear"),
+                                        ("columns over gas", "columns"), ("columns over gas", "auto")])
 def test_tracer_bit_exact(oracle, case, place):
     """accumulateExtinctionAlongPath (:1654-1807) ray by ray against the oracle, every bit of position, cell, optical path and step
-    count -- from the bricked copy of the field (what the hook reads by default), from the plain field, and from the column
-    records of a field whose columns each hold one run of one value (cases.column_clouds, the step cloud)."""
+    count -- from the bricked copy of the field (what the hook reads by default), from the plain field, from the column
+    records of a field whose columns each hold one run of one value (cases.column_clouds, the step cloud), and (round 5) from column
+    records OVER A BASE PROFILE: the same clouds plus a horizontally uniform second component."""
     rng = np.random.default_rng(42)
+    tab = hg_table()
     if case == "step":
         d = cases.step_cloud()
     elif case == "columns":
         d = cases.column_clouds()
+    elif case == "columns over gas":
+        c = cases.column_clouds()
+        gas = np.broadcast_to(np.linspace(3.0e-3, 1.0e-4, c["ext"].shape[0], dtype=np.float32)[:, None, None], c["ext"].shape).copy()
+        d = dict(c, ext=[c["ext"], gas], ssa=[c["ssa"], np.ones_like(gas)], pf=[c["pf"], np.ones(gas.shape, np.int32)])
     else:
         d = cases.irregular_domain()
-    tab = hg_table()
     g = make_gpu(d, tab)
     assert g.has_column_records() == (case != "irregular")
     if place != "auto":
         g.select_grid_place(place)
-    o = make_oracle(oracle, d, [tab.inverse_table(9001)])
+    o = make_oracle(oracle, d, [tab.inverse_table(9001)] * (2 if case == "columns over gas" else 1))
+    if case == "columns over gas":
+        d = dict(d, ext=d["ext"][0])   # (_random_rays only asks for the grid)
     n = 4000
     dirs, pos, idx, target = _random_rays(rng, d, n, o)
     tau, p2, i2, steps = g.trace_rays(dirs, pos, idx, target)

@@ -240,3 +240,51 @@ def test_lds_carve_up_regions_do_not_overlap_and_are_aligned():
                             assert tal % 2 == 0 and (tint % 2 == 0 or not ndir)
                         if intensity:
                             assert dirtab % 4 == 0
+
+
+def test_column_records_over_a_base_profile():
+    """i3rc_hip_column_records_base (host code of the C ABI: what i3rc_hip_create tries when the plain column records do not exist): a
+    cloud field of one run of one value per column PLUS a value per layer -- what cloud + a horizontally uniform gas add up to in
+    getOpticalPropertiesByComponent's float32 sum.  The records and the base give back the field bit for bit; fields without the form
+    say no."""
+    from tools import cases
+    from tools import workloads as W
+    L = M.binding.load()
+
+    def records(ext):
+        ext = np.ascontiguousarray(ext, np.float32)
+        nz, ny, nx = ext.shape
+        rec, base = np.zeros((ny * nx, 2), np.uint32), np.zeros(nz, np.float32)
+        ok = L.i3rc_hip_column_records_base(nx, ny, nz, ext.ctypes.data_as(M.binding.fp), rec.ctypes.data_as(M.binding.up), base.ctypes.data_as(M.binding.fp))
+        return ok, rec, base
+
+    def back(rec, base, shape):
+        nz, ny, nx = shape
+        val = rec[:, 0].view(np.float32).reshape(ny, nx)
+        first, span = (rec[:, 1] & 0xFFFF).reshape(ny, nx).astype(np.int64), (rec[:, 1] >> 16).reshape(ny, nx).astype(np.int64)
+        k = np.arange(1, nz + 1)[:, None, None]
+        return (base[:, None, None] + np.where((k >= first) & (k <= first + span), val[None], np.float32(0))).astype(np.float32)
+
+    fields = []
+    for name in ("landsat119_gas", "landsat36_gas"):                       # the bench workloads: the domain's own float32 sum of its components
+        w = W.get(name)[1]
+        d = W.domain(w)
+        fields.append((d["ext"] + W.gas_component(w, d)).astype(np.float32))
+    c = cases.column_clouds()
+    prof = np.linspace(3.0e-3, 1.0e-4, c["ext"].shape[0], dtype=np.float32)[:, None, None]
+    fields.append((c["ext"] + prof).astype(np.float32))                     # a base of the clouds' own order of magnitude (sums that round)
+    fields.append(c["ext"])                                                  # no base at all: the base comes out as zeros
+    for ext in fields:
+        ok, rec, base = records(ext)
+        assert ok == 1
+        assert np.array_equal(back(rec, base, ext.shape).view(np.uint32), ext.view(np.uint32))
+    assert not records(fields[3])[2].any()
+    # what has not got the form: a second run in a column, a run of two values, a layer in which no column is clear of its cloud
+    ext = fields[2].copy(); ext[0, 0, 0] += np.float32(0.01); ext[5, 0, 0] += np.float32(0.01)
+    col = c["ext"][:, 0, 0]
+    if not (col[0] > 0 and col[5] > 0):
+        assert records(ext)[0] == 0
+    for d in (cases.radar_cloud_64(), cases.irregular_domain()):
+        assert records(d["ext"])[0] == 0
+    full = np.full((4, 2, 2), 0.5, np.float32); full[:, 0, 0] = 0.7          # every layer's smallest value IS its base: fine
+    assert records(full)[0] == 1

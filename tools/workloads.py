@@ -54,6 +54,26 @@ WORKLOADS = {
     "landsat_tiled_7dir": dict(label="Landsat scene tiled 2x2: 256x256x119 + 7 radiance directions + Lambertian surface 0.2, mu0=0.5",
                                baseline_config=4, domain=("landsat_tiled", {}), moments=299, mu0=0.5,
                                params=dict(**DIRS7, **RRI), surface=0.2, photons=125_000_000, cpu_photons=6_000),
+    # ---- beyond the common class (round 5): what Tools/PhysicalPropertiesToDomain.f95 produces is cloud + aerosol + gas -- several
+    # components, every cell optically active --; irregular x / y spacing and a gridded surface send a run to the GENERAL kernels
+    "landsat119_gas": dict(label="i3rcLandsatCloud 128x128x119 + a horizontally uniform Rayleigh-like gas (two components, two "
+                                 "phase-function tables, every cell active: optical depth 0.04), mu0=1, flux", baseline_config=3,
+                           domain=("landsat_cloud", {}), gas=(2.0e-5, 1.5e-5), moments=299, mu0=1.0, params={}, photons=125_000_000, cpu_photons=20_000),
+    "landsat119_gas_7dir": dict(label="i3rcLandsatCloud 128x128x119 + gas (two components) + 7 radiance directions + Lambertian surface 0.2, mu0=0.5",
+                                baseline_config=4, domain=("landsat_cloud", {}), gas=(2.0e-5, 1.5e-5), moments=299, mu0=0.5,
+                                params=dict(**DIRS7, **RRI), surface=0.2, photons=125_000_000, cpu_photons=4_000),
+    "landsat36_gas": dict(label="i3rcLandsatCloud 128x128x36 + gas (two components), mu0=1, flux", baseline_config=3,
+                          domain=("landsat_cloud", dict(nlayers=36)), gas=(2.0e-5, 1.5e-5), moments=299, mu0=1.0, params={}, photons=125_000_000, cpu_photons=40_000),
+    # ... with absorption in both components (parity test: omega and the table entry read per cell AND component)
+    "landsat36_gas_absorbing": dict(label="i3rcLandsatCloud 128x128x36, omega = 0.99, + gas with omega = 0.9 (two components), mu0=1, flux + absorption",
+                                    baseline_config=3, domain=("landsat_cloud", dict(nlayers=36, ssa=0.99)), gas=(2.0e-5, 1.5e-5), gas_ssa=0.9, moments=299,
+                                    mu0=1.0, params={}, photons=125_000_000, cpu_photons=40_000),
+    "landsat119_irregular_7dir": dict(label="i3rcLandsatCloud 128x128x119 on an irregular x / y grid (cell widths 30 m +- 20 %) + 7 radiance "
+                                            "directions + Lambertian surface 0.2, mu0=0.5", baseline_config=4, domain=("landsat_cloud", {}), irregular=0.2,
+                                      moments=299, mu0=0.5, params=dict(**DIRS7, **RRI), surface=0.2, photons=125_000_000, cpu_photons=6_000),
+    "landsat119_brdfgrid_7dir": dict(label="i3rcLandsatCloud 128x128x119 + 7 radiance directions + a gridded Lambertian surface (8 x 8 cells, "
+                                           "reflectance 0.05 ... 0.35), mu0=0.5", baseline_config=4, domain=("landsat_cloud", {}), surface_grid=8,
+                                     moments=299, mu0=0.5, params=dict(**DIRS7, **RRI), photons=125_000_000, cpu_photons=6_000),
 }
 # Work per photon of the REFERENCE'S ALGORITHM on the four bench workloads (S tracer iterations incl. local-estimate rays,
 # K scatterings, E boundary tallies): the figures SURVEY.md 8(d)'s byte formula is evaluated with.  Recorded from runs in
@@ -78,10 +98,43 @@ def get(name):
 
 
 def domain(w):
+    import numpy as np
+
     from tools import cases
 
     fn, kw = w["domain"]
-    return getattr(cases, fn)(**kw)
+    d = getattr(cases, fn)(**kw)
+    if w.get("irregular"):   # irregular x / y spacing: cell widths drawn once (fixed seed) within +- the given fraction of the regular width
+        rng = np.random.default_rng(119)
+        for key in ("xe", "ye"):
+            e = d[key].astype(np.float64)
+            widths = np.diff(e) * rng.uniform(1.0 - w["irregular"], 1.0 + w["irregular"], len(e) - 1)
+            d[key] = np.concatenate([[e[0]], e[0] + np.cumsum(widths)]).astype(np.float32)
+    return d
+
+
+def gas_component(w, d):
+    """extinction of the horizontally uniform gas of a `gas=(bottom, top)` workload, [nz][ny][nx]"""
+    import numpy as np
+
+    nz = d["ext"].shape[0]
+    profile = np.linspace(w["gas"][0], w["gas"][1], nz, dtype=np.float32)
+    return np.broadcast_to(profile[:, None, None], d["ext"].shape).copy()
+
+
+GAS_LEGENDRE = (0.0, 0.1)   # the Rayleigh-like phase function's Legendre coefficients (P1, P2 without the factor 2l + 1)
+
+
+def surface_grid(w, d):
+    """a gridded Lambertian surface over the domain: n x n cells, reflectance 0.05 ... 0.35 in a fixed pattern"""
+    import numpy as np
+
+    n = w["surface_grid"]
+    xs = np.linspace(d["xe"][0], d["xe"][-1], n + 1).astype(np.float32)
+    ys = np.linspace(d["ye"][0], d["ye"][-1], n + 1).astype(np.float32)
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="xy")
+    refl = (0.05 + 0.30 * (((3 * i + 5 * j) % 7) / 6.0)).astype(np.float32)   # [ny][nx]
+    return xs, ys, refl
 
 
 def n_dir(w):
@@ -90,15 +143,24 @@ def n_dir(w):
 
 def make_integrator(w, device=0):
     """The product-side problem (Python mirror of the reference's module API over the C ABI)."""
+    import numpy as np
+
     import i3rc_monte_carlo_model_amd as M
 
     d = domain(w)
     table = M.PhaseFunctionTable([M.henyey_greenstein(0.85, w["moments"])])
     dom = M.new_Domain(d["xe"], d["ye"], d["ze"])
     dom.addOpticalComponent("cloud", d["ext"], d["ssa"], d["pf"], table)
+    if "gas" in w:
+        gas = gas_component(w, d)
+        dom.addOpticalComponent("gas", gas, np.full_like(gas, np.float32(w.get("gas_ssa", 1.0))), np.ones(gas.shape, np.int32),
+                                M.PhaseFunctionTable([M.PhaseFunction(legendre=np.array(GAS_LEGENDRE, np.float32))]))
     g = M.new_Integrator(dom, device=device)
     kw = dict(w["params"])
-    if "surface" in w:
+    if "surface_grid" in w:
+        xs, ys, refl = surface_grid(w, d)
+        kw["surfaceBDRF"] = M.new_SurfaceDescription(refl, xs, ys)
+    elif "surface" in w:
         kw["surfaceBDRF"] = M.new_SurfaceDescription([w["surface"]])
     else:
         kw["surfaceAlbedo"] = 0.0
@@ -114,16 +176,27 @@ def make_oracle(w):
 
     d = domain(w)
     coef = O.hg_coefficients(0.85, w["moments"])
-    inv = O.inverse_table_legendre(coef, 10001)
+    inv = [O.inverse_table_legendre(coef, 10001)]
     nd = n_dir(w)
     fwd = [O.forward_table_legendre(coef, 10001)] if nd else None
-    o = O.Integrator(d["xe"], d["ye"], d["ze"], d["ext"], d["ssa"], d["pf"], [inv], fwd, fwd)
+    ext, ssa, pf = d["ext"], d["ssa"], d["pf"]
+    if "gas" in w:
+        gas = gas_component(w, d)
+        gcoef = np.array(GAS_LEGENDRE, np.float32)
+        ext, ssa, pf = np.stack([ext, gas]), np.stack([ssa, np.full_like(gas, np.float32(w.get("gas_ssa", 1.0)))]), np.stack([pf, np.ones(gas.shape, np.int32)])
+        inv.append(O.inverse_table_legendre(gcoef, 10001))
+        if nd:
+            fwd.append(O.forward_table_legendre(gcoef, 10001))
+    o = O.Integrator(d["xe"], d["ye"], d["ze"], ext, ssa, pf, inv, fwd, fwd)
     kw = {}
     if nd:
         kw.update(intensityMus=w["params"]["intensityMus"], intensityPhis=w["params"]["intensityPhis"],
                   useRRForIntensity=int(bool(w["params"].get("useRussianRouletteForIntensity"))),
                   zetaMin=w["params"].get("zetaMin", 0.3))
-    if "surface" in w:   # new_SurfaceDescription((/ albedo /)): one cell with edges (0, huge), Code/surfaceProperties.f95:98-117
+    if "surface_grid" in w:
+        xs, ys, refl = surface_grid(w, d)
+        kw.update(surfaceBDRF=(xs, ys, refl))
+    elif "surface" in w:   # new_SurfaceDescription((/ albedo /)): one cell with edges (0, huge), Code/surfaceProperties.f95:98-117
         huge = np.finfo(np.float32).max
         kw.update(surfaceBDRF=(np.array([0.0, huge], np.float32), np.array([0.0, huge], np.float32),
                                np.array([[w["surface"]]], np.float32)))
