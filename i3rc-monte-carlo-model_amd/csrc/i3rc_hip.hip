@@ -791,11 +791,11 @@ bool common_class(const i3rc_hip_integrator *h, int srcKind) {
   const bool gridSurface = h->params.useSurfaceBDRF && !uniform_surface(h);
   return h->xyRegular && traced(h) && !gridSurface && h->ncomp == 1 && srcKind == 0;
 }
-// ... and the same class with several components (photon_kernel, MULTI; round 5).  I3RC_MULTI=0 leaves such domains to the general kernels.
+// ... and the same class widened: several components (photon_kernel, MULTI; round 5).  I3RC_MULTI=0 leaves such problems to the general kernels.
+// (... and, since the kernels that run it keep those two paths behind run-time switches, with an irregular x / y grid or a gridded surface)
 bool multi_class(const i3rc_hip_integrator *h, int srcKind) {
   static const bool on = !(std::getenv("I3RC_MULTI") && std::atoi(std::getenv("I3RC_MULTI")) == 0);
-  const bool gridSurface = h->params.useSurfaceBDRF && !uniform_surface(h);
-  return on && h->xyRegular && traced(h) && !gridSurface && h->ncomp > 1 && srcKind == 0;
+  return on && traced(h) && srcKind == 0;
 }
 
 // One radiance direction (nadir views: BASELINE.json's radar case): the radiance kernels without an event ring (photon_kernel,
@@ -1035,7 +1035,7 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
       h->lastKernelName = name;
     }
     if (!Rng::kReplay && !simple && plan.intensity && multi_class(h, A.srcKind) && h->kernelVariant != I3RC_KERNEL_GENERAL && !kNestedBuild) {
-      std::snprintf(name, sizeof(name), "photon_kernel<PhiloxStream, %s, false, %s%s, several components>", plan.intensity ? "true" : "false", placeName[place],
+      std::snprintf(name, sizeof(name), "photon_kernel<PhiloxStream, %s, false, %s%s, wide>", plan.intensity ? "true" : "false", placeName[place],
                     plan.intensity && direct_rays(h) ? ", one direction" : "");
       h->lastKernelName = name;
     }

@@ -367,7 +367,10 @@ __global__ void __launch_bounds__(256) slab_fill_kernel(uint32_t seed0, uint32_t
 // roulette most rays end where they are made: the event phase itself turns its event into a ready ray (the EXPAND arithmetic, at
 // the event phase's lane count -- what EXPAND had with a ring that an event phase half fills), only the survivors go to LDS, and
 // the LDS the ring took pays for a ready store of two wavefronts: rays are traced when a wavefront of SURVIVORS has gathered.
-// MULTI (round 5; with GENERAL = false): the same specialisation for domains of SEVERAL components -- cloud + aerosol + gas is what
+// MULTI (round 5; with GENERAL = false, radiance kernels): the common class WIDENED by what production domains bring -- several components,
+// an irregular x / y grid (only a photon's start looks its cell up: the tracer reads edges, whatever their spacing), a gridded surface
+// (only a reflection looks its reflectance up) -- while max cross-section, the other photon sources and the replay stream stay with the
+// general kernels.  For domains of SEVERAL components -- cloud + aerosol + gas is what
 // Tools/PhysicalPropertiesToDomain.f95 makes --: the component of a scattering by a compare chain over the cell's cumulative
 // extinctions (:637-638: the findIndex of (/0, cumulativeExt/), largest i with table(i) <= deviate), single-scattering albedo and
 // phase-function entry read per cell and component (:642, :684-686), tables per component.  Everything else -- regular grid, ray
@@ -436,8 +439,8 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
   constexpr bool NEED_PID = REPLAY || GENERAL; // explicit photon sources are indexed by photon number
   const size_t ncell = (size_t)P.nx * P.ny * P.nz;
   const bool rayTracing = GENERAL ? (P.useRayTracing != 0) : true;
-  const bool useBDRF = GENERAL ? (P.useBDRF != 0) : false;
-  const bool multiComp = GENERAL ? (P.ncomp > 1) : MULTI;
+  const bool useBDRF = (GENERAL || MULTI) ? (P.useBDRF != 0) : false;
+  const bool multiComp = (GENERAL || MULTI) ? (P.ncomp > 1) : false;   // (one component: no deviate is drawn for the choice, :637 -- the widened class too)
   const bool directional = GENERAL ? (A.srcKind == 0) : true;
   // Directional photons all start at z = z0 + (1 - spacing(1)) (zMax - z0): their start layer is wave-uniform
   const float zStart = P.z0 + (1.0f - spacingf(1.0f)) * (P.zMax - P.z0);
@@ -1131,7 +1134,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
           r.y = Pe.y0 + py * (Pe.yMax - Pe.y0);
           r.z = Pe.z0 + pz * (Pe.zMax - Pe.z0);
           r.ix = 1; r.iy = 1; r.iz = 1;
-          if (!GENERAL) {   // findXYIndicies :1359-1369 with the divisions by the (uniform) cell sizes done by reciprocal
+          if (!GENERAL && !(MULTI && !Pe.xyRegular)) {   // findXYIndicies :1359-1369 with the divisions by the (uniform) cell sizes done by reciprocal
             int i = min((int)exact_div(r.x - Pe.x0, Pe.deltaX, rcpDeltaX) + 1, Pe.nx);
             int j = min((int)exact_div(r.y - Pe.y0, Pe.deltaY, rcpDeltaY) + 1, Pe.ny);
             if (fabsf(L.xE[i] - r.x) < spacingf(r.x)) i = i + 1;
@@ -1140,8 +1143,8 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
             r.iy = j == Pe.ny + 1 ? 1 : j;
             r.iz = izStart;
           } else {
-            find_xy<GENERAL>(Pe, L, r.x, r.y, r.ix, r.iy);
-            find_z<GENERAL>(Pe, L, r.z, r.iz);
+            find_xy<true>(Pe, L, r.x, r.y, r.ix, r.iy);   // (the general kernels, and the several-components ones on an irregular x / y grid)
+            find_z<true>(Pe, L, r.z, r.iz);
           }
           st = ST_TRACE;
         }

@@ -18,7 +18,7 @@ def demangle_photon_kernel(name):
     place = ["GRID_LDS", "GRID_GLOBAL", "GRID_BRICKS", "GRID_COLUMNS", "GRID_COLBASE"][int(m.group(5))]
     tbl = ", table in LDS" if m.group(6) == "1" else ""   # (the fifth template argument: the round-3 experiment, kernels.hpp TBL)
     if m.group(7) == "1": tbl += ", one direction"          # (the sixth: radiance kernels without an event ring, kernels.hpp DIRECT)
-    if m.group(8) == "1": tbl += ", several components"     # (the seventh: the common class with several components, kernels.hpp MULTI)
+    if m.group(8) == "1": tbl += ", wide"     # (the seventh: the common class with several components, kernels.hpp MULTI)
     return f"photon_kernel<{rng}, {'true' if m.group(3) == '1' else 'false'}, {'true' if m.group(4) == '1' else 'false'}, {place}{tbl}>"
 
 
