@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--contact-timeout", type=float, default=float(os.environ.get("I3RC_BENCH_CONTACT_TIMEOUT", "300")),
                     help="N > 1: seconds every rank has for init_process_group and a first all-reduce before the run is called off (naming the rank)")
+    ap.add_argument("--collective-timeout", type=float, default=float(os.environ.get("I3RC_BENCH_COLLECTIVE_TIMEOUT", "600")),
+                    help="N > 1: the process group's timeout, which bounds every collective of the run (torch's default for NCCL: 600 s)")
     ap.add_argument("--contact-only", action="store_true", help="N > 1: stop after the first-contact check (process group up, one all-reduce on every rank)")
     ap.add_argument("--scale-photons", type=float, default=1.0,
                     help="test knob: scales the workload's photon counts (per GPU and per node), so that the default N > 1 mode -- configs 3 / 4 "
@@ -312,7 +314,9 @@ def worker(a):
         import datetime
 
         t_pg = time.perf_counter()
-        limit = datetime.timedelta(seconds=a.contact_timeout)
+        # (the process group's timeout bounds EVERY collective of the run, the timed steps' all-reduces included: --collective-timeout,
+        # torch's own default of ten minutes unless asked otherwise; first contact has its own, shorter watchdog: --contact-timeout)
+        limit = datetime.timedelta(seconds=max(a.collective_timeout, a.contact_timeout))
         if rehearsal:
             dist.init_process_group(backend="gloo", timeout=limit)
         else:
@@ -371,18 +375,26 @@ def worker(a):
             first, mine = rank * per_step, per_step
             total_per_step = per_step * n_gpus
 
-        def step(k, batch):
+        reduce_events = []   # (N > 1: an event on either side of every timed step's all-reduce, on the step's own stream)
+
+        def step(k, batch, timed=False):
             ln = lanes[k % len(lanes)]
             with torch.cuda.stream(ln["stream"]):
                 ln["tally"].zero_()   # computeRadiativeTransfer zeroes its tallies per call (:296-309)
                 ln["integ"].launch(M.new_RandomNumberSequence((iseed, batch)), M.new_PhotonStream(w["mu0"], 0.0, mine),
                                    firstPhoton=first, zero=False)
+                if timed and dist is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(ln["stream"])
                 if rehearsal and dist is not None:
                     host = ln["tally"].cpu()
                     all_reduce_tallies(host, dist)
                     ln["tally"].copy_(host)
                 else:
                     all_reduce_tallies(ln["tally"], dist)  # the single exchange step: sum of tallies over GPUs (RCCL)
+                if timed and dist is not None:
+                    e1.record(ln["stream"])
+                    reduce_events.append((e0, e1))
             return ln
 
         for k in range(warmup):
@@ -392,10 +404,13 @@ def worker(a):
         t0 = time.perf_counter()
         last = None
         for k in range(steps):
-            last = step(k, 1 + k)
+            last = step(k, 1 + k, timed=True)
+        torch.cuda.synchronize()
+        own_elapsed = time.perf_counter() - t0    # this rank's own work, before it waits for the others
         sync()
         elapsed = time.perf_counter() - t0
         elapsed = max_over_ranks(elapsed, dist, device="cpu" if rehearsal else "cuda")
+        reduce_ms = [e0.elapsed_time(e1) for e0, e1 in reduce_events]
         # kernel durations of the timed launches (HIP events recorded on the launch streams, read now)
         kernel_ms, n_launches = [], 0
         for ln, b0 in zip(lanes, before):
@@ -403,8 +418,24 @@ def worker(a):
             n_launches += nl
             if nl:
                 kernel_ms += [float(x) for x in ln["integ"].kernel_ms_history(min(nl, 64))]
+        # N > 1: what every rank did on its own, gathered on rank 0 -- so that the first run on a real 8-GPU node explains its own
+        # efficiency: a slow rank (max / min of the ranks' own times), the all-reduce (from the end of a rank's trace to the end of the
+        # collective: it includes the wait for the slowest rank's trace of that step), the kernels themselves
+        ranks = None
+        if dist is not None:
+            mine_stats = {"rank": rank, "device": f"cuda:{local_rank}", "photons_per_step": mine, "own_elapsed_s": own_elapsed,
+                          "kernel_ms_per_step": (float(np.mean(kernel_ms)) * n_launches / steps) if kernel_ms else None,
+                          "allreduce_ms_per_step": (float(np.mean(reduce_ms)) if reduce_ms else None),
+                          "allreduce_ms_max": (float(np.max(reduce_ms)) if reduce_ms else None)}
+            gathered = [None] * n_gpus
+            dist.all_gather_object(gathered, mine_stats)
+            own = [g["own_elapsed_s"] for g in gathered]
+            ranks = {"per_rank": gathered, "own_elapsed_s_max": max(own), "own_elapsed_s_min": min(own), "slowest_rank": int(np.argmax(own)),
+                     "imbalance": max(own) / max(min(own), 1e-12),
+                     "note": "own_elapsed_s: a rank's wall time for its timed steps up to its own stream synchronisation, before the closing barrier; "
+                             "allreduce_ms: HIP events on the step's stream around the collective (with steps in flight it overlaps the next step's trace)"}
         return dict(scaling=scaling, elapsed=elapsed, steps=steps, mine=mine, per_step=per_step, total_per_step=total_per_step,
-                    kernel_ms=kernel_ms, launches_per_step=n_launches / steps, last=last)
+                    kernel_ms=kernel_ms, launches_per_step=n_launches / steps, last=last, ranks=ranks)
 
     # N = 1: weak and strong are the same run.  N > 1 without --scaling: the metric's case -- ONE batch of the workload's
     # photons per step, sharded over the GPUs (strong) -- is the headline; the weak figure (every GPU the whole batch) is
@@ -478,7 +509,21 @@ def worker(a):
             measured = traffic / (avg_ms * 1e-3) / 1e9
             ipp = pmc["valu_instr_per_photon"]
             rate = ipp * mine / (avg_ms * 1e-3)
-            issue = {"valu_instr_per_photon": ipp, "lane_occupancy": pmc["lane_occupancy"],
+            # The counters are a profiled run's, read from a committed file -- not counted in this run.  What this run DID count itself is its
+            # work per photon (the kernel's own counters: per_photon above) and its kernel's name: both are held against the profiled
+            # launch's, so that a stale or foreign counter file shows in the line instead of passing as this run's.
+            prof = pmc.get("work_per_photon")
+            stale = []
+            if pmc.get("launch") and pmc["launch"] != integ.kernel_name():
+                stale.append(f"the counters are of {pmc['launch']}, this run's kernel is {integ.kernel_name()}")
+            if prof:
+                for key in ("S", "K"):
+                    if abs(prof[key] - kskd[key]) > 0.02 * max(kskd[key], 1e-9):
+                        stale.append(f"work per photon {key}: counters' run {prof[key]:.1f}, this run {kskd[key]:.1f}")
+            counters_from = {"file": pmc["source"], "photons": pmc.get("photons"), "collected_at_commit": pmc.get("collected_at_commit"),
+                             "launch": pmc.get("launch"), "work_per_photon": prof, "this_run_work_per_photon": {"S": kskd["S"], "K": kskd["K"]},
+                             "matches_this_run": (not stale) if (prof or pmc.get("launch")) else None, "mismatch": stale or None}
+            issue = {"valu_instr_per_photon": ipp, "lane_occupancy": pmc["lane_occupancy"], "counters_from": counters_from,
                      "achieved_instr_per_s": rate, "peak": ISSUE_PEAK, "frac": rate / ISSUE_PEAK,
                      "unit": "wave64 VALU instructions/s (whole chip)",
                      "cycles_per_valu_instr_per_simd": N_SIMD * 2.4e9 / rate,
@@ -547,6 +592,8 @@ def worker(a):
         }
         if weak is not None:
             line["weak"] = weak
+        if m.get("ranks") is not None:
+            line["ranks"] = m["ranks"]
         if nd:
             line["result_check"]["meanIntensity"] = [float(x) for x in res["intensity"].mean(axis=(1, 2))]
         print(json.dumps(line), flush=True)

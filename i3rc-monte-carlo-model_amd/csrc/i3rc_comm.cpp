@@ -151,7 +151,7 @@ int rendezvous_broadcast(void *blob, size_t n) {
 // ---- rccl ---------------------------------------------------------------------------------------------------------
 ncclComm_t g_comm = nullptr;
 hipStream_t g_stream = nullptr;
-float *g_dev = nullptr;
+void *g_dev = nullptr;     // staging buffer of the all-reduce (float or double values)
 size_t g_devCap = 0;
 
 int rccl_init() {
@@ -168,19 +168,20 @@ int rccl_init() {
   return 0;
 }
 
-int rccl_sum(float *v, int64_t n) {
-  const size_t bytes = sizeof(float) * (size_t)n;
-  if (hipSetDevice(g_local) != hipSuccess) return fail("i3rc_comm_sum_float: hipSetDevice failed");
+template <class T>
+int rccl_sum(T *v, int64_t n) {
+  const size_t bytes = sizeof(T) * (size_t)n;
+  if (hipSetDevice(g_local) != hipSuccess) return fail("i3rc_comm_sum: hipSetDevice failed");
   if (bytes > g_devCap) {
     if (g_dev) (void)hipFree(g_dev);
-    if (hipMalloc((void **)&g_dev, bytes) != hipSuccess) { g_dev = nullptr; g_devCap = 0; return fail("i3rc_comm_sum_float: hipMalloc failed"); }
+    if (hipMalloc((void **)&g_dev, bytes) != hipSuccess) { g_dev = nullptr; g_devCap = 0; return fail("i3rc_comm_sum: hipMalloc failed"); }
     g_devCap = bytes;
   }
-  if (hipMemcpyAsync(g_dev, v, bytes, hipMemcpyHostToDevice, g_stream) != hipSuccess) return fail("i3rc_comm_sum_float: H2D failed");
-  if (ncclAllReduce(g_dev, g_dev, (size_t)n, ncclFloat, ncclSum, g_comm, g_stream) != ncclSuccess)
-    return fail("i3rc_comm_sum_float: ncclAllReduce failed");
-  if (hipMemcpyAsync(v, g_dev, bytes, hipMemcpyDeviceToHost, g_stream) != hipSuccess) return fail("i3rc_comm_sum_float: D2H failed");
-  if (hipStreamSynchronize(g_stream) != hipSuccess) return fail("i3rc_comm_sum_float: stream synchronisation failed");
+  if (hipMemcpyAsync(g_dev, v, bytes, hipMemcpyHostToDevice, g_stream) != hipSuccess) return fail("i3rc_comm_sum: H2D failed");
+  if (ncclAllReduce(g_dev, g_dev, (size_t)n, sizeof(T) == 8 ? ncclDouble : ncclFloat, ncclSum, g_comm, g_stream) != ncclSuccess)
+    return fail("i3rc_comm_sum: ncclAllReduce failed");
+  if (hipMemcpyAsync(v, g_dev, bytes, hipMemcpyDeviceToHost, g_stream) != hipSuccess) return fail("i3rc_comm_sum: D2H failed");
+  if (hipStreamSynchronize(g_stream) != hipSuccess) return fail("i3rc_comm_sum: stream synchronisation failed");
   return 0;
 }
 
@@ -240,14 +241,17 @@ int shm_init() {
   return 0;
 }
 
-int shm_sum(float *v, int64_t n) {
-  for (int64_t off = 0; off < n; off += kSlotFloats) {
-    const int64_t m = std::min<int64_t>(kSlotFloats, n - off);
-    std::memcpy(g_slots + (size_t)g_rank * kSlotFloats, v + off, sizeof(float) * (size_t)m);
+template <class T>
+int shm_sum(T *v, int64_t n) {
+  const int64_t slot = kSlotFloats * (int64_t)sizeof(float) / (int64_t)sizeof(T);   // elements of T per rank's staging slot
+  T *const slots = (T *)g_slots;
+  for (int64_t off = 0; off < n; off += slot) {
+    const int64_t m = std::min<int64_t>(slot, n - off);
+    std::memcpy(slots + (size_t)g_rank * slot, v + off, sizeof(T) * (size_t)m);
     if (shm_barrier()) return 1;
-    for (int64_t i = 0; i < m; ++i) {   // ranks summed in rank order: every process gets the same float32 result
-      float s = 0.0f;
-      for (int r = 0; r < g_size; ++r) s += g_slots[(size_t)r * kSlotFloats + i];
+    for (int64_t i = 0; i < m; ++i) {   // ranks summed in rank order: every process gets the same result
+      T s = 0;
+      for (int r = 0; r < g_size; ++r) s += slots[(size_t)r * slot + i];
       v[off + i] = s;
     }
     if (shm_barrier()) return 1;
@@ -289,6 +293,12 @@ int i3rc_comm_local_device(void) { return g_backend == SHM ? 0 : g_local; }
 int i3rc_comm_sum_float(float *values, int64_t n) {
   if (n <= 0 || g_backend == NONE || !g_ready) return 0;
   if (!values) return fail("i3rc_comm_sum_float: null buffer");
+  return g_backend == RCCL ? rccl_sum(values, n) : shm_sum(values, n);
+}
+
+int i3rc_comm_sum_double(double *values, int64_t n) {
+  if (n <= 0 || g_backend == NONE || !g_ready) return 0;
+  if (!values) return fail("i3rc_comm_sum_double: null buffer");
   return g_backend == RCCL ? rccl_sum(values, n) : shm_sum(values, n);
 }
 

@@ -1194,14 +1194,18 @@ __global__ void __launch_bounds__(256) moments_excess_kernel(MomentsDev M, const
   __syncthreads();
   if (threadIdx.x == 0) excessSums[(size_t)b * per + jd] = part[0] + part[1] + part[2] + part[3];
 }
-// fields: one thread per element, the group's batches one after the other
+// fields: one thread per element and SLICE of the group's batches (blockIdx.y; a slice's batches one after the other).  A small domain
+// with many batches -- 700 elements x 1e5 batches of a thousand photons -- would otherwise be a few hundred threads walking 1e5 batches
+// each, longer than the trace itself (round-4 advisor): the launch cuts the batches into as many slices as fill the chip.
 __global__ void __launch_bounds__(256) moments_fields_kernel(MomentsDev M, const double *blocks, int count, long long stride, const double *excessSums,
                                                              long long nFields, double *sum, double *sumSq) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= nFields) return;
   const int per = (M.ncomp + 1) * M.nDir;
+  const int perSlice = (count + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int b0 = (int)blockIdx.y * perSlice, b1 = min(count, b0 + perSlice);
   double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < count; ++b) {
+  for (int b = b0; b < b1; ++b) {
     const double x = (double)normalised_value(M, blocks + (size_t)b * stride, excessSums + (size_t)b * per, e);
     s1 += x; s2 += x * x;
   }
@@ -1485,7 +1489,10 @@ int accumulate_moments(i3rc_hip_integrator *h, hipStream_t stream, const double 
     hipLaunchKernelGGL(moments_excess_kernel, dim3((unsigned)(count * per)), dim3(256), 0, stream, M, blocks, stride, (double *)excess.p);
   }
   const long long nFields = L.absorbedProfile;   // (fluxUp ... intensity: everything in front of the profile)
-  hipLaunchKernelGGL(moments_fields_kernel, dim3((unsigned)((nFields + 255) / 256)), dim3(256), 0, stream, M, blocks, count, stride,
+  // (slices of the batch range: enough threads for the chip -- 256 CUs x 8 workgroups -- however few the elements are, at least 8 batches a slice)
+  const long long fieldBlocks = (nFields + 255) / 256;
+  const int slices = (int)std::max<long long>(1, std::min<long long>({(long long)(count + 7) / 8, (2048 + fieldBlocks - 1) / fieldBlocks, 65535}));
+  hipLaunchKernelGGL(moments_fields_kernel, dim3((unsigned)fieldBlocks, (unsigned)slices), dim3(256), 0, stream, M, blocks, count, stride,
                      (const double *)excess.p, nFields, (double *)h->momSum.p, (double *)h->momSq.p);
   hipLaunchKernelGGL(moments_means_kernel, dim3((unsigned)(count * (3 + h->nz + h->nDir))), dim3(256), 0, stream, M, blocks, stride,
                      (const double *)excess.p, (double *)h->momSum.p, (double *)h->momSq.p, (double *)h->momCounters.p);

@@ -23,7 +23,7 @@ module monteCarloRadiativeTransfer
   use surfaceProperties,        only: surfaceDescription, copy_surfaceDescription, finalize_surfaceDescription, &
                                       isReady_surfaceDescription, getSurfaceGrid
   use monteCarloIllumination,   only: photonStream, morePhotonsExist, describeStream, streamArrays, consumeStream
-  use MultipleProcesses,        only: localDevice
+  use MultipleProcesses,        only: localDevice, sumAcrossProcesses
   use i3rcHipInterface
   implicit none
   private
@@ -73,7 +73,7 @@ module monteCarloRadiativeTransfer
   ! Not in the reference: a driver's batch loop as one call, the batches overlapping on the device (see the procedures)
   public :: computeRadiativeTransferBatches, selectBatchResults
   ! ... and the same loop with its statistics -- all a driver keeps of its batches -- gathered on the device
-  public :: computeRadiativeTransferBatchMoments, reportBatchMoments
+  public :: computeRadiativeTransferBatchMoments, reportBatchMoments, sumBatchMomentsAcrossProcesses
 contains
   ! ------------------------------------------------------------------------------------------------
   ! Creation
@@ -720,6 +720,32 @@ contains
       call setStateToFailure(status, "computeRadiativeTransfer: Didn't process any photons.")
     end if
   end subroutine computeRadiativeTransferBatchMoments
+
+  ! The batch moments of every process's share of a loop, summed over the processes: ONE all-reduce of ONE packed float64
+  ! buffer (sums | sums of squares | number of batches) -- where the reference's drivers call sumAcrossProcesses ten times on real(4)
+  ! fields (monteCarloDriver.f95:333-352 over Code/multipleProcesses_mpi.f95:57-131).  Afterwards reportBatchMoments reports
+  ! the whole loop on every process.  A collective: every process calls it.
+  subroutine sumBatchMomentsAcrossProcesses(thisIntegrator, status)
+    type(integrator),   intent(inout) :: thisIntegrator
+    type(ErrorMessage), intent(inout) :: status
+    real(c_double), dimension(:), allocatable :: packed
+    integer :: n
+
+    if(.not. associated(thisIntegrator%momentSums)) then
+      call setStateToFailure(status, "sumBatchMomentsAcrossProcesses: no batch moments have been computed.")
+      return
+    end if
+    n = size(thisIntegrator%momentSums)
+    allocate(packed(2 * n + 1))
+    packed(1:n)         = thisIntegrator%momentSums
+    packed(n + 1:2 * n) = thisIntegrator%momentSquares
+    packed(2 * n + 1)   = real(thisIntegrator%momentBatches, c_double)
+    packed = sumAcrossProcesses(packed)
+    thisIntegrator%momentSums    = packed(1:n)
+    thisIntegrator%momentSquares = packed(n + 1:2 * n)
+    thisIntegrator%momentBatches = nint(packed(2 * n + 1))
+    deallocate(packed)
+  end subroutine sumBatchMomentsAcrossProcesses
 
   subroutine reportBatchMoments(thisIntegrator, numBatches, meanFluxUpStats, meanFluxDownStats, meanFluxAbsorbedStats,      &
                                 fluxUpStats, fluxDownStats, fluxAbsorbedStats, absorbedProfileStats, volumeAbsorptionStats, &

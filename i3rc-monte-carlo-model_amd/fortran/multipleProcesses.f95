@@ -1,7 +1,7 @@
 ! Fortran-95 shell of the MI355X photon-tracing integrator -- process layer.
 ! Public interface of the reference's module MultipleProcesses (Code/multipleProcesses_nompi.f95:15-99,
 ! Code/multipleProcesses_mpi.f95:17-131): MasterProc, initializeProcesses, synchronizeProcesses,
-! finalizeProcesses, sumAcrossProcesses (real scalar and rank 1-4 arrays).
+! finalizeProcesses, sumAcrossProcesses (real scalar and rank 1-4 arrays; as an extension a real(8) rank-1 array).
 !
 ! One process per GPU.  Where the reference calls MPI_REDUCE(MPI_REAL, MPI_SUM) (:57-131) this module calls
 ! i3rc_comm_sum_float (include/i3rc_comm.h): an RCCL all-reduce over xGMI (every rank receives the sum, a superset of
@@ -14,7 +14,7 @@ module MultipleProcesses
   logical, save :: MasterProc = .true.
 
   interface sumAcrossProcesses
-    module procedure sumScalar, sumRank1, sumRank2, sumRank3, sumRank4
+    module procedure sumScalar, sumRank1, sumRank2, sumRank3, sumRank4, sumRank1Double
   end interface sumAcrossProcesses
 
   interface
@@ -36,6 +36,12 @@ module MultipleProcesses
       real(c_float), intent(inout) :: values(*)
       integer(c_int64_t), value    :: n
       integer(c_int)               :: rc
+    end function
+    function i3rc_comm_sum_double(values, n) bind(C, name = "i3rc_comm_sum_double") result(rc)
+      import
+      real(c_double), intent(inout) :: values(*)
+      integer(c_int64_t), value     :: n
+      integer(c_int)                :: rc
     end function
     function i3rc_comm_finalize() bind(C, name = "i3rc_comm_finalize") result(rc)
       import
@@ -138,6 +144,21 @@ contains
     total = reshape(flat, shape(x))
     deallocate(flat)
   end function sumRank4
+
+  ! An extension (the reference's MPI_REDUCE is MPI_REAL, :57-131): one float64 all-reduce of a packed buffer -- what the build's own
+  ! driver sums its device-side batch moments with (monteCarloRadiativeTransfer: sumBatchMomentsAcrossProcesses), instead of
+  ! rounding them to real(4) and reducing field by field.
+  function sumRank1Double(x) result(total)
+    real(c_double), dimension(:), intent(in) :: x
+    real(c_double), dimension(size(x))       :: total
+    total = x
+    if(size(total) == 0) return
+    if(i3rc_comm_sum_double(total, int(size(total), c_int64_t)) /= 0) then
+      print *, "sumAcrossProcesses failed: " // lastError()
+      stop 1
+    end if
+  end function sumRank1Double
+
   function lastError() result(message)
     character(len = 256) :: message
     character(kind = c_char), pointer :: chars(:)

@@ -6,6 +6,7 @@ program commSelfTest
   integer :: numProcs, thisProc, i, j, k, l
   real    :: s, v1(5), v2(3, 2), v3(2, 3, 2), v4(2, 2, 2, 3), big(3000000)
   real    :: want
+  real(8) :: d1(700001)   ! (an odd length beyond one staging slot of the shm backend: 2^19 float64 values)
   logical :: ok
 
   call initializeProcesses(numProcs, thisProc)
@@ -28,6 +29,11 @@ program commSelfTest
   ok = ok .and. all(v4 == 0.)
   big = real(thisProc + 1)                                          ! longer than one staging slot of the shm backend
   big = sumAcrossProcesses(big);                                    ok = ok .and. all(big == want)
+  ! the float64 extension: values a real(4) sum would round (1 + 2^-40 per rank), exact in float64
+  d1 = (1.d0 + 2.d0**(-40)) * (thisProc + 1)
+  d1(700001) = 1.d15 + thisProc
+  d1 = sumAcrossProcesses(d1)
+  ok = ok .and. all(d1(:700000) == (1.d0 + 2.d0**(-40)) * want) .and. d1(700001) == numProcs * 1.d15 + numProcs * (numProcs - 1) / 2
   call synchronizeProcesses
   if(ok) then
     print '(a, i0, a, i0, a, l1)', "rank ", thisProc, " of ", numProcs, " sums ok master=", MasterProc

@@ -17,7 +17,7 @@ program i3rcDriver
   use monteCarloRadiativeTransfer, only: integrator, new_Integrator, specifyParameters, isReady_Integrator, &
                                          finalize_Integrator, computeRadiativeTransfer, reportResults,           &
                                          computeRadiativeTransferBatches, selectBatchResults, &
-                                         computeRadiativeTransferBatchMoments, reportBatchMoments
+                                         computeRadiativeTransferBatchMoments, reportBatchMoments, sumBatchMomentsAcrossProcesses
   use UserInterface,               only: printStatus, getOneArgument
   implicit none
 
@@ -50,7 +50,7 @@ program i3rcDriver
   integer :: inFlight, groupSize, groupStart, inGroup, deviceMoments
   real    :: tallyWords
   character(len = 32) :: envText
-  logical :: wantRadiance
+  logical :: wantRadiance, momentsAreGlobal = .false.
   real    :: t0, t1, t2, cpuSetup
   integer :: nc, v, rc                       ! netCDF result file: file id, variable id, return code
   real, allocatable :: xEdges(:), yEdges(:), zEdges(:)
@@ -146,6 +146,11 @@ program i3rcDriver
   if(deviceMoments /= 0 .and. inFlight /= 1) then
     call computeRadiativeTransferBatchMoments(mc, iseed, firstBatch, perProc, solarMu, solarAzimuth, numPhotonsPerBatch, status)
     call printStatus(status)
+    ! the processes' shares of the loop: ONE all-reduce of the packed float64 moments (where the reference's driver reduces ten
+    ! real(4) fields one by one, :333-352) -- what reportBatchMoments hands out below is the whole loop's, on every process
+    call sumBatchMomentsAcrossProcesses(mc, status)
+    call printStatus(status)
+    momentsAreGlobal = .true.
     call reportBatchMoments(mc, meanFluxUpStats = mMeans(1, :), meanFluxDownStats = mMeans(2, :), meanFluxAbsorbedStats = mMeans(3, :), &
                             fluxUpStats = mUp, fluxDownStats = mDown, fluxAbsorbedStats = mAbs, absorbedProfileStats = mProfile,        &
                             volumeAbsorptionStats = mVolume, status = status)
@@ -181,11 +186,13 @@ program i3rcDriver
   end do
 
   ! -- gather over processes, then mean and standard error from the two moments
-  mMeans(1, :) = sumAcrossProcesses(mMeans(1, :)); mMeans(2, :) = sumAcrossProcesses(mMeans(2, :))
-  mMeans(3, :) = sumAcrossProcesses(mMeans(3, :))
-  mUp = sumAcrossProcesses(mUp); mDown = sumAcrossProcesses(mDown); mAbs = sumAcrossProcesses(mAbs)
-  mProfile = sumAcrossProcesses(mProfile); mVolume = sumAcrossProcesses(mVolume)
-  if(wantRadiance) mRad = sumAcrossProcesses(mRad)
+  if(.not. momentsAreGlobal) then   ! (the batch-by-batch loop: real(4) sums, field by field, as the reference's driver reduces them)
+    mMeans(1, :) = sumAcrossProcesses(mMeans(1, :)); mMeans(2, :) = sumAcrossProcesses(mMeans(2, :))
+    mMeans(3, :) = sumAcrossProcesses(mMeans(3, :))
+    mUp = sumAcrossProcesses(mUp); mDown = sumAcrossProcesses(mDown); mAbs = sumAcrossProcesses(mAbs)
+    mProfile = sumAcrossProcesses(mProfile); mVolume = sumAcrossProcesses(mVolume)
+    if(wantRadiance) mRad = sumAcrossProcesses(mRad)
+  end if
   call synchronizeProcesses
   call cpu_time(t2)
   t2 = sumAcrossProcesses(t2 - t0)

@@ -26,6 +26,10 @@ int i3rc_comm_init(int *numProcs, int *thisProc);   /* initializeProcesses(numPr
 int i3rc_comm_local_device(void);                    /* HIP device of this process (LOCAL_RANK), 0 for one process */
 int i3rc_comm_barrier(void);                         /* synchronizeProcesses */
 int i3rc_comm_sum_float(float *values, int64_t n);   /* sumAcrossProcesses: in place, result on every rank */
+/* ... and in float64 (ncclDouble): no counterpart in the reference, whose MPI_REDUCE is MPI_REAL -- for the build's own driver, which
+ * gathers a loop's statistics on the device in float64 (i3rc_hip_run_batches_moments) and sums them over the ranks in ONE packed
+ * buffer without rounding them to real(4) first (fortran/tools/i3rcDriver.f95, sumAcrossProcesses for real(8) arrays). */
+int i3rc_comm_sum_double(double *values, int64_t n);
 int i3rc_comm_finalize(void);                        /* finalizeProcesses */
 const char *i3rc_comm_last_error(void);
 

@@ -28,7 +28,12 @@ def test_gpus_1_goes_through_the_spawn_path():
     assert j["config"]["photons_per_step"] == 2000000 and j["value"] > 1e7
     assert j["roofline"]["kernel"] == "photon_kernel<PhiloxStream, false, false, GRID_LDS, table in LDS>"
     assert abs(j["result_check"]["meanFluxUp"] - 0.3253) < 2e-3
-    assert len(j["devices"]) == 1
+    assert len(j["devices"]) == 1 and "ranks" not in j
+    # (round 5) the instruction counters are a profiled run's, read from a committed file: the line says which, and whether that run's
+    # kernel and work per photon are this run's
+    cf = j["roofline"]["issue"]["counters_from"]
+    assert cf["file"].startswith("profiles/") and cf["photons"] > 0 and abs(cf["this_run_work_per_photon"]["S"] - j["roofline"]["per_photon"]["S"]) < 1e-9
+    assert cf["matches_this_run"] in (True, None), cf
 
 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
@@ -42,6 +47,12 @@ def test_two_ranks_end_to_end_in_rehearsal_mode(scaling):
     assert j["config"]["photons_per_step"] == (2 * n if scaling == "weak" else n)
     assert j["config"]["photons_per_gpu_per_step"] == (n if scaling == "weak" else n // 2 + 1)
     assert abs(j["result_check"]["meanFluxUp"] - 0.3253) < 3e-3
+    # (round 5) an N > 1 line says what every rank did on its own: kernel time, all-reduce time, own wall time -- and who was slowest
+    rk = j["ranks"]
+    assert [r["rank"] for r in rk["per_rank"]] == [0, 1] and rk["slowest_rank"] in (0, 1)
+    for r in rk["per_rank"]:
+        assert r["kernel_ms_per_step"] > 0 and r["allreduce_ms_per_step"] > 0 and 0 < r["own_elapsed_s"] <= j["ms_per_step"] * j["steps"] / 1e3 * 1.001
+    assert rk["own_elapsed_s_min"] <= rk["own_elapsed_s_max"] and rk["imbalance"] >= 1.0
 
 
 def test_two_ranks_default_is_the_metrics_case_with_the_weak_figure_beside_it():

@@ -355,7 +355,7 @@ def test_reference_drivers_run_unchanged_on_gpu(tmp_path):
         assert set(fo.variables) == set(fr.variables) and set(fo.dimensions) == set(fr.dimensions)
         for k in fr.variables:
             assert fo.variables[k].dimensions == fr.variables[k].dimensions
-            # two runs of the same deck: float32 LDS partial sums are order dependent, so not bit-equal
+            # two drivers on the same deck: the reference's adds real(4) values batch by batch, the shell's gathers float64 moments
             # (standard errors are square roots of small differences of squares: they amplify a last-bit change of a mean)
             tol = 5e-3 if k.endswith("_StdErr") else 2e-5
             assert np.allclose(fo.variables[k].data, fr.variables[k].data, rtol=tol, atol=1e-6), k
@@ -369,11 +369,14 @@ def test_reference_drivers_run_unchanged_on_gpu(tmp_path):
         rcs, outs = _spawn_ranks([own, str(out / "own2.nml")], 2, 29641, cwd=ROOT)
         assert rcs == [0, 0], outs
         assert "batches on each of" in outs[0]
+        # (round 5: the two processes' device moments are summed in float64, packed into ONE all-reduce -- sumBatchMomentsAcrossProcesses --
+        # instead of ten real(4) reduces: the files of two processes equal those of one to the printed digits, every line of them)
         two = open(str(out / "own2_flux.txt")).read().splitlines()
-        one = own_flux.splitlines()
-        m1 = [float(v) for v in one[12].split()[1:]]
-        m2 = [float(v) for v in two[12].split()[1:]]
-        assert np.allclose(m1, m2, atol=2e-4), (one[12], two[12])
+        same_to_the_printed_digits(two[9:], own_flux.splitlines()[9:], "two processes: flux")
+        for name in ("rad", "absprof"):
+            a = open(str(out / f"own2_{name}.txt")).read().splitlines()
+            b = open(str(out / f"own_{name}.txt")).read().splitlines()
+            same_to_the_printed_digits(a, b, "two processes: " + name)
     from scipy.io import netcdf_file
 
     f = netcdf_file(str(out / "stepCloud_results.nc"), "r", mmap=False)

@@ -3,6 +3,7 @@
 # directories, and collecting one of them put older measurements over newer ones.
 #   tools/evidence_round.sh <tag> counters   (GPU box) per BASELINE workload: the --pmc passes (tools/pmc_profile.sh), rocprofv3
 #                                            --kernel-trace --stats of `bench.py --config <w>`, the bench line itself
+#   tools/evidence_round.sh <tag> general    (GPU box) the same for the general-class workloads (several components, irregular grid, gridded surface)
 #   tools/evidence_round.sh <tag> loop       (GPU box) the batch loop and the rest: fused / look-ahead / moments timing, the
 #                                            drivers end to end, the strong-scaling proxy, config_bench, the phase profile,
 #                                            call overhead, the issue-rate and atomic-rate microbenchmarks
@@ -11,6 +12,8 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=$1; PART=$2; O=$R/gpurun_out/$TAG
 WL="step16 radar64_nadir landsat36 landsat119_7dir"
+# round 5: the problems beyond the common class -- several components, an irregular x / y grid, a gridded surface (tools/workloads.py)
+GL="landsat119_gas landsat119_gas_7dir landsat119_irregular_7dir landsat119_brdfgrid_7dir"
 clean() { grep -v "amdgpu.ids" "$1" > "$1.clean" && mv "$1.clean" "$1"; }
 case $PART in
 counters)
@@ -30,11 +33,29 @@ counters)
     echo "$w done: $(python3 -c "import json;j=json.load(open('$O/bench_$w.json'));print('%.3e photons/s'%j['value'], j['roofline']['kernel'])")"
   done
   echo "evidence $TAG: counters done";;
+general)
+  # the same three things -- counter passes, rocprofv3 kernel stats of the bench, the bench line -- for the general-class workloads
+  mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+  declare -A N=( [landsat119_gas]=50000000 [landsat119_gas_7dir]=10000000 [landsat119_irregular_7dir]=10000000 [landsat119_brdfgrid_7dir]=10000000 )
+  for w in ${WORKLOADS:-$GL}; do
+    PASSES="1 2 9 10" $R/tools/pmc_profile.sh $TAG/pmc_$w $w ${N[$w]} > $O/pmc_$w.log 2>&1 || echo "pmc $w failed"
+    ( export RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533
+      rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$w -- python3 $R/bench.py --config $w --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_prof_$w.json 2> $O/bench_prof_$w.err ) || echo "stats $w failed"
+    python3 $R/bench.py --config $w --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err || echo "bench $w failed"
+    echo "$w done: $(python3 -c "import json;j=json.load(open('$O/bench_$w.json'));print('%.3e photons/s'%j['value'], j['roofline']['kernel'])")"
+  done
+  # ... and each of them on the GENERAL kernels (what ran them until round 4) and on the round-4 place of their field, one launch each
+  ( for w in landsat119_gas landsat119_gas_7dir landsat119_irregular_7dir landsat119_brdfgrid_7dir; do
+      n=${N[$w]}; python3 $R/tools/run_case.py $w $n | tail -1; KERNEL=general python3 $R/tools/run_case.py $w $n | tail -1
+      case $w in *gas*) GRID=bricks KERNEL=general python3 $R/tools/run_case.py $w $n | tail -1;; esac
+    done
+    python3 $R/tools/run_case.py landsat119 50000000 | tail -1; python3 $R/tools/run_case.py landsat119_7dir 10000000 | tail -1 ) > $O/general_kernels.txt 2>&1; clean $O/general_kernels.txt
+  echo "evidence $TAG: general done";;
 loop)
   mkdir -p $O; cd $R
   ( for spec in "step16 1e5 1000" "step16 1e6 1000" "step32 1e6 1000" "radar640 1e6 100" "landsat36 1e6 100" "landsat119 1e6 50" "radar64_nadir 1e6 100" "landsat119_7dir 1e6 28"; do
       python3 tools/fused_timing.py $spec; I3RC_FUSED=0 python3 tools/fused_timing.py $spec; done ) > $O/fused_timing.txt 2>&1; clean $O/fused_timing.txt
-  ( for spec in "landsat36 1e6 100" "landsat119 1e6 50" "step16 1e6 300" "radar64_nadir 1e6 100" "landsat119_7dir 1e6 28"; do python3 tools/moments_timing.py $spec; done ) > $O/moments_timing.txt 2>&1; clean $O/moments_timing.txt
+  ( for spec in "landsat36 1e6 100" "landsat119 1e6 50" "step16 1e6 300" "radar64_nadir 1e6 100" "landsat119_7dir 1e6 28" "step16 1e3 20000"; do python3 tools/moments_timing.py $spec; done ) > $O/moments_timing.txt 2>&1; clean $O/moments_timing.txt
   ( python3 tools/lookahead_timing.py step16 1e6 1000; python3 tools/lookahead_timing.py step32 1e6 1000; python3 tools/lookahead_timing.py landsat36 1e6 200
     python3 tools/lookahead_timing.py radar64_nadir 1e6 200 ) > $O/lookahead_timing.txt 2>&1; clean $O/lookahead_timing.txt
   ( bash tools/driver_timing.sh; bash tools/driver_timing.sh ) > $O/driver_timing.txt 2>&1; clean $O/driver_timing.txt
@@ -48,7 +69,8 @@ loop)
   [ -x tools/microbench/atomic_rate ] && tools/microbench/atomic_rate > $O/atomic_rate.txt 2>&1
   echo "evidence $TAG: loop done";;
 collect)
-  for w in $WL; do
+  [ -f $O/general_kernels.txt ] && cp $O/general_kernels.txt $R/profiles/${TAG}_general_kernels.txt
+  for w in $WL $GL; do
     [ -f $O/bench_$w.json ] && cp $O/bench_$w.json $R/profiles/${TAG}_${w}_bench.json
     f=$(ls -t $O/stats_$w/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $R/profiles/${TAG}_${w}_kernel_stats.csv
     [ -f $O/pmc_$w/summary.txt ] && cp $O/pmc_$w/summary.txt $R/profiles/${TAG}_${w}_pmc_summary.txt
@@ -58,5 +80,5 @@ collect)
     [ -f $O/$f.txt ] && cp $O/$f.txt $R/profiles/${TAG}_$f.txt; done
   python3 $R/tools/pmc_to_json.py --collect $R/profiles/${TAG}_pmc.json $R/profiles/${TAG}_*_pmc_summary.txt > /dev/null
   ls -la --time-style=+%H:%M $R/profiles | grep " ${TAG}_";;
-*) echo "usage: tools/evidence_round.sh <tag> counters|loop|collect"; exit 2;;
+*) echo "usage: tools/evidence_round.sh <tag> counters|general|loop|collect"; exit 2;;
 esac

@@ -12,6 +12,21 @@ import re
 import sys
 
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _commit():
+    import subprocess
+
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+    except Exception:
+        return None
+
+
+COMMIT = _commit()   # (HEAD where the summaries were turned into the JSON: the build container; None on the GPU box, which has no .git)
+
+
 def summarise(out, workload):
     vals, photons = {}, 0
     for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
@@ -22,9 +37,15 @@ def summarise(out, workload):
                 vals["_VGPR"] = r["VGPR_Count"]; vals["_SGPR"] = r["SGPR_Count"]; vals["_LDS"] = r["LDS_Block_Size"]
                 vals["_kernel"] = re.sub(r"^void i3rc::", "", r["Kernel_Name"]).split("(")[0]
     for f in glob.glob(os.path.join(out, "p*.out")):
-        m = re.search(r"ms, (\d+) photons\)", open(f).read())
+        t = open(f).read()
+        m = re.search(r"ms, (\d+) photons\)", t)
         if m:
             photons = int(m.group(1))
+        # what the profiled launch did, in the kernel's own words (tools/run_case.py's line): its name and its work per photon --
+        # bench.py holds its own run against these, so that counters of another kernel or another workload do not pass as this one's
+        m = re.search(r"kernel (photon_kernel<[^>]*>) S=([\d.]+) K=([\d.]+)", t)
+        if m:
+            vals["_launch"] = m.group(1); vals["_S"] = m.group(2); vals["_K"] = m.group(3)
     with open(os.path.join(out, "summary.txt"), "w") as o:
         o.write(f"# workload {workload} photons {photons}\n")
         for k in sorted(vals):
@@ -45,7 +66,10 @@ def collect(dst, files):
                 v[k] = float(x)
             except ValueError:
                 v[k] = x
-        e = {"photons": n, "kernel": v.get("_kernel"), "summary": f}
+        e = {"photons": n, "kernel": v.get("_kernel"), "summary": os.path.relpath(f, ROOT) if os.path.isabs(f) else f}
+        if "_launch" in v:
+            e["launch"] = v["_launch"]; e["work_per_photon"] = {"S": float(v["_S"]), "K": float(v["_K"])}
+        e["collected_at_commit"] = COMMIT
         if "SQ_INSTS_VALU" in v:
             e["valu_instr_per_photon"] = v["SQ_INSTS_VALU"] / n
             e["salu_instr_per_photon"] = v.get("SQ_INSTS_SALU", 0) / n
