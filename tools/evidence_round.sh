@@ -45,11 +45,12 @@ general)
     echo "$w done: $(python3 -c "import json;j=json.load(open('$O/bench_$w.json'));print('%.3e photons/s'%j['value'], j['roofline']['kernel'])")"
   done
   # ... and each of them on the GENERAL kernels (what ran them until round 4) and on the round-4 place of their field, one launch each
-  ( for w in landsat119_gas landsat119_gas_7dir landsat119_irregular_7dir landsat119_brdfgrid_7dir; do
+  ( export REPEAT=3
+    for w in landsat119_gas landsat119_gas_7dir landsat119_irregular_7dir landsat119_brdfgrid_7dir; do
       n=${N[$w]}; python3 $R/tools/run_case.py $w $n | tail -1; KERNEL=general python3 $R/tools/run_case.py $w $n | tail -1
       case $w in *gas*) GRID=bricks KERNEL=general python3 $R/tools/run_case.py $w $n | tail -1;; esac
     done
-    python3 $R/tools/run_case.py landsat119 50000000 | tail -1; python3 $R/tools/run_case.py landsat119_7dir 10000000 | tail -1 ) > $O/general_kernels.txt 2>&1; clean $O/general_kernels.txt
+    python3 $R/tools/run_case.py landsat119 50000000 | tail -1; python3 $R/tools/run_case.py landsat119_7dir 10000000 | tail -1 ) > $O/general_kernels.txt 2>&1; clean $O/general_kernels.txt   # (REPEAT=3: the last of three launches, not a process's first)
   echo "evidence $TAG: general done";;
 loop)
   mkdir -p $O; cd $R
