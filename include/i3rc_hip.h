@@ -173,7 +173,7 @@ int i3rc_hip_launch_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1
  *     what a launch of its own gives.  Radiance kernels have no register for that: photons and dropped photons (what the
  *     normalisation needs) are exact per batch, their other counters (steps, scatterings, ray starts ...) are counted per
  *     wavefront and handed to the batch the wavefront was given last -- exact over the batches of a group, not per batch.
- *     The TALLIES are per batch in every case.  Timings: profiles/r04_fused_timing.txt (step cloud, radar and Landsat fields,
+ *     The TALLIES are per batch in every case.  Timings: profiles/r05_fused_timing.txt (step cloud, radar and Landsat fields,
  *     with and without radiances, against one launch per batch).
  *   - otherwise up to inFlight batches (1..8; 0 = 6) are on the device at a time, each a launch on a HIP stream of its
  *     own with its own tally buffer (GPU_MAX_HW_QUEUES=8 in the environment gives these another 10-15 %).
@@ -224,7 +224,7 @@ int i3rc_hip_run_batches_moments(i3rc_hip_integrator *h, uint32_t seed0, uint32_
  * not recorded in i3rc_hip_kernel_ms_history.  A loop that is only guessed at keeps each of its three slots within 96 MiB of
  * pinned memory (groups of a Landsat-sized field then hold 18 batches); a group that cannot be launched for want of memory is
  * not tried again at every call -- such a loop goes on with single batches launched ahead.  The unchanged reference driver
- * end to end: profiles/r04_driver_timing.txt.  Directional sources only.  Synchronous. */
+ * end to end: profiles/r05_driver_timing.txt.  Directional sources only.  Synchronous. */
 int i3rc_hip_compute_batch(i3rc_hip_integrator *h, uint32_t seed0, uint32_t seed1, int64_t nPhotons,
                            const i3rc_source *src, int lookAhead, double *hostTallies);
 

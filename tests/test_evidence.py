@@ -37,7 +37,18 @@ def test_design_evidence_tables_quote_what_the_profiles_hold():
     for what, values, path in rows:
         full = os.path.join(ROOT, path)
         assert os.path.exists(full), (what, path)
-        numbers = [float(t) for t in NUM.findall(open(full).read())]
+        text = open(full).read()
+        if path.endswith("_pmc.json"):
+            # one file, every workload's counters: a row must say WHOSE figures it quotes -- `workload` in its first cell -- and only that
+            # workload's entry is searched (round 4's DESIGN.md printed the step cloud's figures in the Landsat row and this test, which
+            # then accepted any number anywhere in the file, could not see it)
+            import json
+
+            j = json.loads(text)
+            named = [k for k in j if f"`{k}`" in what]
+            assert len(named) == 1, ("a row that cites a *_pmc.json names its workload as `key` in its first cell", what, sorted(j))
+            text = json.dumps(j[named[0]])
+        numbers = [float(t) for t in NUM.findall(text)]
         for cell in values:
             for tok in NUM.findall(cell):
                 s = _sig(tok)

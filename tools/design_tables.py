@@ -1,10 +1,10 @@
 """Rewrites the value cells of DESIGN.md's evidence tables (section 6 / 7) from the files under profiles/ that the rows cite, so that
 a new evidence round (tools/evidence_round.sh <tag> counters | loop | collect) reaches the document without retyping:
-    python3 tools/design_tables.py [tag]         (default r04; prints the rows it changed)
+    python3 tools/design_tables.py [tag]         (default r05; prints the rows it changed)
 A row is found by the beginning of its first cell; rows this script does not know are left alone (tests/test_evidence.py checks all)."""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 P = lambda name: os.path.join(ROOT, "profiles", f"{TAG}_{name}")
 J = lambda w: json.load(open(P(f"{w}_bench.json")))
 pmc = json.load(open(P("pmc.json")))
@@ -40,17 +40,17 @@ def bench_rows():
     rows["… kernel time per launch, HIP events, ms"] = [["%.2f" % s["roofline"]["kernel_ms_avg"]], ["%.1f" % r["roofline"]["kernel_ms_avg"]]]
     rows["… rocprofv3 kernel average over 6 calls, ns"] = [[e(kernel_avg_ns("step16"))], [e(kernel_avg_ns("radar64_nadir"))]]
     rows["… `roofline.frac` (kernel's own work = the reference's)"] = ["%.3f" % s["roofline"]["frac"]]
-    rows["… vector instructions per photon; lane occupancy |"] = ["%.1f; %.3f" % (pmc["step16"]["valu_instr_per_photon"], pmc["step16"]["lane_occupancy"])]
-    rows["… HBM bytes per photon (2·FETCH + WRITE)"] = ["%.3f" % pmc["step16"]["hbm_bytes_per_photon"]]
+    rows["… `step16`: vector instructions per photon; lane occupancy"] = ["%.1f; %.3f" % (pmc["step16"]["valu_instr_per_photon"], pmc["step16"]["lane_occupancy"])]
+    rows["… `step16`: HBM bytes per photon (2·FETCH + WRITE)"] = ["%.3f" % pmc["step16"]["hbm_bytes_per_photon"]]
     rows["… CPU port on the box's 16 cores, photons/s"] = [e(s["cpu_baseline"]["value"])]
     rows["radar-64 64×64×54 + nadir radiance, 1e8 photons (configs[2]): photons/s"] = [e(r["value"])]
     rows["… `roofline.frac`; with the reference algorithm's work |"] = [["%.3f; %.3f" % (r["roofline"]["frac"], r["roofline"]["reference_equivalent"]["frac"])],
                                                                      ["%.3f; %.3f" % (l7["roofline"]["frac"], l7["roofline"]["reference_equivalent"]["frac"])]]
-    rows["… vector instructions per photon; scalar; lane occupancy"] = ["%.1f; %.1f; %.3f" % (pmc["radar64_nadir"]["valu_instr_per_photon"], pmc["radar64_nadir"]["salu_instr_per_photon"], pmc["radar64_nadir"]["lane_occupancy"])]
+    rows["… `radar64_nadir`: vector instructions per photon; scalar; lane occupancy"] = ["%.1f; %.1f; %.3f" % (pmc["radar64_nadir"]["valu_instr_per_photon"], pmc["radar64_nadir"]["salu_instr_per_photon"], pmc["radar64_nadir"]["lane_occupancy"])]
     rows["Landsat 128×128×36 flux, 1.25e8 photons (configs[3] per GPU"] = [e(l3["value"])]
     rows["… `roofline.frac`; vector instructions per photon; lane occupancy"] = ["%.3f; %.1f; %.3f" % (l3["roofline"]["frac"], l3["roofline"]["issue"]["valu_instr_per_photon"], l3["roofline"]["issue"]["lane_occupancy"])]
     rows["Landsat 128×128×119 + 7 directions + surface, 1.25e8 photons (configs[4] per GPU"] = [e(l7["value"])]
-    rows["… vector instructions per photon; lane occupancy; HBM bytes per photon"] = ["%.0f; %.3f; %.1f" % (pmc["landsat119_7dir"]["valu_instr_per_photon"], pmc["landsat119_7dir"]["lane_occupancy"], pmc["landsat119_7dir"]["hbm_bytes_per_photon"])]
+    rows["… `landsat119_7dir`: vector instructions per photon; lane occupancy; HBM bytes per photon"] = ["%.0f; %.3f; %.1f" % (pmc["landsat119_7dir"]["valu_instr_per_photon"], pmc["landsat119_7dir"]["lane_occupancy"], pmc["landsat119_7dir"]["hbm_bytes_per_photon"])]
 
 
 def config_rows():
