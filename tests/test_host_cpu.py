@@ -30,7 +30,7 @@ def test_cabi_library_exports_every_declared_symbol():
     # process layer (include/i3rc_comm.h)
     comm = ctypes.CDLL(M.build.build_comm())
     cdecl = sorted(set(re.findall(r"\b(i3rc_comm_[a-z_]+)\s*\(", open(os.path.join(ROOT, "include", "i3rc_comm.h")).read())))
-    assert len(cdecl) == 6
+    assert len(cdecl) == 7
     for name in cdecl:
         assert hasattr(comm, name), name
 
