@@ -61,6 +61,18 @@ for seed in range(first, first + count):
         d = cases.column_clouds(seed=seed, nx=int(aux.integers(1, 12)), ny=int(aux.integers(1, 8)), nz=int(aux.integers(1, 14)), ssa=float(aux.choice([1.0, 0.95, 0.5])))
         tab = hg_table(float(aux.choice([0.0, 0.85, 0.95])), 64)
     places = [str(aux.choice(["auto", "auto", "linear", "bricks", "columns"])) for _ in range(2)]
+    # (round 5) from a third stream: one seed in eight traces column clouds OVER A GAS (two components whose sum has column records over a
+    # base profile), and the second schedule of every configuration runs the GENERAL kernels one time in three -- the widened-class
+    # kernels (several components, irregular x / y, gridded surface) must trace the general kernels' photons: the counters say
+    aux5 = np.random.default_rng(seed + 9_000_011)
+    unequal_columns = kind == "irregular"
+    if not big and kind != "two" and aux5.random() < 0.125:
+        kind = "two"; unequal_columns = True   # (column_clouds is irregularly spaced: column means do not add up to the energy)
+        c = cases.column_clouds(seed=seed, nx=int(aux5.integers(1, 12)), ny=int(aux5.integers(1, 8)), nz=int(aux5.integers(2, 14)), ssa=float(aux5.choice([1.0, 0.95])))
+        gas = np.broadcast_to(np.linspace(float(aux5.choice([3.0e-3, 2.0e-5])), 1.0e-5, c["ext"].shape[0], dtype=np.float32)[:, None, None], c["ext"].shape).copy()
+        d = dict(c, ext=[c["ext"], gas], ssa=[c["ssa"], np.full_like(gas, np.float32(aux5.choice([1.0, 0.8])))], pf=[c["pf"], np.ones(gas.shape, np.int32)])
+        tab = [hg_table(0.85, 64), t_gas]
+    second_kernel = "general" if aux5.random() < 0.34 else "auto"
     p = {}
     if rng.random() < 0.4: p["useRayTracing"] = False
     if rng.random() < 0.3: p["useRussianRoulette"] = False
@@ -156,6 +168,7 @@ for seed in range(first, first + count):
         except M.I3RCError as e:
             note("   rejected:", e); res = None; break
         g.set_tuning(**tune)
+        if len(res) == 1: g.set_tuning(tune["evThreshold"], tune.get("blocksPerCU", 0), kernel=second_kernel, lightThreshold=tune.get("lightThreshold"))
         g.select_grid_place(place if place != "columns" or g.has_column_records() else "linear")
         src = M.PhotonStream(arrays=arr) if explicit else M.new_PhotonStream(mu0, az, n)
         r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((seed, 1)), src)
@@ -185,7 +198,7 @@ for seed in range(first, first + count):
     if nd and not np.isfinite(r["intensity"]).all(): problems.append("non-finite radiance")
     drop = c0["dropped"] / n
     # (column means add up to the photons' energy on grids of equal columns only: not on the irregular ones)
-    if kind != "irregular" and "surfaceAlbedo" in p and p.get("useRussianRoulette", True) is False and abs(tot + drop - 1.0) > 0.02 + 3.0 / np.sqrt(n):
+    if not unequal_columns and "surfaceAlbedo" in p and p.get("useRussianRoulette", True) is False and abs(tot + drop - 1.0) > 0.02 + 3.0 / np.sqrt(n):
         problems.append(("energy", tot, drop))
     if os.environ.get("ORACLE") == "1" and not explicit and "surfaceBDRF" not in p:
         # domain-mean fluxes against the CPU oracle (its own MT19937 stream: 5 sigma of the two samples)
@@ -202,7 +215,7 @@ for seed in range(first, first + count):
             a, b = float(r[k].mean()), float(ro[k].mean())
             # (crude standard errors: binomial-like, widened where the tallies are heavy-tailed -- irregular columns, and
             # the downward flux over a bright surface, which counts every one of a photon's surface hits)
-            tol = 5.0 * np.sqrt(max(a, b, 0.02) * (1.0 / n + 1.0 / m)) * (3.0 if kind == "irregular" else 1.0) + 1e-3
+            tol = 5.0 * np.sqrt(max(a, b, 0.02) * (1.0 / n + 1.0 / m)) * (3.0 if unequal_columns else 1.0) + 1e-3
             if k == "fluxDown" and p.get("surfaceAlbedo", 0.0) > 0.5: tol *= 4.0
             if abs(a - b) > tol: problems.append(("oracle", k, a, b, tol))
     note("   ok" if not problems else "   PROBLEM", problems, "up %.4f down %.4f abs %.4f dropped %.4f" % (r["fluxUp"].mean(), r["fluxDown"].mean(), r["fluxAbsorbed"].mean(), drop))

@@ -24,6 +24,13 @@ PLAN = {
     "landsat36": (100, 1_000_000, 8, 250_000),       # 1e8 / 3.2e7 (~9 s)
     "landsat36_absorbing": (100, 1_000_000, 8, 250_000),   # omega = 0.99 in the cloudy cells: absorption tallies, the shared-omega argument
     "landsat119_7dir": (100, 250_000, 8, 40_000),    # 2.5e7 / 5.1e6 (~20 s)
+    # (round 5) beyond the common class: two components (general flux kernel / widened-class radiance kernels, column records over a base
+    # profile), an irregular x / y grid, a gridded surface
+    "landsat36_gas_absorbing": (100, 1_000_000, 8, 200_000),
+    "landsat119_gas": (100, 1_000_000, 8, 150_000),
+    "landsat119_gas_7dir": (100, 250_000, 8, 30_000),
+    "landsat119_irregular_7dir": (100, 250_000, 8, 40_000),
+    "landsat119_brdfgrid_7dir": (100, 250_000, 8, 40_000),
 }
 # (round 4) per-column fields of every workload (the oracle child saves them whatever the size of the domain), and config 4 also
 # against the oracle's committed fixture of 2.4e7 photons (tests/golden/config4_columns.npz), with 1e8 photons on the GPU
