@@ -3,7 +3,7 @@
 module CharacterUtils
   implicit none
   private
-  integer, parameter :: fieldWidth = 32
+  integer, parameter :: fieldWidth = 25   ! (the length of the reference's results, Code/characterUtils.f95:13: tests/test_ref_numerics.py)
   public :: CharToInt, IntToChar, CharToReal
 contains
   elemental function CharToInt(inputString)

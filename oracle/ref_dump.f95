@@ -1,9 +1,10 @@
-! oracle/ref_dump.f95 -- TEST INFRASTRUCTURE.  A caller, written for this repository, of three modules' public
-! procedures: numericUtilities (findIndex, computeLobattoTerms, computeGaussLegendreTerms, computeLegendrePolynomials)
-! and surfaceProperties (new_SurfaceDescription, computeSurfaceReflectance), with ErrorMessages underneath.
+! oracle/ref_dump.f95 -- TEST INFRASTRUCTURE.  A caller, written for this repository, of four modules' public
+! procedures: numericUtilities (findIndex, computeLobattoTerms, computeGaussLegendreTerms, computeLegendrePolynomials),
+! surfaceProperties (new_SurfaceDescription, computeSurfaceReflectance), ErrorMessages (the status object every procedure
+! of the boundary reports through) and CharacterUtils.
 !
 ! Linked against the REFERENCE's modules -- compiled unmodified and in place from /root/reference/Code/
-! {ErrorMessages,numericUtilities,surfaceProperties}.f95, the three modules of the path that need no netCDF -- it is
+! {ErrorMessages,numericUtilities,surfaceProperties,characterUtils}.f95, the modules of the path and its boundary that need no netCDF -- it is
 ! oracle/_ref/ref_dump (oracle/Makefile, target _ref; build container only) and writes what tests/golden/ref_numerics.npz
 ! holds (tests/golden/make_ref_numerics.py).  Linked against the shell's modules of the same names it is
 ! fortran/build/shellNumericsDump, whose output the tests hold against that fixture bit for bit.
@@ -16,10 +17,15 @@
 !   legendre maxL m      mus(m)                                                   -> P(0:maxL, m), l fastest
 !   surface nx ny m      xPosition(nx+1), yPosition(ny+1), R(nx, ny) x fastest, x(m), y(m)  -> status, reflectance(m)
 !   uniform m            R, x(m), y(m)                                             -> status, reflectance(m)
+!   errors k             k lines "X text": X = S / W / F (setStateTo... with the text), s / w / f (without a text), C / c
+!                        (setStateToCompleteSuccess), I (initializeState)      -> after each: "isSuccess isWarning isFailure n" and the
+!                        n messages of the history (firstMessage ... moreMessagesExist), in brackets; the limits; "end"
+!   chars k              k lines "I integer" / "C string" / "R string"          -> [IntToChar] and its len / CharToInt / CharToReal's bits; "end"
 program refDump
   use ErrorMessages
   use numericUtilities
   use surfaceProperties
+  use CharacterUtils
   implicit none
   character(len = 32)  :: command
   character(len = 256) :: line
@@ -37,6 +43,8 @@ program refDump
       case("legendre");  call dumpLegendre
       case("surface");   call dumpSurface(.false.)
       case("uniform");   call dumpSurface(.true.)
+      case("errors");    call dumpErrors
+      case("chars");     call dumpChars
       case default
         write(*, '(a)') "unknown " // trim(command)
         stop 2
@@ -148,4 +156,63 @@ contains
     call writeReals(refl)
     deallocate(xPos, yPos, flat, params, x, y, refl)
   end subroutine dumpSurface
+
+  subroutine dumpErrors
+    integer :: k, i, n, maxN, maxLen
+    character(len = 400) :: op
+    type(ErrorMessage)   :: status
+    read(line, *) command, k
+    write(*, '(a)') "errors"
+    do i = 1, k
+      read(*, '(a)') op
+      select case(op(1:1))
+        case("S"); call setStateToSuccess(status, trim(op(3:)))
+        case("W"); call setStateToWarning(status, trim(op(3:)))
+        case("F"); call setStateToFailure(status, trim(op(3:)))
+        case("C"); call setStateToCompleteSuccess(status, trim(op(3:)))
+        case("s"); call setStateToSuccess(status)
+        case("w"); call setStateToWarning(status)
+        case("f"); call setStateToFailure(status)
+        case("c"); call setStateToCompleteSuccess(status)
+        case("I"); call initializeState(status)
+      end select
+      write(*, '(3(i0, 1x))', advance = "no") merge(1, 0, stateIsSuccess(status)), merge(1, 0, stateIsWarning(status)), merge(1, 0, stateIsFailure(status))
+      ! the history, as a driver prints it (UserInterface's printStatus: firstMessage ... moreMessagesExist)
+      n = 0
+      call firstMessage(status)
+      do
+        if(.not. moreMessagesExist(status)) exit
+        n = n + 1
+        call nextMessage(status)
+      end do
+      write(*, '(i0)') n
+      call firstMessage(status)
+      do
+        if(.not. moreMessagesExist(status)) exit
+        write(*, '(a)') "[" // trim(getCurrentMessage(status)) // "]"
+        call nextMessage(status)
+      end do
+    end do
+    call getErrorMessageLimits(status, maxNumberOfMessages = maxN, maxMessageLength = maxLen)
+    write(*, '(a, 1x, i0, 1x, i0)') "limits", maxN, maxLen
+    write(*, '(a)') "end"
+  end subroutine dumpErrors
+
+  subroutine dumpChars
+    integer :: k, i, v
+    character(len = 200) :: op
+    read(line, *) command, k
+    write(*, '(a)') "chars"
+    do i = 1, k
+      read(*, '(a)') op
+      select case(op(1:1))
+        case("I")
+          read(op(3:), *) v
+          write(*, '(a, 1x, i0)') "[" // trim(IntToChar(v)) // "]", len(IntToChar(v))
+        case("C"); write(*, '(i0)') CharToInt(trim(op(3:)))
+        case("R"); write(*, '(i0)') transfer(CharToReal(trim(op(3:))), 1)
+      end select
+    end do
+    write(*, '(a)') "end"
+  end subroutine dumpChars
 end program refDump

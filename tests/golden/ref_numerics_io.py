@@ -122,6 +122,15 @@ def cases():
     # the uniform surface new_SurfaceDescription((/ R /)): positions (/0, huge/) -- photons anywhere, also left of 0
     x = np.array([1.0, 250.0, 1e6, 1e30, -1.0, -250.0, -1e30, 3.0e38], dtype=F)
     out.append(dict(kind="uniform", name="0.2", R=np.array([0.2], dtype=F), x=x, y=x[::-1].copy()))
+    # -- ErrorMessages (the status object of the boundary) and CharacterUtils ----------------------------------------------------------
+    ops = ["S new_Domain: ok", "W getInfo: nothing to report", "f", "F computeRadiativeTransfer: no photons to process.", "s", "w",
+           "C all clear", "F again", "I", "S after initializeState", "c", "W a text with   inner   blanks and trailing   "]
+    ops += ["F " + "x" * 300]                                   # longer than a message can be (256)
+    ops += [f"F overflow {i}" for i in range(1, 106)]           # more than the history holds (100): the last slot is overwritten
+    ops += ["S the one after the overflow", "C cleared again"]
+    out.append(dict(kind="errors", name="history", ops=np.array(ops)))
+    cops = [f"I {v}" for v in (0, 7, -7, 42, 2147483647, -2147483647, 1000000)] + ["C 17", "C   -3  ", "C 0", "R 2.5", "R   -1.e-3", "R 100", "R 0.85"]
+    out.append(dict(kind="chars", name="conversions", ops=np.array(cops)))
     return out
 
 
@@ -148,6 +157,8 @@ def script(cs):
                      _ints(bits(c["R"])) + _ints(bits(c["x"])) + _ints(bits(c["y"])))
         elif k == "uniform":
             s.append(f"uniform {len(c['x'])}\n" + _ints(bits(c["R"])) + _ints(bits(c["x"])) + _ints(bits(c["y"])))
+        elif k in ("errors", "chars"):
+            s.append(f"{k} {len(c['ops'])}\n" + "".join(str(o) + "\n" for o in c["ops"]))
         else:
             raise ValueError(k)
     return "".join(s)
@@ -160,6 +171,11 @@ def parse(text, cs):
     for c in cs:
         head = lines[at].split()
         assert head[0] == c["kind"], (head, c["kind"], c["name"])
+        if c["kind"] in ("errors", "chars"):   # text: every line up to "end"
+            end = lines.index("end", at)
+            res.append(dict(lines=np.array(lines[at + 1:end])))
+            at = end + 1
+            continue
         n = int(head[1])
         v = np.array([int(x) for x in lines[at + 1:at + 1 + n]], dtype=np.int64)
         at += 1 + n
@@ -178,7 +194,7 @@ def parse(text, cs):
 
 
 INPUT_KEYS = {"findIndex": ("table", "values", "guess"), "lobatto": ("n",), "gauss": ("n",), "legendre": ("maxL", "mus"),
-              "surface": ("xs", "ys", "R", "x", "y"), "uniform": ("R", "x", "y")}
+              "surface": ("xs", "ys", "R", "x", "y"), "uniform": ("R", "x", "y"), "errors": ("ops",), "chars": ("ops",)}
 
 
 def save(path, cs, results, header):

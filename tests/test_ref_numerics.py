@@ -1,4 +1,5 @@
-"""The oracle, the shell and the host mirror against THE REFERENCE ITSELF, bit for bit.
+"""The oracle, the shell and the host mirror against THE REFERENCE ITSELF, bit for bit (and, for the status object and the string
+conversions of the boundary -- ErrorMessages, CharacterUtils --, line for line).
 
 tests/golden/ref_numerics.npz holds the answers of the reference's own numericUtilities / surfaceProperties -- the three
 netCDF-free modules of the hot path, compiled unmodified and in place (oracle/Makefile, target _ref; the generator is
@@ -53,6 +54,11 @@ def test_the_fixture_covers_what_it_says(ref):
     s = [c for c in cs if c["kind"] == "surface" and c["name"] == "grid4x3"][0]
     assert (s["x"] > s["xs"][-1]).any() and (s["x"] < s["xs"][0]).any() and (s["y"] > s["ys"][-1]).any() and (s["y"] < s["ys"][0]).any()
     assert [int(r["refused"]) for c, r in zip(cs, rs) if c["kind"] == "surface"] == [0, 0, 0, 1, 1]
+    # the status object of the boundary: a history that overflows (100 messages), a text longer than a message (256), every state
+    e = [(c, r) for c, r in zip(cs, rs) if c["kind"] == "errors"][0]
+    assert len(e[0]["ops"]) > 110 and "limits 100 256" in list(e[1]["lines"]) and sum(l.startswith("[overflow") for l in e[1]["lines"]) > 3000
+    ch = [(c, r) for c, r in zip(cs, rs) if c["kind"] == "chars"][0]
+    assert list(ch[1]["lines"])[3] == "[42] 25"
 
 
 def test_oracle_find_index_equals_the_reference(ref):
