@@ -1247,7 +1247,8 @@ bool fusable(const i3rc_hip_integrator *h, int64_t nPhotons) {
   // domains keep one launch per batch, whose tail is a small part of a launch that long anyway)
   static const bool radianceOff = std::getenv("I3RC_FUSED_RADIANCE") && std::atoi(std::getenv("I3RC_FUSED_RADIANCE")) == 0;
   if (h->nDir > 0 && (radianceOff || kNestedBuild)) return false;
-  return common_class(h, 0) && h->kernelVariant != I3RC_KERNEL_GENERAL && nPhotons < ((int64_t)1 << 31) &&
+  // (round 5: the widened class too -- several components, an irregular x / y grid, a gridded surface: photon_kernel<PhiloxBatchStream, ..., MULTI>)
+  return (common_class(h, 0) || multi_class(h, 0)) && h->kernelVariant != I3RC_KERNEL_GENERAL && nPhotons < ((int64_t)1 << 31) &&
          h->layout.total * (int64_t)sizeof(double) <= ((int64_t)256 << 20);
 }
 
@@ -1340,14 +1341,23 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
   A.counterBlocks = (double *)g.counterBlocks.p;
   if ((uint64_t)count * R >= ((uint64_t)1 << 31)) return h->fail("fused launch: too many tally blocks");
   using Kernel = void (*)(DevProblem, RunArgs, int, int);
-  static const Kernel kernels[4] = {photon_kernel<PhiloxBatchStream, false, false, GRID_LDS>, photon_kernel<PhiloxBatchStream, false, false, GRID_GLOBAL>,
-                                    photon_kernel<PhiloxBatchStream, false, false, GRID_BRICKS>, photon_kernel<PhiloxBatchStream, false, false, GRID_COLUMNS>};
+  static const Kernel kernels[5] = {photon_kernel<PhiloxBatchStream, false, false, GRID_LDS>, photon_kernel<PhiloxBatchStream, false, false, GRID_GLOBAL>,
+                                    photon_kernel<PhiloxBatchStream, false, false, GRID_BRICKS>, photon_kernel<PhiloxBatchStream, false, false, GRID_COLUMNS>, nullptr};
   const int place = plan.place;
+  // the widened class (several components, irregular x / y, a gridded surface): its own fused kernels, flux ones too -- a driver's loop
+  // of 1e6-photon batches on Landsat-36 + gas then costs 1.1 ms per batch instead of 2.6 (profiles/r05_fused_wide.txt)
+  const bool wide = !common_class(h, 0);
+  static const Kernel wideKernels[3][5] = {
+      {photon_kernel<PhiloxBatchStream, false, false, GRID_LDS, false, false, true>, photon_kernel<PhiloxBatchStream, false, false, GRID_GLOBAL, false, false, true>, photon_kernel<PhiloxBatchStream, false, false, GRID_BRICKS, false, false, true>, photon_kernel<PhiloxBatchStream, false, false, GRID_COLUMNS, false, false, true>, photon_kernel<PhiloxBatchStream, false, false, GRID_COLBASE, false, false, true>},
+      {photon_kernel<PhiloxBatchStream, true, false, GRID_LDS, false, false, true>, photon_kernel<PhiloxBatchStream, true, false, GRID_GLOBAL, false, false, true>, photon_kernel<PhiloxBatchStream, true, false, GRID_BRICKS, false, false, true>, photon_kernel<PhiloxBatchStream, true, false, GRID_COLUMNS, false, false, true>, photon_kernel<PhiloxBatchStream, true, false, GRID_COLBASE, false, false, true>},
+      {photon_kernel<PhiloxBatchStream, true, false, GRID_LDS, false, true, true>, photon_kernel<PhiloxBatchStream, true, false, GRID_GLOBAL, false, true, true>, photon_kernel<PhiloxBatchStream, true, false, GRID_BRICKS, false, true, true>, photon_kernel<PhiloxBatchStream, true, false, GRID_COLUMNS, false, true, true>, photon_kernel<PhiloxBatchStream, true, false, GRID_COLBASE, false, true, true>}};
   // (the inverse table's cosines in LDS, workgroups of 1024 threads: as in launch(); these instantiations are planned for eight
   // waves per SIMD -- two workgroups per compute unit -- and pay for it with two vector registers in scratch)
   Kernel kern = kernels[place];
   int threads = 256;
   size_t ldsBytes = lds_bytes<PhiloxBatchStream>(h, plan, false);
+  if (wide) kern = wideKernels[plan.intensity ? (direct_rays(h) ? 2 : 1) : 0][place];
+  else
   if (plan.intensity) {   // radiance problems: through the event ring, or (one direction) without it -- as in launch()
     static const Kernel ring[4] = {photon_kernel<PhiloxBatchStream, true, false, GRID_LDS>, photon_kernel<PhiloxBatchStream, true, false, GRID_GLOBAL>,
                                    photon_kernel<PhiloxBatchStream, true, false, GRID_BRICKS>, photon_kernel<PhiloxBatchStream, true, false, GRID_COLUMNS>};
@@ -1357,7 +1367,7 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
   } else {
     static const bool tblOn = !(std::getenv("I3RC_TABLE_LDS") && std::atoi(std::getenv("I3RC_TABLE_LDS")) == 0);
     static const int tblPlaces = std::getenv("I3RC_FUSED_TABLE_LDS_PLACES") ? std::atoi(std::getenv("I3RC_FUSED_TABLE_LDS_PLACES")) : 11;   // (measured: Landsat-36 +13 %, radar 640 +12 %, step cloud +1.5 ... 3 % in the kernels' own time; on column records +1 ... 2.5 %)
-    if (tblOn && ((tblPlaces >> place) & 1) && place != GRID_BRICKS && (plan.P.uniformPf >= 1 || h->nInvEntries[0] == 1) &&
+    if (!wide && tblOn && ((tblPlaces >> place) & 1) && place != GRID_BRICKS && (plan.P.uniformPf >= 1 || h->nInvEntries[0] == 1) &&
         plan.ldsBytes + sizeof(float) * (size_t)plan.P.comp0.nInv <= 79 * 1024) {
       static const Kernel tbl[4] = {photon_kernel<PhiloxBatchStream, false, false, GRID_LDS, true>, photon_kernel<PhiloxBatchStream, false, false, GRID_GLOBAL, true>,
                                     nullptr, photon_kernel<PhiloxBatchStream, false, false, GRID_COLUMNS, true>};
@@ -1367,12 +1377,13 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
     }
   }
   if (ldsBytes > 160 * 1024 - 256) return h->fail("the launch needs more LDS than a compute unit has");
+  if (!kern) return h->fail("internal: no fused kernel for this problem at this place of the extinction field");
   const void *fn = (const void *)kern;
   {
     static const char *const placeName[5] = {"GRID_LDS", "GRID_GLOBAL", "GRID_BRICKS", "GRID_COLUMNS", "GRID_COLBASE"};
-    static thread_local char name[96];
-    std::snprintf(name, sizeof(name), "photon_kernel<PhiloxBatchStream, %s, false, %s%s>", plan.intensity ? "true" : "false", placeName[place],
-                  threads == 1024 ? ", table in LDS" : (plan.intensity && direct_rays(h) ? ", one direction" : ""));
+    static thread_local char name[112];
+    std::snprintf(name, sizeof(name), "photon_kernel<PhiloxBatchStream, %s, false, %s%s%s>", plan.intensity ? "true" : "false", placeName[place],
+                  threads == 1024 ? ", table in LDS" : (plan.intensity && direct_rays(h) ? ", one direction" : ""), wide ? ", wide" : "");
     h->lastKernelName = name;
   }
   int perCU = h->blocksPerCU;

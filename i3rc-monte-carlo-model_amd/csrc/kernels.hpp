@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(256) slab_fill_kernel(uint32_t seed0, uint32_t
 // tracing, no BRDF grid, Directional source -- as compiled out as in the one-component kernels; the deviates are drawn as the general
 // kernels draw them (the component's from the stream's cursor), so that a MULTI launch traces the general kernels' photons.
 template <class Rng, bool INTENSITY, bool GENERAL, int GRID, bool TBL = false, bool DIRECT = false, bool MULTI = false>
-__global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (MULTI ? I3RC_MULTI_WAVES : I3RC_RADIANCE_WAVES)) : ((GENERAL || GRID == GRID_BRICKS) ? I3RC_MIN_WAVES : ((Rng::kBatched && !TBL) ? I3RC_FUSED_WAVES : I3RC_FLUX_WAVES))) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
+__global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (MULTI ? I3RC_MULTI_WAVES : I3RC_RADIANCE_WAVES)) : ((GENERAL || GRID == GRID_BRICKS) ? I3RC_MIN_WAVES : ((Rng::kBatched && !TBL) ? (MULTI ? I3RC_FUSED_WAVES - 1 : I3RC_FUSED_WAVES) : I3RC_FLUX_WAVES))) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   {
@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
   constexpr bool REPLAY = Rng::kReplay;        // per-photon fates are recorded by i3rc_hip_run_replay only
   constexpr bool BATCHED = Rng::kBatched;      // fused multi-batch launch: every lane knows its photon's batch (rng.batch)
   static_assert(!BATCHED || !GENERAL, "fused multi-batch launches: specialised kernels");
-  static_assert(!MULTI || (INTENSITY && !GENERAL && !TBL && !BATCHED && !Rng::kReplay), "MULTI: a specialisation of the plain production radiance kernels");
+  static_assert(!MULTI || (!GENERAL && !TBL && !Rng::kReplay && (INTENSITY || BATCHED)), "MULTI: the widened class -- radiance kernels, and the fused flux kernels (plain flux launches of the class run the general flux kernel)");
   // Work counters of a fused launch.  Flux kernels: exact per batch, gathered per lane (below).  Radiance kernels have no
   // vector register to spare for that: their counters stay per WAVE and are handed to the batch whose photons the wave was
   // given last -- photons and dropped photons (what the normalisation needs) are exact per batch, the others over the group.

@@ -670,8 +670,23 @@ def test_fused_batches_equal_one_launch_per_batch():
                 ("Landsat field (bricks), two radiances", cases.landsat_cloud(ssa=0.98), dict(rri, intensityMus=[0.8, 0.3], intensityPhis=[90.0, 225.0], surfaceAlbedo=0.2), 0.5, [(15000, 3)]),
                 # (a ray carries its batch in 13 bits: a loop of more than 8192 tiny batches on a tiny domain is cut into groups within that)
                 ("one column, nadir radiance, 8300 batches of 33 photons", cases.plane_parallel(optical_depth=2.0, ssa=0.9), dict(rri, intensityMus=[1.0], intensityPhis=[0.0], surfaceAlbedo=0.3), 0.6, [(33, 8300)])]
-    for what, d, params, mu0, runs in problems:
-        g = make_gpu(d, hg_table(), **params)
+    # (round 5) ... and for the widened class: two components (flux: a fused kernel of its own where plain launches run the general flux
+    # kernel; radiances with and without the ring), column clouds over a gas (records over a base profile) on an irregular grid, a gridded surface
+    t2 = [M.PhaseFunctionTable([M.henyey_greenstein(0.85, 32), M.henyey_greenstein(0.6, 16)]),
+          M.PhaseFunctionTable([M.PhaseFunction(legendre=np.array([0.0, 0.1], np.float32))])]
+    cc = cases.column_clouds()
+    gas = np.broadcast_to(np.linspace(3.0e-3, 1.0e-4, cc["ext"].shape[0], dtype=np.float32)[:, None, None], cc["ext"].shape).copy()
+    colgas = dict(cc, ext=[cc["ext"], gas], ssa=[cc["ssa"], np.full_like(gas, f32(0.9))], pf=[cc["pf"], np.ones(gas.shape, np.int32)])
+    grid = M.new_SurfaceDescription(np.array([[0.1, 0.5], [0.3, 0.7]], np.float32), np.array([0.0, 250.0, 500.0], np.float32), np.array([0.0, 250.0, 500.0], np.float32))
+    problems += [("two components, flux (wide)", cases.two_component(), dict(surfaceAlbedo=0.3), 0.7, [(20000, 7), (50, 5), (777, 33)], t2),
+                 ("two components, two radiances (wide)", cases.two_component(), dict(rri, intensityMus=[1.0, 0.4], intensityPhis=[0.0, 100.0], surfaceAlbedo=0.3), 0.7, [(15000, 5)], t2),
+                 ("two components, one radiance (wide)", cases.two_component(), dict(rri, intensityMus=[0.8], intensityPhis=[200.0], surfaceAlbedo=0.2), 0.7, [(15000, 5), (60, 9)], t2),
+                 ("column clouds over a gas, irregular grid, flux (wide)", colgas, dict(surfaceAlbedo=0.2), 0.6, [(20000, 5)], [hg_table(), t2[1]]),
+                 ("column clouds over a gas, irregular grid, two radiances (wide)", colgas, dict(rri, intensityMus=[0.6, 1.0], intensityPhis=[20.0, 0.0], surfaceAlbedo=0.3), 0.6, [(15000, 4)], [hg_table(), t2[1]]),
+                 ("step cloud over a gridded surface, flux (wide)", cases.step_cloud(ssa=0.95, nlayers=8), dict(surfaceBDRF=grid), 0.7, [(20000, 6)], None),
+                 ("step cloud over a gridded surface, nadir radiance (wide)", cases.step_cloud(ssa=0.95, nlayers=8), dict(rri, surfaceBDRF=grid, intensityMus=[1.0], intensityPhis=[0.0]), 0.7, [(20000, 6)], None)]
+    for what, d, params, mu0, runs, *tabs in problems:
+        g = make_gpu(d, tabs[0] if tabs and tabs[0] is not None else hg_table(), **params)
         if "(bricks)" in what:
             g.select_grid_place("bricks")   # (the scene has column records, which AUTO would read)
         rad = g if "intensityMus" in params else None
@@ -681,7 +696,7 @@ def test_fused_batches_equal_one_launch_per_batch():
             assert "PhiloxStream" in g.kernel_name()
             g.set_batch_fusion(1)
             fused = g.computeRadiativeTransferBatches((5, 3), nb, mu0, 25.0, n)
-            assert "PhiloxBatchStream" in g.kernel_name(), g.kernel_name()
+            assert "PhiloxBatchStream" in g.kernel_name() and ("wide" in g.kernel_name()) == ("(wide)" in what), g.kernel_name()
             _same_batches(one, fused, (what, n, nb), rad)
             plain = g.computeRadiativeTransfer(M.new_RandomNumberSequence((5, 3 + nb - 1)), M.new_PhotonStream(mu0, 25.0, n))
             _same_batches([plain], [one[-1]], (what, n, nb, "plain call"))
@@ -827,9 +842,21 @@ def test_an_announced_loop_is_streamed_and_never_overshot():
         assert got["counters"]["photons"] == want["counters"]["photons"] == n
         assert_same_sums(_tallies_only(stream, got), _tallies_only(plain, want), want["counters"], directions=8, what=b)
         assert got["intensity"].mean() > 0
-    # a problem of the general kernels (a BRDF grid) is left to i3rc_hip_run_batches
-    stream.specifyParameters(surfaceBDRF=M.new_SurfaceDescription(np.array([[0.1, 0.3], [0.2, 0.4]], np.float32), np.array([0.0, 250.0, 500.0], np.float32),
-                                                                  np.array([0.0, 250.0, 500.0], np.float32)))
+    # a gridded surface is streamed too since round 5 (the widened class has fused kernels of its own) ...
+    for g in (plain, stream):
+        g.specifyParameters(surfaceBDRF=M.new_SurfaceDescription(np.array([[0.1, 0.3], [0.2, 0.4]], np.float32), np.array([0.0, 250.0, 500.0], np.float32),
+                                                                 np.array([0.0, 250.0, 500.0], np.float32)))
+        g._ensure_tables()
+    assert lib.i3rc_hip_expect_batches(stream._h, 21, 5, 6, n, C.byref(s), C.byref(acc)) == 0 and acc.value == 1
+    for b in range(6):
+        assert lib.i3rc_hip_compute_batch(stream._h, 21, 5 + b, n, C.byref(s), 3, raw.ctypes.data_as(B.dp)) == 0, lib.i3rc_hip_last_error(stream._h)
+        got = stream.finish(raw.copy())
+        assert "wide" in stream.kernel_name(), stream.kernel_name()
+        want = plain.computeRadiativeTransfer(M.new_RandomNumberSequence((21, 5 + b)), M.new_PhotonStream(0.7, 40.0, n))
+        assert got["counters"]["photons"] == want["counters"]["photons"] == n
+        assert_same_sums(_tallies_only(stream, got), _tallies_only(plain, want), want["counters"], directions=8, what=("gridded surface", b))
+    # ... a problem of the general kernels (max cross-section) is left to i3rc_hip_run_batches
+    stream.specifyParameters(useRayTracing=False)
     stream._ensure_tables()
     assert lib.i3rc_hip_expect_batches(stream._h, 21, 5, nb, n, C.byref(s), C.byref(acc)) == 0 and acc.value == 0
     plain.finalize_Integrator(); stream.finalize_Integrator()
