@@ -294,7 +294,8 @@ int i3rc_hip_set_light_threshold(i3rc_hip_integrator *h, int lanes);
 
 /* A Directional batch longer than this many photons is cut into several kernel launches over consecutive photon
  * ranges (same result: every photon has its own random stream).  0 = default, 2^22 photons per compute unit (about
- * 1e9 on an MI355X): workgroups keep partial sums in float32, which stops counting at 2^24. */
+ * 1e9 on an MI355X): the work counters a wave hands over are 32-bit (until round 4 also: workgroups kept partial sums in float32,
+ * which stops counting at 2^24; they are float64 now). */
 int i3rc_hip_set_launch_limit(i3rc_hip_integrator *h, int64_t photons);
 
 /* Fusion of a loop's batches (i3rc_hip_run_batches, the look-ahead of i3rc_hip_compute_batch): -1 = automatic (default:
