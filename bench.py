@@ -59,6 +59,8 @@ def parse_args():
                     help="N > 1: seconds every rank has for init_process_group and a first all-reduce before the run is called off (naming the rank)")
     ap.add_argument("--collective-timeout", type=float, default=float(os.environ.get("I3RC_BENCH_COLLECTIVE_TIMEOUT", "600")),
                     help="N > 1: the process group's timeout, which bounds every collective of the run (torch's default for NCCL: 600 s)")
+    ap.add_argument("--process-group", action="store_true", default=os.environ.get("I3RC_BENCH_PROCESS_GROUP") == "1",
+                    help="N = 1: initialise torch.distributed all the same (a one-rank world over RCCL) and run the N > 1 code paths through it")
     ap.add_argument("--contact-only", action="store_true", help="N > 1: stop after the first-contact check (process group up, one all-reduce on every rank)")
     ap.add_argument("--scale-photons", type=float, default=1.0,
                     help="test knob: scales the workload's photon counts (per GPU and per node), so that the default N > 1 mode -- configs 3 / 4 "
@@ -308,7 +310,10 @@ def worker(a):
         return 3
     torch.cuda.set_device(local_rank)
     dist = None
-    if n_gpus > 1:
+    # --process-group (or I3RC_BENCH_PROCESS_GROUP=1) at N = 1: bring the process group up all the same -- a world of ONE rank over RCCL --
+    # so that everything an N > 1 run does beside tracing (init_process_group on the device, the first-contact check, the all-reduce of
+    # every step, the gathers of the report) executes on the real backend of a one-GPU box: the two-rank RCCL tests need two GPUs
+    if n_gpus > 1 or a.process_group:
         import torch.distributed as dist
 
         import datetime

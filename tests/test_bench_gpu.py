@@ -135,3 +135,14 @@ def test_two_ranks_over_rccl(scaling):
     assert "cuda:0" in j["devices"][0] and "cuda:1" in j["devices"][1]
     assert j["config"]["photons_per_step"] == (2 * n if scaling == "weak" else n)
     assert abs(j["result_check"]["meanFluxUp"] - 0.3253) < 2e-3
+
+
+def test_one_rank_world_over_rccl():
+    # --process-group at N = 1: a world of ONE rank over RCCL -- init_process_group on the device, the first-contact check, one
+    # all-reduce (ncclAllReduce) of the packed float64 tally buffer per step, the gathers of the report: every line an N > 1 run
+    # executes beside tracing, on the real backend, on a one-GPU box (two ranks over RCCL need two GPUs: test_two_ranks_over_rccl)
+    j = _bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--photons", "2000000", "--no-cpu-baseline", "--process-group"])
+    assert j["backend"] == "nccl" and j["world_size"] == 1 and j["n_gpus"] == 1
+    assert j["config"]["photons_per_step"] == 2000000 and abs(j["result_check"]["meanFluxUp"] - 0.3253) < 2e-3
+    r = j["ranks"]["per_rank"]
+    assert len(r) == 1 and r[0]["rank"] == 0 and r[0]["kernel_ms_per_step"] > 0 and r[0]["allreduce_ms_per_step"] >= 0
