@@ -468,7 +468,7 @@ def worker(a):
     if counters["photons"] != float(check["total_per_step"]):
         sys.stderr.write(f"bench: inconsistent results (photons {counters['photons']:.0f}, expected {check['total_per_step']})\n")
         return 4
-    albedo = w.get("surface", 0.0)
+    albedo = w.get("surface", w.get("albedo", 0.0))
     if albedo == 0.0 and "surface_grid" not in w and not absorbing:
         closure = float(res["fluxUp"].mean() + res["fluxDown"].mean()) + counters["dropped"] / counters["photons"]
         if abs(closure - 1.0) > 1e-4:

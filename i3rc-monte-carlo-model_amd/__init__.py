@@ -8,5 +8,5 @@ from . import binding, build, host, multigpu, phasefunctions  # noqa: F401
 from .binding import I3RCError  # noqa: F401
 from .host import (Domain, Integrator, PhotonStream, RandomNumberSequence, SurfaceDescription,  # noqa: F401
                    new_Domain, new_Integrator, new_PhaseFunctionTable, new_PhotonStream,
-                   new_RandomNumberSequence, new_SurfaceDescription)
+                   new_RandomNumberSequence, new_SurfaceDescription, read_Domain)
 from .phasefunctions import PhaseFunction, PhaseFunctionTable, henyey_greenstein  # noqa: F401

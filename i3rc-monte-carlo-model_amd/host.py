@@ -20,7 +20,7 @@ import numpy as np
 
 from . import binding as B
 from .binding import I3RCError, f32, pf
-from .phasefunctions import PI_MCRT, PhaseFunctionTable, hybrid_phase_functions, spacing
+from .phasefunctions import PI_MCRT, PhaseFunction, PhaseFunctionTable, hybrid_phase_functions, spacing
 
 r32 = np.float32  # scalar float32 (f32() from the binding makes contiguous ARRAYS)
 
@@ -587,6 +587,38 @@ class Integrator:
 # Reference-style free functions ---------------------------------------------------------------------------
 def new_Domain(xPosition, yPosition, zPosition):
     return Domain(xPosition, yPosition, zPosition)
+
+
+def read_Domain(fileName):
+    """read_Domain (Code/opticalProperties.f95:708-871) and, per component, read_PhaseFunctionTable
+    (Code/scatteringPhaseFunctions.f95:928-1090): a domain file -- netCDF classic, the schema of SURVEY.md 8f row 1 --
+    into a Domain.  Arrays in the file are (z, y, x), a horizontally uniform component is (z); the storage type of a
+    component's table is "LegendreCoefficients" (start / length vectors into one coefficient vector) or "Angle-Value"."""
+    from scipy.io import netcdf_file
+
+    try:
+        f = netcdf_file(fileName, "r", mmap=False)
+    except (OSError, TypeError, ValueError) as e:
+        raise I3RCError(f"read_Domain: Can't open file {fileName}: {e}")
+    try:
+        var = lambda n: np.array(f.variables[n].data)   # noqa: E731
+        text = lambda a: (a.decode() if isinstance(a, bytes) else str(a)).strip()   # noqa: E731
+        d = Domain(var("x-Edges"), var("y-Edges"), var("z-Edges"))
+        for c in range(1, int(f.numberOfComponents) + 1):
+            pre = f"Component{c}_"
+            if text(getattr(f, pre + "phaseFunctionStorageType")) == "Angle-Value":
+                ang, val = var(pre + "scatteringAngle"), var(pre + "phaseFunctionValues")   # (entry, angle)
+                entries = [PhaseFunction(angles=ang, values=v) for v in val.reshape(-1, ang.size)]
+            else:
+                coef, start, length = var(pre + "legendreCoefficients"), var(pre + "start"), var(pre + "length")
+                entries = [PhaseFunction(legendre=coef[s - 1:s - 1 + n]) for s, n in zip(start, length)]
+            table = PhaseFunctionTable(entries, key=var(pre + "phaseFunctionKeyT"),
+                                       description=text(getattr(f, pre + "description", b"")))
+            d.addOpticalComponent(text(getattr(f, pre + "Name")), var(pre + "Extinction"), var(pre + "SingleScatteringAlbedo"),
+                                  var(pre + "PhaseFunctionIndex").astype(np.int32), table, zLevelBase=int(getattr(f, pre + "zLevelBase")))
+        return d
+    except (KeyError, AttributeError) as e:
+        raise I3RCError(f"read_Domain: {fileName} doesn't appear to be a domain file: {e}")
 
 
 def new_Integrator(atmosphere, device=0):

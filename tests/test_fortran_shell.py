@@ -213,6 +213,120 @@ def test_reference_drivers_link_unchanged(shell_built):
     assert not any(os.path.basename(t) in ("monteCarloDriver.f95", "planeParallel.f95") for t in tracked)
 
 
+def _domain_file_arrays(path):
+    """every variable and global attribute of a domain file (scipy's netCDF reader: independent of the shell's)"""
+    from scipy.io import netcdf_file
+
+    f = netcdf_file(path, "r", mmap=False)
+    return {k: np.array(v.data) for k, v in f.variables.items()}, {k: getattr(f, k) for k in f._attributes}
+
+
+def _same_variables(a, b, what):
+    va, vb = _domain_file_arrays(a)[0], _domain_file_arrays(b)[0]
+    assert sorted(va) == sorted(vb), (what, sorted(set(va) ^ set(vb)))
+    for k in va:
+        assert va[k].dtype == vb[k].dtype and va[k].shape == vb[k].shape, (what, k, va[k].shape, vb[k].shape)
+        assert np.array_equal(va[k].view(np.uint8), vb[k].view(np.uint8)), (what, k, int((va[k] != vb[k]).sum()))
+    return va
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="reference tree not present (GPU box)")
+def test_reference_case_generators_and_tools_run_unchanged_on_the_shell(shell_built, tmp_path):
+    """SURVEY.md 8f row 4, pinned by the reference's own programs: I3RC-Examples/i3rcStepCloud.f95, i3rcLandsatCloud.f95 and
+    Tools/OpticalPropertiesToDomain.f95, compiled unchanged and in place against the shell (`make linkcheck`), write domain files whose
+    every variable -- edges, extinction, single-scattering albedo, table index, Legendre coefficients, table keys -- equals BIT FOR
+    BIT what the shell's own tools (fortran/tools/*.f95, written from the case definitions and the importer's readme) write; the
+    files differ in two text attributes (the component's name and description).  The reference's inputs are read where they lie or
+    from the fixture's restatement of them; every output goes to the test's directory."""
+    r = _run(["make", "-C", FDIR, "linkcheck"])
+    assert r.returncode == 0 and "case generators and Tools compiled and linked unchanged" in r.stdout, r.stdout + r.stderr
+    data = tmp_path / "Data"          # (the generators read and write ./Data/: a directory of the test's own)
+    data.mkdir()
+    _write_i3rc_data_files(str(data))
+    for exe in ("i3rcStepCloud_ref", "i3rcLandsatCloud_ref"):
+        r = _run([os.path.join(shell_built, exe)], cwd=str(tmp_path))
+        assert r.returncode == 0, exe + r.stdout + r.stderr
+    for ref_name, tool, args in (("StepCloud_NonAbsorbing.opt", "makeStepCloudDomain", ["32", "1.0"]),
+                                 ("StepCloud_Absorbing.opt", "makeStepCloudDomain", ["32", "0.99"]),
+                                 ("LandsatCloud_NonAbsorbing.opt", "makeLandsatCloudDomain", [str(data), "1.0", "119"]),
+                                 ("LandsatCloud_Absorbing.opt", "makeLandsatCloudDomain", [str(data), "0.99", "119"])):
+        mine = str(tmp_path / ("shell_" + ref_name))
+        cmd = [os.path.join(shell_built, tool)] + ([mine] + args if tool == "makeStepCloudDomain" else [args[0], mine] + args[1:])
+        r = _run(cmd)
+        assert r.returncode == 0, r.stdout + r.stderr
+        v = _same_variables(str(data / ref_name), mine, ref_name)
+        assert v["Component1_Extinction"].shape == ((32, 1, 32) if "Step" in ref_name else (119, 128, 128))
+    # the importer, on the reference's own example: an LES stratocumulus field of 73 728 cells, 27 phase functions
+    prp = "/root/reference/Tools/Examples/les_stcu_w213.prp"
+    for who, exe in (("ref", "OpticalPropertiesToDomain_ref"), ("shell", "opticalPropertiesToDomain")):
+        nml = tmp_path / f"{who}.nml"
+        nml.write_text(f"&fileNames\n PropFileName = '{prp}',\n outputFileName = '{tmp_path}/{who}_les.dom'\n/\n")
+        r = _run([os.path.join(shell_built, exe), str(nml)], cwd=str(tmp_path))
+        assert r.returncode == 0, who + r.stdout + r.stderr
+    v = _same_variables(str(tmp_path / "ref_les.dom"), str(tmp_path / "shell_les.dom"), "les_stcu_w213")
+    assert v["Component1_Extinction"].shape == (18, 64, 64) and v["Component1_length"].shape == (27,)
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="reference tree not present (GPU box)")
+def test_reference_tool_chain_domains_are_the_committed_fixtures(shell_built):
+    """tests/golden/tools_*.dom.gz -- MakeMieTable -> PhysicalPropertiesToDomain, the reference's programs unchanged on the shell, on
+    the reference's example inputs (tests/golden/make_tool_domains.py) -- made again here: the same bytes."""
+    import gzip
+    import importlib.util
+    import tempfile
+
+    r = _run(["make", "-C", FDIR, "linkcheck"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    spec = importlib.util.spec_from_file_location("make_tool_domains", os.path.join(ROOT, "tests", "golden", "make_tool_domains.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with tempfile.TemporaryDirectory() as tmp:
+        files = mod.make(tmp)
+    for name, data in files.items():
+        assert gzip.decompress(open(os.path.join(ROOT, "tests", "golden", mod.OUT[name]), "rb").read()) == data, name
+
+
+def _tool_chain_domain(name, directory):
+    """one of tests/golden/tools_*.dom.gz unpacked into `directory`"""
+    import gzip
+
+    path = os.path.join(str(directory), name + ".dom")
+    with open(path, "wb") as f:
+        f.write(gzip.decompress(open(os.path.join(ROOT, "tests", "golden", f"tools_{name}.dom.gz"), "rb").read()))
+    return path
+
+
+def test_python_mirror_reads_domain_files(shell_built, tmp_path):
+    """read_Domain of the Python mirror (host.py; Code/opticalProperties.f95:708-871): a file the shell's generator wrote gives the
+    arrays of the numpy statement of the case; the tool-chain fixtures give their components -- three-dimensional and horizontally
+    uniform ones, level bases, tables of 35 entries with up to 1381 Legendre coefficients."""
+    import i3rc_monte_carlo_model_amd as M
+    from tools import cases
+
+    dom = str(tmp_path / "step.dom")
+    assert _run([os.path.join(shell_built, "makeStepCloudDomain"), dom, "16", "0.99"]).returncode == 0
+    d, want = M.read_Domain(dom), cases.step_cloud(ssa=0.99, nlayers=16)
+    c = d.components[0]
+    assert d.shape == (16, 1, 32) and len(d.components) == 1 and c["zbase"] == 1 and not c["uniform"]
+    assert np.array_equal(d.x, want["xe"]) and np.array_equal(d.z, want["ze"]) and np.array_equal(c["ext"], want["ext"])
+    assert np.array_equal(c["ssa"], want["ssa"]) and np.array_equal(c["pfi"], want["pf"])
+    assert c["table"].n_entries == 1 and np.array_equal(c["table"].entries[0].legendre, M.henyey_greenstein(0.85, 64).legendre)
+    les = M.read_Domain(_tool_chain_domain("les_stcu_rayleigh", tmp_path))
+    assert les.shape == (18, 64, 64) and [c["name"] for c in les.components] == ["Particle type 1", "Rayleigh scattering"]
+    cloud, gas = les.components
+    assert cloud["ext"].shape == (16, 64, 64) and cloud["zbase"] == 2 and cloud["table"].n_entries == 35
+    assert max(e.legendre.size for e in cloud["table"].entries) == 1381
+    assert gas["uniform"] and gas["ext"].shape == (18, 1, 1) and gas["zbase"] == 1 and np.all(gas["ssa"] == 1)
+    assert np.allclose(gas["table"].entries[0].legendre, [0.0, 0.1])                      # Rayleigh: 1 + P2 / 2
+    total, cum, ssa, pfi, tables = les.getOpticalPropertiesByComponent()
+    assert total.shape == (18, 64, 64) and np.all(total > 0) and np.all(cum[1] == 1) and len(tables) == 2
+    mix = M.read_Domain(_tool_chain_domain("mixture", tmp_path))
+    assert mix.shape == (11, 1, 1) and [c["ext"].shape[0] for c in mix.components] == [10, 10, 11]
+    assert np.all(mix.components[2]["ssa"] == 0)                                           # molecular absorption
+    with pytest.raises(M.I3RCError):
+        M.read_Domain(str(tmp_path / "no such file"))
+
+
 def _spawn_ranks(cmd, world, port, extra_env=None, cwd=None):
     procs = []
     for r in range(world):
@@ -276,6 +390,24 @@ def test_multiple_processes_module_over_rccl_one_rank():
     assert rcs == [0] and "rank 0 of 1 sums ok master=T" in outs[0], outs
 
 
+def same_to_the_printed_digits(a, b, what):
+    """two result files of the drivers, line by line: equal to the digits their formats print (see the caller's note)"""
+    assert len(a) == len(b), what
+    values = off = 0
+    for x, y in zip(a, b):
+        if x == y or "Property_File" in x:
+            continue
+        fx, fy = x.split(), y.split()
+        assert len(fx) == len(fy), (what, x, y)
+        assert not x.lstrip().startswith("!") or "Average" in x, (what, x, y)   # (header lines agree as text)
+        for u, v in zip(fx, fy):
+            if u != v:
+                assert abs(float(u) - float(v)) <= 1.0001e-4, (what, x, y)
+                off += 1
+    values = sum(len(x.split()) for x in a)
+    assert off <= max(1, values // 100), (what, off, values)
+
+
 @pytest.mark.gpu
 def test_reference_drivers_run_unchanged_on_gpu(tmp_path):
     pp = os.path.join(BUILD, "planeParallel_ref")
@@ -319,21 +451,6 @@ def test_reference_drivers_run_unchanged_on_gpu(tmp_path):
         # gathers its batch moments on the device in float64 (computeRadiativeTransferBatchMoments), the reference's driver adds
         # real(4) values one after the other: where a value lies within 1e-7 of a rounding boundary of F9.4 the last printed digit
         # may differ by one -- allowed for at most one value in a hundred, by one unit.
-        def same_to_the_printed_digits(a, b, what):
-            assert len(a) == len(b), what
-            values = off = 0
-            for x, y in zip(a, b):
-                if x == y or "Property_File" in x:
-                    continue
-                fx, fy = x.split(), y.split()
-                assert len(fx) == len(fy), (what, x, y)
-                assert not x.lstrip().startswith("!") or "Average" in x, (what, x, y)   # (header lines agree as text)
-                for u, v in zip(fx, fy):
-                    if u != v:
-                        assert abs(float(u) - float(v)) <= 1.0001e-4, (what, x, y)
-                        off += 1
-            values = sum(len(x.split()) for x in a)
-            assert off <= max(1, values // 100), (what, off, values)
         same_to_the_printed_digits(own_flux.splitlines()[9:], flux.splitlines()[9:], "flux")
         for name in ("rad", "absprof", "absvol"):   # whole files, headers included (Property_File differs by name only)
             a = open(str(out / f"own_{name}.txt")).read().splitlines()
@@ -423,6 +540,62 @@ def test_generated_case_domains_run_through_the_driver_on_gpu(tmp_path):
     # solarFlux = 1 and the same photons: the means agree to the 4 decimals the flux file prints
     assert abs(fup - np.mean(ups)) < 2e-4 and abs(fdn - np.mean(dns)) < 2e-4 and abs(fab - np.mean(abss)) < 2e-4
     assert abs(eup - np.std(ups, ddof=1) / np.sqrt(10)) < 2e-4
+
+
+@pytest.mark.gpu
+def test_reference_tool_chain_domain_through_the_drivers_on_gpu(tmp_path):
+    """What a user of the reference's tools hands to the drivers: the LES stratocumulus field + Rayleigh scattering that the
+    reference's MakeMieTable and PhysicalPropertiesToDomain wrote (tests/golden/tools_les_stcu_rayleigh.dom.gz: two components, a Mie
+    table of 35 entries with up to 1381 Legendre coefficients, irregular layers) -- read_Domain, tables, ten batches with two radiance
+    directions over a Lambertian surface -- through the shell's driver, through the reference's unchanged monteCarloDriver where it
+    was built, and through the Python mirror on the same seeds (each side reads the file and makes its own tables)."""
+    import i3rc_monte_carlo_model_amd as M
+
+    drv = _need(os.path.join(BUILD, "i3rcDriver"))
+    dom = _tool_chain_domain("les_stcu_rayleigh", tmp_path)
+    deck = """&radiativeTransfer
+  solarFlux = 1., solarMu = 0.5, solarAzimuth = 20., surfaceAlbedo = 0.06, intensityMus = 1., 0.6, intensityPhis = 0., 135. /
+&monteCarlo
+  numPhotonsPerBatch = 100000, numBatches = 10, iseed = 21, nPhaseIntervals = 10001 /
+&algorithms
+  useRayTracing = .true., useRussianRoulette = .true., useRussianRouletteForIntensity = .true., zetaMin = 0.3 /
+&output
+  reportVolumeAbsorption = .false., reportAbsorptionProfile = .true. /
+&fileNames
+  domainFileName = "%s", outputFluxFile = "%s/WHO_flux.txt", outputRadFile = "%s/WHO_rad.txt", outputAbsProfFile = "%s/WHO_prof.txt" /
+""" % (dom, tmp_path, tmp_path, tmp_path)
+    (tmp_path / "own.nml").write_text(deck.replace("WHO", "own"))
+    r = _run([drv, str(tmp_path / "own.nml")], cwd=ROOT)
+    assert r.returncode == 0 and "Wrote ASCII results" in r.stdout, r.stdout + r.stderr
+    flux = open(str(tmp_path / "own_flux.txt")).read()
+    m = re.search(r"Average:\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)", flux)
+    fup, eup, fdn, edn, fab, eab = map(float, m.groups())
+    assert 0.2 < fup < 0.9 and abs(fup + fab + fdn * (1 - 0.06) - 1.0) < 2e-3       # what comes in goes out or is absorbed (surface included)
+    mc = os.path.join(BUILD, "monteCarloDriver_ref")
+    if os.path.exists(mc):   # the reference's own driver, unchanged, on the same deck: the same photons, the same files
+        (tmp_path / "ref.nml").write_text(deck.replace("WHO", "ref"))
+        r = _run([mc, str(tmp_path / "ref.nml")], cwd=ROOT)
+        assert r.returncode == 0 and "Wrote ASCII results" in r.stdout, r.stdout + r.stderr
+        for name in ("flux", "rad", "prof"):
+            a = open(str(tmp_path / f"own_{name}.txt")).read().splitlines()
+            b = open(str(tmp_path / f"ref_{name}.txt")).read().splitlines()
+            same_to_the_printed_digits(a[9:] if name == "flux" else a, b[9:] if name == "flux" else b, "tool-chain domain: " + name)
+    # the Python mirror on the file: its own read_Domain, its own tables, the driver's seeds
+    g = M.new_Integrator(M.read_Domain(dom))
+    g.specifyParameters(surfaceAlbedo=0.06, minInverseTableSize=10001, intensityMus=[1.0, 0.6], intensityPhis=[0.0, 135.0],
+                        useRussianRouletteForIntensity=True, zetaMin=0.3)
+    res = [g.computeRadiativeTransfer(M.new_RandomNumberSequence((21, b)), M.new_PhotonStream(0.5, 20.0, 100000)) for b in range(1, 11)]
+    assert "wide" in g.kernel_name(), g.kernel_name()     # several components, radiance: the widened class's kernels
+    ups, dns, abss = ([float(x[k].mean()) for x in res] for k in ("fluxUp", "fluxDown", "fluxAbsorbed"))
+    assert abs(fup - np.mean(ups)) < 2e-4 and abs(fdn - np.mean(dns)) < 2e-4 and abs(fab - np.mean(abss)) < 2e-4
+    assert abs(eup - np.std(ups, ddof=1) / np.sqrt(10)) < 2e-4
+    pixels = np.array([[float(v) for v in line.split()] for line in open(str(tmp_path / "own_rad.txt")).read().splitlines()
+                       if not line.lstrip().startswith("!")])                     # x, y, mean, standard error: 64 x 64 pixels per direction
+    assert pixels.shape == (2 * 64 * 64, 4)
+    for k in range(2):   # (the file prints four decimals per pixel: their mean over 4096 pixels is good to 1e-5)
+        want = np.mean([float(x["intensity"][k].mean()) for x in res])
+        assert abs(pixels[k * 4096:(k + 1) * 4096, 2].mean() - want) < 2e-4, (k, pixels[k * 4096:(k + 1) * 4096, 2].mean(), want)
+    g.finalize_Integrator()
 
 
 def test_photon_stream_constructors_equal_the_oracles_bit_for_bit(shell_built, oracle):

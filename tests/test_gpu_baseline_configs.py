@@ -308,6 +308,43 @@ def test_two_components_column_by_column_with_absorption(tmp_path):
     assert abs(kg - z["scatterings"].sum() / (n_ref * len(z["nBad"]))) < 0.01 * kg
 
 
+def test_tool_chain_les_stratocumulus_with_rayleigh_against_the_oracle(oracle, tmp_path):
+    """A production-style domain against the oracle: the LES stratocumulus field + Rayleigh scattering as the REFERENCE'S OWN
+    TOOLS wrote it (MakeMieTable -> PhysicalPropertiesToDomain on Tools/Examples, tests/golden/make_tool_domains.py): two
+    components -- cloud droplets with a Mie table of 35 effective radii (18 of them in use, up to 1381 Legendre coefficients: forward
+    peaks of 3e4), a horizontally uniform gas in 18 irregular layers --, two radiance directions, a Lambertian surface, sun at 60
+    degrees.  Both sides get the same tables; domain means of the fluxes and of each radiance direction within
+    3 sqrt(se_gpu^2 + se_ref^2), and the kernels are the widened class's."""
+    from tests.test_fortran_shell import _tool_chain_domain
+    dom = M.read_Domain(_tool_chain_domain("les_stcu_rayleigh", tmp_path))
+    nz, ny, nx = dom.shape
+
+    def full(c, key, dtype):   # a component's array on the whole grid (level base, horizontally uniform components)
+        a = np.zeros((nz, ny, nx), dtype)
+        z0 = c["zbase"] - 1
+        a[z0:z0 + c[key].shape[0]] = np.broadcast_to(c[key], (c[key].shape[0], ny, nx))
+        return a
+    d = dict(xe=dom.x, ye=dom.y, ze=dom.z, ext=[full(c, "ext", np.float32) for c in dom.components],
+             ssa=[full(c, "ssa", np.float32) for c in dom.components], pf=[full(c, "pfi", np.int32) for c in dom.components])
+    inv = [c["table"].inverse_table(10001) for c in dom.components]
+    fwd = [c["table"].forward_table(10001) for c in dom.components]
+    mus, phis = [1.0, 0.6], [0.0, 135.0]
+    g = M.new_Integrator(dom)
+    g.specifyParameters(surfaceAlbedo=0.06, minInverseTableSize=10001, intensityMus=mus, intensityPhis=phis,
+                        useRussianRouletteForIntensity=True, zetaMin=0.3)
+    for k in range(len(dom.components)):
+        g.set_tables(k + 1, inverse=inv[k], forward=fwd[k], forward_orig=fwd[k])
+    o = make_oracle(oracle, d, inv, fwd, fwd)
+    o.specify(intensityMus=mus, intensityPhis=phis, useRRForIntensity=1, zetaMin=0.3, surfaceAlbedo=0.06)
+    gr, orr = _two_stage(oracle, g, o, 12, 50000, 0.5, ("fluxUp", "fluxDown", "fluxAbsorbed", "intensity"), per_direction=True)
+    assert "wide" in g.kernel_name(), g.kernel_name()
+    # the same work on both sides: scatterings per photon (the Mie table's entries are chosen per cell, the gas by the compare chain)
+    kg = sum(r["counters"]["scatterings"] for r in gr) / (len(gr) * 50000)
+    ko = sum(r["scatterings"] for r in orr) / (len(orr) * 50000)
+    assert abs(kg - ko) < 0.02 * ko, (kg, ko)
+    g.finalize_Integrator()
+
+
 def test_config4_column_by_column_against_the_oracles_fixture():
     """Config 4 (Landsat 128 x 128 x 119 + 7 radiance directions + the surface object) COLUMN BY COLUMN against a fixture the oracle
     wrote in the build container (tests/golden/make_config4_columns.py: 48 batches of 5e5 photons, 2.4e7 in all -- thirty photons

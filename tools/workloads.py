@@ -39,6 +39,12 @@ WORKLOADS = {
     "landsat36_absorbing": dict(label="i3rcLandsatCloud 128x128x36 (labelled synthetic), omega = 0.99, mu0=1, flux + absorption", baseline_config=3,
                                 domain=("landsat_cloud", dict(nlayers=36, ssa=0.99)), moments=299, mu0=1.0, params={},
                                 photons=125_000_000, photons_node=1_000_000_000, cpu_photons=60_000),
+    # the I3RC cases' ABSORBING versions (the reference's generators write both: I3RC-Examples/i3rcStepCloud.f95:97, i3rcLandsatCloud.f95:138):
+    # omega = 0.99 -- every scattering tallies absorbed flux and volume absorption (:642-649)
+    "step16_absorbing": dict(label="i3rcStepCloud 32x1x16, omega = 0.99, mu0=1, flux + absorption", baseline_config=1,
+                             domain=("step_cloud", dict(nlayers=16, ssa=0.99)), moments=64, mu0=1.0, params={}, photons=100_000_000, cpu_photons=200_000),
+    "landsat119_absorbing": dict(label="i3rcLandsatCloud 128x128x119, omega = 0.99, mu0=1, flux + absorption", baseline_config=3,
+                                 domain=("landsat_cloud", dict(ssa=0.99)), moments=299, mu0=1.0, params={}, photons=125_000_000, cpu_photons=40_000),
     "landsat119": dict(label="i3rcLandsatCloud 128x128x119 (reference-exact field, mu0=1), flux", baseline_config=3,
                        domain=("landsat_cloud", {}), moments=299, mu0=1.0, params={}, photons=125_000_000, photons_node=1_000_000_000, cpu_photons=40_000),
     "landsat119_7dir": dict(label="i3rcLandsatCloud 128x128x119 + 7 radiance directions + Lambertian surface 0.2 "
@@ -74,6 +80,16 @@ WORKLOADS = {
     "landsat119_brdfgrid_7dir": dict(label="i3rcLandsatCloud 128x128x119 + 7 radiance directions + a gridded Lambertian surface (8 x 8 cells, "
                                            "reflectance 0.05 ... 0.35), mu0=0.5", baseline_config=4, domain=("landsat_cloud", {}), surface_grid=8,
                                      moments=299, mu0=0.5, params=dict(**DIRS7, **RRI), photons=125_000_000, cpu_photons=6_000),
+    # ---- a domain as the reference's own tool chain writes it (tests/golden/make_tool_domains.py: MakeMieTable -> PhysicalPropertiesToDomain on
+    # Tools/Examples, the reference's programs unchanged on the shell): an LES stratocumulus field of 64 x 64 x 16 cloudy cells in 18 irregular
+    # layers, a Mie table of 35 effective radii (up to 1381 Legendre coefficients, the table entry chosen per cell), + Rayleigh scattering
+    "les_stcu_rayleigh": dict(label="LES stratocumulus 64x64x18 from the reference's tool chain (Mie table of 35 entries + Rayleigh gas: two components), "
+                                    "mu0=0.5, Lambertian surface 0.06, flux", baseline_config=3, domain_file="tests/golden/tools_les_stcu_rayleigh.dom.gz",
+                              mu0=0.5, params={}, albedo=0.06, photons=100_000_000, cpu_photons=100_000),
+    "les_stcu_rayleigh_2dir": dict(label="LES stratocumulus 64x64x18 from the reference's tool chain (Mie table + Rayleigh gas) + 2 radiance directions, "
+                                         "mu0=0.5, Lambertian surface 0.06", baseline_config=4, domain_file="tests/golden/tools_les_stcu_rayleigh.dom.gz",
+                                   mu0=0.5, params=dict(intensityMus=[1.0, 0.6], intensityPhis=[0.0, 135.0], **RRI), albedo=0.06,
+                                   photons=50_000_000, cpu_photons=50_000),
 }
 # Work per photon of the REFERENCE'S ALGORITHM on the four bench workloads (S tracer iterations incl. local-estimate rays,
 # K scatterings, E boundary tallies): the figures SURVEY.md 8(d)'s byte formula is evaluated with.  Recorded from runs in
@@ -102,6 +118,8 @@ def domain(w):
 
     from tools import cases
 
+    if "domain_file" in w:
+        return domain_from_file(w)[1]
     fn, kw = w["domain"]
     d = getattr(cases, fn)(**kw)
     if w.get("irregular"):   # irregular x / y spacing: cell widths drawn once (fixed seed) within +- the given fraction of the regular width
@@ -111,6 +129,34 @@ def domain(w):
             widths = np.diff(e) * rng.uniform(1.0 - w["irregular"], 1.0 + w["irregular"], len(e) - 1)
             d[key] = np.concatenate([[e[0]], e[0] + np.cumsum(widths)]).astype(np.float32)
     return d
+
+
+def domain_from_file(w):
+    """A workload whose domain is a FILE (gzipped netCDF classic, the reference's domain-file schema): (Domain, arrays) -- the Python
+    mirror's read_Domain, and every component's arrays on the whole grid [component][z][y][x] as the oracle takes them."""
+    import gzip
+    import os
+    import tempfile
+
+    import numpy as np
+
+    import i3rc_monte_carlo_model_amd as M
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), w["domain_file"])
+    with tempfile.NamedTemporaryFile(suffix=".dom") as tmp:
+        tmp.write(gzip.decompress(open(path, "rb").read()))
+        tmp.flush()
+        dom = M.read_Domain(tmp.name)
+    nz, ny, nx = dom.shape
+
+    def full(c, key, dtype):
+        a = np.zeros((nz, ny, nx), dtype)
+        z0 = c["zbase"] - 1
+        a[z0:z0 + c[key].shape[0]] = np.broadcast_to(c[key], (c[key].shape[0], ny, nx))
+        return a
+    d = dict(xe=dom.x, ye=dom.y, ze=dom.z, ext=np.stack([full(c, "ext", np.float32) for c in dom.components]),
+             ssa=np.stack([full(c, "ssa", np.float32) for c in dom.components]), pf=np.stack([full(c, "pfi", np.int32) for c in dom.components]))
+    return dom, d
 
 
 def gas_component(w, d):
@@ -147,10 +193,13 @@ def make_integrator(w, device=0):
 
     import i3rc_monte_carlo_model_amd as M
 
-    d = domain(w)
-    table = M.PhaseFunctionTable([M.henyey_greenstein(0.85, w["moments"])])
-    dom = M.new_Domain(d["xe"], d["ye"], d["ze"])
-    dom.addOpticalComponent("cloud", d["ext"], d["ssa"], d["pf"], table)
+    if "domain_file" in w:
+        dom, d = domain_from_file(w)
+    else:
+        d = domain(w)
+        table = M.PhaseFunctionTable([M.henyey_greenstein(0.85, w["moments"])])
+        dom = M.new_Domain(d["xe"], d["ye"], d["ze"])
+        dom.addOpticalComponent("cloud", d["ext"], d["ssa"], d["pf"], table)
     if "gas" in w:
         gas = gas_component(w, d)
         dom.addOpticalComponent("gas", gas, np.full_like(gas, np.float32(w.get("gas_ssa", 1.0))), np.ones(gas.shape, np.int32),
@@ -163,7 +212,7 @@ def make_integrator(w, device=0):
     elif "surface" in w:
         kw["surfaceBDRF"] = M.new_SurfaceDescription([w["surface"]])
     else:
-        kw["surfaceAlbedo"] = 0.0
+        kw["surfaceAlbedo"] = w.get("albedo", 0.0)
     g.specifyParameters(minInverseTableSize=10001, minForwardTableSize=10001, useRayTracing=True, useRussianRoulette=True, **kw)
     return g, d
 
@@ -174,11 +223,16 @@ def make_oracle(w):
 
     from oracle import pyoracle as O
 
-    d = domain(w)
-    coef = O.hg_coefficients(0.85, w["moments"])
-    inv = [O.inverse_table_legendre(coef, 10001)]
     nd = n_dir(w)
-    fwd = [O.forward_table_legendre(coef, 10001)] if nd else None
+    if "domain_file" in w:   # (the tables of a file's components: the Python mirror's restatement of the reference's table routines)
+        dom, d = domain_from_file(w)
+        inv = [c["table"].inverse_table(10001) for c in dom.components]
+        fwd = [c["table"].forward_table(10001) for c in dom.components] if nd else None
+    else:
+        d = domain(w)
+        coef = O.hg_coefficients(0.85, w["moments"])
+        inv = [O.inverse_table_legendre(coef, 10001)]
+        fwd = [O.forward_table_legendre(coef, 10001)] if nd else None
     ext, ssa, pf = d["ext"], d["ssa"], d["pf"]
     if "gas" in w:
         gas = gas_component(w, d)
@@ -200,6 +254,8 @@ def make_oracle(w):
         huge = np.finfo(np.float32).max
         kw.update(surfaceBDRF=(np.array([0.0, huge], np.float32), np.array([0.0, huge], np.float32),
                                np.array([[w["surface"]]], np.float32)))
+    if "albedo" in w:
+        kw.update(surfaceAlbedo=w["albedo"])
     if kw:
         o.specify(**kw)
     return o, d
