@@ -92,6 +92,7 @@ struct i3rc_hip_integrator {
   int xyRegular = 0, zRegular = 0;
   std::vector<int> maxPfIndex;
   float uniformSsa = -1.f;   // one-component domains: the value every cell shares, else -1
+  bool absorbing = false;    // some cell of some component has omega < 1: launches tally volume absorption, and fluxAbsorbed is formed from it (absorbed_columns_kernel)
   int uniformPf = 0;         // ... and the phase-function entry every cell shares, else 0
 
   i3rc_tally_layout layout{};
@@ -418,6 +419,7 @@ int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int n
     for (size_t i = 0; i < ncell; ++i) m = std::max(m, pfIndex[(size_t)c * ncell + i]);
     h->maxPfIndex[c] = m;
   }
+  for (size_t i = 0; i < ncell * (size_t)ncomp && !h->absorbing; ++i) h->absorbing = ssa[i] < 1.0f;
   if (ncomp == 1) {
     // Values that every cell WITH EXTINCTION shares travel in the kernel arguments (specialised kernels: ray tracing, where a
     // photon can only be scattered in a cell of positive extinction -- the tracer never stops in any other --, so what the
@@ -736,10 +738,10 @@ int i3rc_hip_lds_plan(const int32_t *q, int32_t *out) {
   DevProblem P;
   std::memset(&P, 0, sizeof(P));
   P.nx = q[0]; P.ny = q[1]; P.nz = q[2]; P.ncomp = q[3]; P.nDir = q[4]; P.ldsTallies = q[5]; P.ldsIntensity = q[6];
-  P.rayQueueCap = q[7]; P.clearNx = q[8]; P.clearShift = q[9];
+  P.rayQueueCap = q[7]; P.clearNx = q[8]; P.clearShift = q[9]; P.ldsVolume = q[16];
   const LdsPlan lp = lds_plan(P, q[10] != 0, q[11] != 0, q[12], q[13] != 0, q[14], q[15]);
-  const int v[11] = {lp.xE, lp.yE, lp.zE, lp.tallies, lp.dirCos, lp.dirTab, lp.queue, lp.tInt, lp.ext, lp.cosTab, lp.end};
-  for (int k = 0; k < 11; ++k) out[k] = v[k];
+  const int v[12] = {lp.xE, lp.yE, lp.zE, lp.tallies, lp.dirCos, lp.dirTab, lp.queue, lp.tInt, lp.ext, lp.cosTab, lp.end, lp.tVol};
+  for (int k = 0; k < 12; ++k) out[k] = v[k];
   return 0;
 }
 
@@ -898,7 +900,10 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false, b
   // tally straight to the float64 buffer in global memory -- a measurement knob, and one more order of the same float64 additions)
   static const bool ldsTalliesEnv = !(std::getenv("I3RC_LDS_TALLIES") && std::atoi(std::getenv("I3RC_LDS_TALLIES")) == 0);
   const bool privatise = !fused && ldsTalliesEnv && h->ldsTalliesOn;
-  if (privatise && lds + 3 * ncol * sizeof(tally_t) + 4 <= kLdsBudget / 2) { P.ldsTallies = 1; lds += 3 * ncol * sizeof(tally_t) + 4; }
+  if (privatise && lds + 2 * ncol * sizeof(tally_t) + 4 <= kLdsBudget / 2) { P.ldsTallies = 1; lds += 2 * ncol * sizeof(tally_t) + 4; }
+  // (an absorbing domain of few cells -- the step cloud's 512 or 1024 --: its volume-absorption tallies, which every scattering adds to)
+  P.ldsVolume = 0;
+  if (privatise && h->absorbing && lds + ncell * sizeof(tally_t) + 4 <= kLdsBudget / 2) { P.ldsVolume = 1; lds += ncell * sizeof(tally_t) + 4; }
   P.ldsIntensity = 0;
   {
     const size_t nInt = (size_t)(h->ncomp + 1) * h->nDir * ncol * sizeof(tally_t) + 4;
@@ -911,6 +916,28 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false, b
   plan.ldsBytes = (lds + 15) & ~(size_t)15;
   plan.intensity = h->nDir > 0;
   plan.place = P.ldsGrid ? GRID_LDS : (P.colRec ? (P.colBase ? GRID_COLBASE : GRID_COLUMNS) : (P.extBrick ? GRID_BRICKS : GRID_GLOBAL));
+  return 0;
+}
+
+// fluxAbsorbed(ix, iy) of a tally block = the sum of its column's volumeAbsorption (:644-647 add the same increment to both; the kernels
+// tally the cell only: Tally::absorbed).  An assignment: a block that several launches add to is summed again after each of them.
+__global__ void __launch_bounds__(256) absorbed_columns_kernel(double *blocks, long long stride, int oAbs, int oVol, int ncol, int nz) {
+  const int col = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (col >= ncol) return;
+  double *const blk = blocks + (size_t)blockIdx.y * stride;
+  double s = 0.0;
+  for (int k = 0; k < nz; ++k) s += blk[oVol + (size_t)k * ncol + col];
+  blk[oAbs + col] = s;
+}
+int absorbed_columns(i3rc_hip_integrator *h, hipStream_t stream, double *blocks, int nBlocks, long long stride) {
+  if (!h->absorbing || nBlocks < 1) return 0;   // (nothing absorbs: both tallies stay zero)
+  const int ncol = h->nx * h->ny;
+  for (int first = 0; first < nBlocks; first += 65535) {
+    const int n = std::min(65535, nBlocks - first);
+    hipLaunchKernelGGL(absorbed_columns_kernel, dim3((unsigned)((ncol + 255) / 256), (unsigned)n), dim3(256), 0, stream, blocks + (size_t)first * stride,
+                       stride, (int)h->layout.fluxAbsorbed, (int)h->layout.volumeAbsorption, ncol, h->nz);
+    HIPCHK(h, hipGetLastError());
+  }
   return 0;
 }
 
@@ -1106,7 +1133,7 @@ int launch(i3rc_hip_integrator *h, const LaunchPlan &plan, const RunArgs &A, boo
   }
   HIPCHK(h, hipGetLastError());
   if (timeIt) { HIPCHK(h, hipEventRecord(h->evStop[slot], h->stream)); h->timedLaunches++; }
-  return 0;
+  return absorbed_columns(h, h->stream, plan.P.tally, 1, 0);
 }
 
 
@@ -1420,6 +1447,7 @@ int launch_fused_group(i3rc_hip_integrator *h, i3rc_hip_integrator::FusedSlot &g
     HIPCHK(h, hipGetLastError());
     result = (const double *)g.compact.p;
   }
+  if (absorbed_columns(h, g.stream, const_cast<double *>(result), count, (long long)h->layout.total)) return 1;
   {
     const long long n = (long long)count * I3RC_NUM_COUNTERS;
     hipLaunchKernelGGL(reduce_counters_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream, (const double *)g.counterBlocks.p,

@@ -98,9 +98,14 @@ struct Tally {
     if (!BATCHED && P.ldsTallies) lds_add((top ? L.tUp : L.tDown) + col, w);
     else add_global(base() + (top ? P.oUp : P.oDown) + col, w);
   }
-  __device__ __forceinline__ void absorbed(int col, int cell, float w) const {
-    if (!BATCHED && P.ldsTallies) lds_add(&L.tAbs[col], w); else add_global(base() + P.oAbs + col, w);
-    add_global(base() + P.oVol + cell, w);
+  // Absorption (:644-647: fluxAbsorbed(ix, iy) and volumeAbsorption(ix, iy, iz) take the same increment): ONE tally, the cell's.  The
+  // column's sum is the sum of its cells' and is formed from them after the launch (absorbed_columns_kernel, i3rc_hip.hip): the same
+  // float64 additions in another order.  Scattered float64 atomics execute at the memory side, some 2e10 a second for the whole chip
+  // (profiles/r05_atomic_rate.txt): two per scattering made the I3RC cases' absorbing versions (omega = 0.99) two to three times slower
+  // than the conservative ones on the Landsat fields -- and nineteen times on the step cloud, whose 512 cells every wave of the chip
+  // added to; a domain of few cells gathers them per workgroup in LDS (ldsVolume).
+  __device__ __forceinline__ void absorbed(int cell, float w) const {
+    if (!BATCHED && P.ldsVolume) lds_add(&L.tVol[cell], w); else add_global(base() + P.oVol + cell, w);
   }
 };
 
@@ -386,7 +391,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
     lds_float *const base = (lds_float *)smem;
     const int ncol = P.nx * P.ny;
     L.xE = base + lp.xE; L.yE = base + lp.yE; L.zE = base + lp.zE;
-    L.tUp = (lds_tally *)(base + lp.tallies); L.tDown = L.tUp + ncol; L.tAbs = L.tUp + 2 * ncol;
+    L.tUp = (lds_tally *)(base + lp.tallies); L.tDown = L.tUp + ncol; L.tVol = (lds_tally *)(base + lp.tVol);
     L.dirCos = base + lp.dirCos; L.dirTab = base + lp.dirTab; L.queue = base + lp.queue;
     L.tInt = (lds_tally *)(base + lp.tInt); L.ext = base + lp.ext; L.cosTab = base + lp.cosTab;
   }
@@ -396,7 +401,9 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
   for (int i = threadIdx.x; i <= P.ny; i += blockDim.x) L.yE[i] = P.yE[i];
   for (int i = threadIdx.x; i <= P.nz; i += blockDim.x) L.zE[i] = P.zE[i];
   if (P.ldsTallies)
-    for (int i = threadIdx.x; i < 3 * P.nx * P.ny; i += blockDim.x) L.tUp[i] = (tally_t)0;
+    for (int i = threadIdx.x; i < 2 * P.nx * P.ny; i += blockDim.x) L.tUp[i] = (tally_t)0;
+  if (P.ldsVolume)
+    for (int i = threadIdx.x; i < P.nx * P.ny * P.nz; i += blockDim.x) L.tVol[i] = (tally_t)0;
   if (GRID == GRID_LDS) {
     const int ncell = P.nx * P.ny * P.nz;
     for (int i = threadIdx.x; i < ncell; i += blockDim.x) L.ext[i] = P.totalExt[i];
@@ -1239,7 +1246,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
               if (!GENERAL && !MULTI && Pe.uniformSsa >= 0.0f) ssa = Pe.uniformSsa;
               else ssa = Pe.ssa[(size_t)(comp - 1) * ncell + cell];
               if (ssa < 1.0f) {                                           // :642-649
-                tally.absorbed((r.iy - 1) * Pe.nx + (r.ix - 1), cell, w * (1.0f - ssa));
+                tally.absorbed(cell, w * (1.0f - ssa));
                 w = w * ssa;
               }
               int pfi;
@@ -1374,12 +1381,18 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
     double *const out = ka->P.tally;
     if (ka->P.ldsTallies) {
       const int ncol = ka->P.nx * ka->P.ny;
-      const int oUp = ka->P.oUp, oDown = ka->P.oDown, oAbs = ka->P.oAbs;
+      const int oUp = ka->P.oUp, oDown = ka->P.oDown;
       for (int i = threadIdx.x; i < ncol; i += blockDim.x) {
-        const tally_t u = L.tUp[i], d = L.tDown[i], a = L.tAbs[i];
+        const tally_t u = L.tUp[i], d = L.tDown[i];
         if (u != (tally_t)0) add_global(out + oUp + i, u);
         if (d != (tally_t)0) add_global(out + oDown + i, d);
-        if (a != (tally_t)0) add_global(out + oAbs + i, a);
+      }
+    }
+    if (ka->P.ldsVolume) {
+      const int nVol = ka->P.nx * ka->P.ny * ka->P.nz, oVol = ka->P.oVol;
+      for (int i = threadIdx.x; i < nVol; i += blockDim.x) {
+        const tally_t v = L.tVol[i];
+        if (v != (tally_t)0) add_global(out + oVol + i, v);
       }
     }
     if (ka->P.ldsIntensity) {
@@ -1413,7 +1426,7 @@ __global__ void __launch_bounds__(256) trace_rays_kernel(const DevProblem P, lon
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   L.xE = (lds_float *)smem; L.yE = L.xE + P.nx + 1; L.zE = L.yE + P.ny + 1;
-  L.tUp = L.tDown = L.tAbs = nullptr; L.dirCos = nullptr;
+  L.tUp = L.tDown = L.tVol = nullptr; L.dirCos = nullptr;
   L.ext = L.zE + P.nz + 1;   // the clear-air map of the bricked field
   if (GRID == GRID_BRICKS && CLEARMAP)
     for (int i = threadIdx.x; i < P.clearNx * (((P.ny - 1) >> P.clearShift) + 1); i += blockDim.x) L.ext[i] = __uint_as_float(P.clearMap[i]);

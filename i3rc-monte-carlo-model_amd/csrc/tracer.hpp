@@ -80,7 +80,8 @@ struct DevProblem {
   // tallies (float64, packed; offsets in elements: i3rc_hip_create keeps the whole buffer below 2^31 elements)
   double *tally;
   int oUp, oDown, oAbs, oVol, oInt, oExc, oCnt;
-  int ldsTallies;                     // 1: fluxUp/Down/Absorbed privatised in LDS (ncol small)
+  int ldsTallies;                     // 1: fluxUp / fluxDown privatised in LDS (ncol small)
+  int ldsVolume;                      // 1: volumeAbsorption privatised in LDS (an absorbing domain of few cells)
   int ldsGrid;                        // 1: totalExt staged in LDS
   int ldsIntensity;                   // 1: intensityByComponent privatised in LDS ((ncomp+1)*nDir*ncol small)
   int rayQueueCap;                    // radiance runs: events a wave's ray queue holds (power of two; kRecWords floats each)
@@ -136,7 +137,8 @@ typedef __attribute__((address_space(3))) tally_t lds_tally;
 constexpr int kTallyWords = (int)(sizeof(tally_t) / sizeof(float));
 struct Lds {
   lds_float *xE, *yE, *zE;    // edges
-  lds_tally *tUp, *tDown, *tAbs;  // privatised flux tallies (valid when ldsTallies)
+  lds_tally *tUp, *tDown;     // privatised flux tallies (valid when ldsTallies)
+  lds_tally *tVol;            // privatised volumeAbsorption (valid when ldsVolume)
   lds_float *ext;             // totalExt copy (valid when ldsGrid); bricked fields: the clear-air map (DevProblem::clearMap) as words; GRID_COLBASE: the base profile
   lds_float *dirCos;          // intensity directions
   lds_float *dirTab;          // ... and, per direction, what a ray of that direction derives from it (Ray::set_direction), 16 words: see photon_kernel
@@ -163,7 +165,7 @@ constexpr int kCounterReplicas = 64;   // fused multi-batch launches: copies of 
 //   direct        ... of the one-direction form (photon_kernel, DIRECT)
 //   grid          GridPlace of the instantiation;  intensity: its INTENSITY (a bricked field's clear-air map: flux kernels only)
 //   waves         waves per workgroup;  tableWords: the inverse table's cosines behind everything else (TBL), else 0
-struct LdsPlan { int xE, yE, zE, tallies, dirCos, dirTab, queue, tInt, ext, cosTab, end; };
+struct LdsPlan { int xE, yE, zE, tallies, dirCos, dirTab, queue, tInt, ext, cosTab, end, tVol; };
 template <class PR>
 __host__ __device__ inline LdsPlan lds_plan(const PR &P, bool queues, bool direct, int grid, bool intensity, int waves, int tableWords) {
   LdsPlan o;
@@ -173,8 +175,11 @@ __host__ __device__ inline LdsPlan lds_plan(const PR &P, bool queues, bool direc
   o.zE = p; p += P.nz + 1;
   const int ncol = P.nx * P.ny;
   if (P.ldsTallies) p = (p + kTallyWords - 1) & ~(kTallyWords - 1);
-  o.tallies = p;                               // fluxUp | fluxDown | fluxAbsorbed, ncol tally_t each (valid when ldsTallies)
-  if (P.ldsTallies) p += 3 * ncol * kTallyWords;
+  o.tallies = p;                               // fluxUp | fluxDown, ncol tally_t each (valid when ldsTallies)
+  if (P.ldsTallies) p += 2 * ncol * kTallyWords;
+  if (P.ldsVolume) p = (p + kTallyWords - 1) & ~(kTallyWords - 1);
+  o.tVol = p;                                  // volumeAbsorption, ncol * nz tally_t (valid when ldsVolume: small absorbing domains)
+  if (P.ldsVolume) p += ncol * P.nz * kTallyWords;
   o.dirCos = p; p += 3 * P.nDir;
   if (queues) p = (p + 3) & ~3;                // (the 128-bit reads of dirTab)
   o.dirTab = p;

@@ -345,11 +345,13 @@ int i3rc_hip_set_lds_tallies(i3rc_hip_integrator *h, int on);
 
 /* Test hook, host code only (no device needed): the carve-up of a workgroup's dynamic LDS that photon_kernel makes -- the very
  * function the kernel sets its pointers from and the launch sizes its allocation from (csrc/tracer.hpp, lds_plan).
- *   q[0..15]  = nx, ny, nz, ncomp, nDir, ldsTallies, ldsIntensity, rayQueueCap, clearNx, clearShift,
+ *   q[0..16]  = nx, ny, nz, ncomp, nDir, ldsTallies, ldsIntensity, rayQueueCap, clearNx, clearShift,
  *               queues (radiance kernel with ray queues), direct (its one-direction form), grid place (0 LDS, 1 global, 2 bricks,
- *               3 column records), intensity (radiance kernel), waves per workgroup, words of the inverse table kept in LDS
- *   out[0..10] = word offsets of: x edges, y edges, z edges, flux tallies, directions, per-direction ray constants, ray queues,
- *               radiance tallies, extinction grid / clear-air map, inverse table; and the end (= words a launch allocates). */
+ *               3 column records), intensity (radiance kernel), waves per workgroup, words of the inverse table kept in LDS,
+ *               ldsVolume (volume-absorption tallies gathered in LDS: absorbing domains of few cells)
+ *   out[0..11] = word offsets of: x edges, y edges, z edges, flux tallies (up, down), directions, per-direction ray constants, ray
+ *               queues, radiance tallies, extinction grid / clear-air map, inverse table; the end (= words a launch allocates); and
+ *               the volume-absorption tallies (which lie between the flux tallies and the directions). */
 int i3rc_hip_lds_plan(const int32_t *q, int32_t *out);
 
 /* Test hook: the raw Philox4x32-10 blocks (out[n][blocksPerPhoton][4]) of photons firstPhoton..+n-1 and the

@@ -210,7 +210,7 @@ def test_lds_carve_up_regions_do_not_overlap_and_are_aligned():
     for nx, ny, nz in shapes:
         for ndir in (0, 1, 2, 7):
             for place in (0, 1, 2, 3):
-                for tallies in (0, 1):
+                for tallies, volume in ((0, 0), (1, 0), (1, 1), (0, 1)):
                     for table in (0, 10001):
                         intensity = 1 if ndir else 0
                         direct = 1 if ndir == 1 else 0
@@ -218,13 +218,13 @@ def test_lds_carve_up_regions_do_not_overlap_and_are_aligned():
                         if table and intensity:
                             continue   # (the table-in-LDS instantiations are flux kernels)
                         q = np.array([nx, ny, nz, ncomp, ndir, tallies, 1 if (ndir and tallies) else 0, cap, clear_nx, clear_shift,
-                                      intensity, direct, place, intensity, 16 if table else 4, table], np.int32)
-                        out = np.zeros(11, np.int32)
+                                      intensity, direct, place, intensity, 16 if table else 4, table, volume], np.int32)
+                        out = np.zeros(12, np.int32)
                         assert lib.i3rc_hip_lds_plan(q.ctypes.data_as(B.ip), out.ctypes.data_as(B.ip)) == 0
-                        xE, yE, zE, tal, dirs, dirtab, queue, tint, ext, costab, end = (int(v) for v in out)
+                        xE, yE, zE, tal, dirs, dirtab, queue, tint, ext, costab, end, tvol = (int(v) for v in out)
                         ncol = nx * ny
                         waves = 16 if table else 4
-                        sizes = [(xE, nx + 1), (yE, ny + 1), (zE, nz + 1), (tal, 6 * ncol if tallies else 0), (dirs, 3 * ndir),
+                        sizes = [(xE, nx + 1), (yE, ny + 1), (zE, nz + 1), (tal, 4 * ncol if tallies else 0), (tvol, 2 * ncol * nz if volume else 0), (dirs, 3 * ndir),
                                  (dirtab, 16 * ndir if intensity else 0),
                                  (queue, waves * (14 * cap + 12 * (128 if direct else 64)) if intensity else 0),
                                  (tint, 2 * (ncomp + 1) * ndir * ncol if (ndir and tallies) else 0),
@@ -238,6 +238,8 @@ def test_lds_carve_up_regions_do_not_overlap_and_are_aligned():
                         assert end - at < 4                                   # nothing wasted beyond alignment
                         if tallies:
                             assert tal % 2 == 0 and (tint % 2 == 0 or not ndir)
+                        if volume:
+                            assert tvol % 2 == 0
                         if intensity:
                             assert dirtab % 4 == 0
 
