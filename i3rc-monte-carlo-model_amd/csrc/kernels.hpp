@@ -107,6 +107,8 @@ struct Tally {
   __device__ __forceinline__ void absorbed(int cell, float w) const {
     if (!BATCHED && P.ldsVolume) lds_add(&L.tVol[cell], w); else add_global(base() + P.oVol + cell, w);
   }
+  __device__ __forceinline__ bool volume_in_lds() const { return !BATCHED && P.ldsVolume; }
+  __device__ __forceinline__ void absorbed_sum(int cell, double sum) const { add_global(base() + P.oVol + cell, sum); }   // (a lane's run in one cell: photon_kernel)
 };
 
 // computeIntensityContribution :1419-1611 for one event; adds straight into intensityByComponent.
@@ -468,6 +470,19 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
   float w = 0.0f;
   int order = 0;
   int st = ST_NEW;
+  // Absorption where the tally goes to global memory: what a photon's CONSECUTIVE scatterings in one cell add to it leaves as one
+  // atomic -- when the next scattering lies in another cell, or the photon ends (so that a fused launch's lane never holds a sum of
+  // another batch's block).  In clouds whose cells are optically thick (an LES field: 55 m cells, free paths of 10 m) a photon is
+  // scattered several times in a row in the cell it is in; the memory side takes some 2e10 scattered atomics a second, which one per
+  // scattering reaches at 1.1e9 photons/s (Tally::absorbed).  The sum is float64: the same additions in another grouping.
+#ifndef I3RC_MERGE_ABSORPTION
+#define I3RC_MERGE_ABSORPTION 1
+#endif
+  // (flux kernels: the radiance kernels, the general ones at three waves per SIMD and the fused table-in-LDS kernels at eight have no
+  // three registers to spare -- with them they spilled 6 ... 20 bytes a lane)
+  constexpr bool MERGE = I3RC_MERGE_ABSORPTION != 0 && !INTENSITY && !(Rng::kBatched && TBL);
+  int pendCell = -1;
+  double pendSum = 0.0;
   long long pid = -1;                 // photon number within the launch (NEED_PID builds)
   int fate = -1, fateCol = -1;        // REPLAY builds
   float fateW = 0.0f;
@@ -1049,6 +1064,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
           order += atBlack ? 1 : 0;
           fate = dropped ? 3 : (atTop ? 0 : 1);
         }
+        if (MERGE && pendCell >= 0) { tally.absorbed_sum(pendCell, pendSum); pendCell = -1; }
         close_photon();
         st = ST_NEW;
       }
@@ -1246,7 +1262,15 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
               if (!GENERAL && !MULTI && Pe.uniformSsa >= 0.0f) ssa = Pe.uniformSsa;
               else ssa = Pe.ssa[(size_t)(comp - 1) * ncell + cell];
               if (ssa < 1.0f) {                                           // :642-649
-                tally.absorbed(cell, w * (1.0f - ssa));
+                const float inc = w * (1.0f - ssa);
+                if (!MERGE || tally.volume_in_lds()) tally.absorbed(cell, inc);
+                else {
+                  if (cell != pendCell) {
+                    if (pendCell >= 0) tally.absorbed_sum(pendCell, pendSum);
+                    pendCell = cell; pendSum = 0.0;
+                  }
+                  pendSum += (double)inc;
+                }
                 w = w * ssa;
               }
               int pfi;
@@ -1290,7 +1314,10 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
           }
         }
         // a photon that died in part C (roulette, absorbing surface) is closed here and respawns at the next event phase
-        if (st == ST_NEW) close_photon();
+        if (st == ST_NEW) {
+          if (MERGE && pendCell >= 0) { tally.absorbed_sum(pendCell, pendSum); pendCell = -1; }
+          close_photon();
+        }
       }
       if constexpr (DIRECT) {   // one radiance direction: the event becomes a ready ray here and now (make_ray), survivors only go to LDS
         if (defer) {

@@ -167,7 +167,7 @@ constexpr int kCounterReplicas = 64;   // fused multi-batch launches: copies of 
 //   waves         waves per workgroup;  tableWords: the inverse table's cosines behind everything else (TBL), else 0
 struct LdsPlan { int xE, yE, zE, tallies, dirCos, dirTab, queue, tInt, ext, cosTab, end, tVol; };
 template <class PR>
-__host__ __device__ inline LdsPlan lds_plan(const PR &P, bool queues, bool direct, int grid, bool intensity, int waves, int tableWords) {
+__host__ __device__ __attribute__((always_inline)) inline LdsPlan lds_plan(const PR &P, bool queues, bool direct, int grid, bool intensity, int waves, int tableWords) {
   LdsPlan o;
   int p = 0;
   o.xE = p; p += P.nx + 1;

@@ -466,6 +466,56 @@ def test_step_cloud_at_1e8_photons_size_independent_properties(oracle):
     assert col[:12].max() < col[20:].min()
 
 
+def test_absorption_is_tallied_per_cell_and_the_column_sums_follow():
+    """:644-647 add one increment to fluxAbsorbed(ix, iy) and to volumeAbsorption(ix, iy, iz).  The kernels tally the cell only (one
+    scattered float64 atomic per scattering instead of two: the absorbing I3RC cases ran two to nineteen times slower than the
+    conservative ones on them) -- in LDS where the domain has few cells -- and fluxAbsorbed is the sum of its column's cells, formed
+    on the device after the launch (absorbed_columns_kernel): exactly that sum, in the raw block of a plain launch, of a launch that
+    adds to a block already summed, and of every batch of a fused group; and the same photons give the same sums whether the cells are
+    gathered in LDS or not (the order of the float64 additions: tests/sums.py)."""
+    n = 200_000
+    for d, kw in ((cases.step_cloud(ssa=0.99), {}), (cases.step_cloud(ssa=0.9, nlayers=3), dict(surfaceAlbedo=0.3)), (cases.two_component(seed=5, nx=6, ny=4, nz=8), {})):
+        tab = ([M.PhaseFunctionTable([M.henyey_greenstein(0.85, 32), M.henyey_greenstein(0.6, 16)]),
+                M.PhaseFunctionTable([M.PhaseFunction(legendre=np.array([0.0, 0.1], np.float32))])] if isinstance(d["ext"], list) else hg_table())
+        g = make_gpu(d, tab, **kw)
+        lay, (nz, ny, nx) = g.layout(), (len(d["ze"]) - 1, len(d["ye"]) - 1, len(d["xe"]) - 1)
+        ncol = nx * ny
+
+        def columns(raw):
+            vol = raw[lay.volumeAbsorption:lay.volumeAbsorption + nz * ncol].reshape(nz, ncol)
+            s = np.zeros(ncol)
+            for k in range(nz):
+                s = s + vol[k]
+            return s, raw[lay.fluxAbsorbed:lay.fluxAbsorbed + ncol]
+        r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((3, 1)), M.new_PhotonStream(0.7, 10.0, n))
+        want, got = columns(r["raw"])
+        assert want.sum() > 0 and np.array_equal(want, got)
+        # a second launch adding to the same block (the photon stream's second half)
+        g.launch(M.new_RandomNumberSequence((3, 2)), M.new_PhotonStream(0.7, 10.0, n // 2))
+        g.launch(M.new_RandomNumberSequence((3, 2)), M.new_PhotonStream(0.7, 10.0, n // 2), firstPhoton=n // 2, zero=False)
+        both = g.finish()
+        want, got = columns(both["raw"])
+        assert np.array_equal(want, got)
+        whole = g.computeRadiativeTransfer(M.new_RandomNumberSequence((3, 2)), M.new_PhotonStream(0.7, 10.0, n))
+        assert_same_sums(both["raw"][:lay.counters], whole["raw"][:lay.counters], whole["counters"], what="two launches into one block")
+        # the cells gathered in LDS or not
+        g.set_lds_tallies(False)
+        plain = g.computeRadiativeTransfer(M.new_RandomNumberSequence((3, 1)), M.new_PhotonStream(0.7, 10.0, n))
+        g.set_lds_tallies(True)
+        assert plain["counters"] == r["counters"]
+        assert_same_sums(plain["raw"][:lay.counters], r["raw"][:lay.counters], r["counters"], what="volume absorption in LDS or not")
+        want, got = columns(plain["raw"])
+        assert np.array_equal(want, got)
+        # every batch of a fused group
+        for b, res in enumerate(g.computeRadiativeTransferBatches((3, 1), 3, 0.7, 10.0, n // 4)):
+            want, got = columns(res["raw"])
+            assert want.sum() > 0 and np.array_equal(want, got), b
+        # the normalised fields say the same: fluxAbsorbed = sum over the layers of volumeAbsorption x depth
+        dz = np.diff(d["ze"]).astype(np.float64)
+        assert np.allclose((r["volumeAbsorption"].astype(np.float64) * dz[:, None, None]).sum(0), r["fluxAbsorbed"], rtol=2e-6, atol=1e-12)
+        g.finalize_Integrator()
+
+
 def test_step_cloud_flux_fields_at_1e8_photons_against_the_oracle_at_1e8(tmp_path):
     # The north star's acceptance line taken literally: flux tallies within 3 sigma of the reference at 1e8 photons.
     # BASELINE.json configs[1] on the GPU (20 batches of 5e6) against the CPU restatement at the same 1e8 photons

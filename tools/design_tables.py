@@ -166,5 +166,32 @@ for i, line in enumerate(lines):
         if new != line:
             print(line, "\n ->", new); lines[i] = new; changed += 1
         break
+# Rows of the per-workload tables beyond the BASELINE four (general class, absorbing cases, tool-chain domain): found by the FILE they
+# cite and the kind of their first cell -- "...: photons/s" of <w>_bench.json, "… kernel time per launch, HIP events, ms; `roofline.frac`",
+# "… rocprofv3 kernel average, ns" of <w>_kernel_stats.csv, "… `<w>`: vector instructions per photon; lane occupancy; HBM bytes per photon"
+BASE4 = ("step16", "radar64_nadir", "landsat36", "landsat119_7dir")
+for i, line in enumerate(lines):
+    if not line.startswith("| ") or f"`profiles/{TAG}_" not in line:
+        continue
+    cells = [c.strip() for c in line.strip().strip("|").split("|")]
+    if len(cells) != 3:
+        continue
+    m = re.match(rf"`profiles/{TAG}_(\w+?)_(bench\.json|kernel_stats\.csv)`", cells[2])
+    new = None
+    if m and m.group(1) not in BASE4 and os.path.exists(P(f"{m.group(1)}_bench.json")):
+        w = m.group(1)
+        if m.group(2) == "bench.json" and cells[0].endswith("photons/s"):
+            new = e(J(w)["value"])
+        elif m.group(2) == "bench.json" and cells[0].startswith("… kernel time per launch, HIP events, ms; `roofline.frac`"):
+            new = "%.1f; %.3f" % (J(w)["roofline"]["kernel_ms_avg"], J(w)["roofline"]["frac"])
+        elif m.group(2) == "kernel_stats.csv" and cells[0].startswith("… rocprofv3 kernel average, ns"):
+            new = e(kernel_avg_ns(w))
+    mp = re.match(r"… `(\w+)`: vector instructions per photon; lane occupancy; HBM bytes per photon$", cells[0])
+    if mp and mp.group(1) not in BASE4 and mp.group(1) in pmc:
+        q = pmc[mp.group(1)]
+        new = "%.0f; %.3f; %.1f" % (q["valu_instr_per_photon"], q["lane_occupancy"], q["hbm_bytes_per_photon"])
+    if new is not None and new != cells[1]:
+        out = "| " + " | ".join([cells[0], new, cells[2]]) + " |"
+        print(line, "\n ->", out); lines[i] = out; changed += 1
 open(os.path.join(ROOT, "DESIGN.md"), "w").write("\n".join(lines))
 print(changed, "rows changed")

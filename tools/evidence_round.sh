@@ -4,6 +4,7 @@
 #   tools/evidence_round.sh <tag> counters   (GPU box) per BASELINE workload: the --pmc passes (tools/pmc_profile.sh), rocprofv3
 #                                            --kernel-trace --stats of `bench.py --config <w>`, the bench line itself
 #   tools/evidence_round.sh <tag> general    (GPU box) the same for the general-class workloads (several components, irregular grid, gridded surface)
+#   tools/evidence_round.sh <tag> absorbing  (GPU box) the same for the absorbing I3RC cases and the tool-chain domain
 #   tools/evidence_round.sh <tag> loop       (GPU box) the batch loop and the rest: fused / look-ahead / moments timing, the
 #                                            drivers end to end, the strong-scaling proxy, config_bench, the phase profile,
 #                                            call overhead, the issue-rate and atomic-rate microbenchmarks
@@ -14,6 +15,8 @@ TAG=$1; PART=$2; O=$R/gpurun_out/$TAG
 WL="step16 radar64_nadir landsat36 landsat119_7dir"
 # round 5: the problems beyond the common class -- several components, an irregular x / y grid, a gridded surface (tools/workloads.py)
 GL="landsat119_gas landsat119_gas_7dir landsat119_irregular_7dir landsat119_brdfgrid_7dir"
+# ... the I3RC cases' absorbing versions (omega = 0.99) and the LES stratocumulus + Rayleigh domain the reference's tool chain wrote
+AL="step16_absorbing landsat36_absorbing landsat119_absorbing les_stcu_rayleigh les_stcu_rayleigh_2dir"
 clean() { grep -v "amdgpu.ids" "$1" > "$1.clean" && mv "$1.clean" "$1"; }
 case $PART in
 counters)
@@ -33,10 +36,13 @@ counters)
     echo "$w done: $(python3 -c "import json;j=json.load(open('$O/bench_$w.json'));print('%.3e photons/s'%j['value'], j['roofline']['kernel'])")"
   done
   echo "evidence $TAG: counters done";;
-general)
+general|absorbing)
   # the same three things -- counter passes, rocprofv3 kernel stats of the bench, the bench line -- for the general-class workloads
+  # (absorbing: for the I3RC cases' absorbing versions and the domain of the reference's tool chain)
   mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-  declare -A N=( [landsat119_gas]=50000000 [landsat119_gas_7dir]=10000000 [landsat119_irregular_7dir]=10000000 [landsat119_brdfgrid_7dir]=10000000 )
+  declare -A N=( [landsat119_gas]=50000000 [landsat119_gas_7dir]=10000000 [landsat119_irregular_7dir]=10000000 [landsat119_brdfgrid_7dir]=10000000
+                 [step16_absorbing]=50000000 [landsat36_absorbing]=50000000 [landsat119_absorbing]=50000000 [les_stcu_rayleigh]=50000000 [les_stcu_rayleigh_2dir]=20000000 )
+  [ $PART = absorbing ] && GL=$AL
   for w in ${WORKLOADS:-$GL}; do
     PASSES="1 2 9 10" $R/tools/pmc_profile.sh $TAG/pmc_$w $w ${N[$w]} > $O/pmc_$w.log 2>&1 || echo "pmc $w failed"
     ( export RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533
@@ -44,6 +50,7 @@ general)
     python3 $R/bench.py --config $w --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err || echo "bench $w failed"
     echo "$w done: $(python3 -c "import json;j=json.load(open('$O/bench_$w.json'));print('%.3e photons/s'%j['value'], j['roofline']['kernel'])")"
   done
+  [ $PART = absorbing ] && { echo "evidence $TAG: absorbing done"; exit 0; }
   # ... and each of them on the GENERAL kernels (what ran them until round 4) and on the round-4 place of their field, one launch each
   ( export REPEAT=3
     for w in landsat119_gas landsat119_gas_7dir landsat119_irregular_7dir landsat119_brdfgrid_7dir; do
@@ -71,7 +78,7 @@ loop)
   echo "evidence $TAG: loop done";;
 collect)
   [ -f $O/general_kernels.txt ] && cp $O/general_kernels.txt $R/profiles/${TAG}_general_kernels.txt
-  for w in $WL $GL; do
+  for w in $WL $GL $AL; do
     [ -f $O/bench_$w.json ] && cp $O/bench_$w.json $R/profiles/${TAG}_${w}_bench.json
     f=$(ls -t $O/stats_$w/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $R/profiles/${TAG}_${w}_kernel_stats.csv
     [ -f $O/pmc_$w/summary.txt ] && cp $O/pmc_$w/summary.txt $R/profiles/${TAG}_${w}_pmc_summary.txt
@@ -81,5 +88,5 @@ collect)
     [ -f $O/$f.txt ] && cp $O/$f.txt $R/profiles/${TAG}_$f.txt; done
   python3 $R/tools/pmc_to_json.py --collect $R/profiles/${TAG}_pmc.json $R/profiles/${TAG}_*_pmc_summary.txt > /dev/null
   ls -la --time-style=+%H:%M $R/profiles | grep " ${TAG}_";;
-*) echo "usage: tools/evidence_round.sh <tag> counters|general|loop|collect"; exit 2;;
+*) echo "usage: tools/evidence_round.sh <tag> counters|general|absorbing|loop|collect"; exit 2;;
 esac
