@@ -122,7 +122,28 @@ def loop_rows():
     rows["the whole batch of 1e8 photons, one step in flight"] = [e(float(re.search(r"whole batch of 1e8 photons x 5 steps, 1 step in flight: ([\d.e+]+) photons/s", st).group(1)))]
 
 
-bench_rows(); config_rows(); phase_rows(); loop_rows()
+def general_kernel_rows():
+    """profiles/<tag>_general_kernels.txt: one launch each (the last of three) of the general-class workloads on the kernels of HEAD, on the
+    general kernels and on the bricks"""
+    lines = [l for l in text("general_kernels.txt").split("\n") if "photons/s" in l and "kernel photon_kernel" in l]
+    def rate(workload, *needles, absent=()):
+        for l in lines:
+            if l.startswith(workload + ":") and all(n in l for n in needles) and not any(a in l for a in absent):
+                return e(float(l.split(":")[1].split("photons/s")[0]))
+        raise SystemExit(f"general_kernels.txt: no line for {workload} {needles}")
+    rows["Landsat-119 + gas, flux, 5e7 photons: general flux kernel on records over a base profile (HEAD)"] = [rate("landsat119_gas", "GRID_COLBASE")]
+    rows["… on the bricks (the round-4 place of such a field)"] = [rate("landsat119_gas", "GRID_BRICKS")]
+    rows["Landsat-119 + gas + 7 directions, 1e7: widened-class kernel, records over a base profile (HEAD)"] = [rate("landsat119_gas_7dir", "wide")]
+    rows["… general radiance kernel, the same records"] = [rate("landsat119_gas_7dir", "true, true, GRID_COLBASE")]
+    rows["… general radiance kernel on the bricks (round 4)"] = [rate("landsat119_gas_7dir", "GRID_BRICKS")]
+    rows["Landsat-119 + 7 directions, irregular x / y grid, 1e7: widened-class kernel (HEAD)"] = [rate("landsat119_irregular_7dir", "wide")]
+    rows["… general radiance kernel (round 4)"] = [[rate("landsat119_irregular_7dir", "true, true")], [rate("landsat119_brdfgrid_7dir", "true, true")]]
+    rows["Landsat-119 + 7 directions, gridded surface, 1e7: widened-class kernel (HEAD)"] = [rate("landsat119_brdfgrid_7dir", "wide")]
+    rows["for comparison, the common class on the same scene: Landsat-119 flux, 5e7"] = [rate("landsat119", "table in LDS")]
+    rows["… Landsat-119 + 7 directions + uniform surface, 1e7"] = [rate("landsat119_7dir", "GRID_COLUMNS>")]
+
+
+bench_rows(); config_rows(); phase_rows(); loop_rows(); general_kernel_rows()
 lines = open(os.path.join(ROOT, "DESIGN.md")).read().split("\n")
 # the Fortran drivers end to end: two runs in the file; the row quotes both and carries the smaller one as its value
 dt = text("driver_timing.txt")
