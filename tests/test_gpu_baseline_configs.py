@@ -345,6 +345,44 @@ def test_tool_chain_les_stratocumulus_with_rayleigh_against_the_oracle(oracle, t
     g.finalize_Integrator()
 
 
+def test_tool_chain_three_component_column_against_the_oracle(oracle, tmp_path):
+    """The other domain of the reference's tool chain (Tools/Examples/cloudAndDust_to_domain.nml through PhysicalPropertiesToDomain,
+    tests/golden/tools_mixture.dom.gz): ONE column of eleven irregular layers with THREE components -- droplets (35 Mie entries), absorbing
+    dust (omega 0.87 ... 0.92, 35 entries) and molecular absorption with omega = 0 in every layer, so that a "scattering" by the third
+    component ends the photon (:642-649: the weight times omega is 0).  Fluxes, the absorbed profile layer by layer and a radiance
+    direction against the oracle; what comes in is reflected, transmitted or absorbed."""
+    from tests.test_fortran_shell import _tool_chain_domain
+    dom = M.read_Domain(_tool_chain_domain("mixture", tmp_path))
+    nz, ny, nx = dom.shape
+    assert (nz, ny, nx) == (11, 1, 1) and len(dom.components) == 3
+
+    def full(c, key, dtype):
+        a = np.zeros((nz, ny, nx), dtype)
+        z0 = c["zbase"] - 1
+        a[z0:z0 + c[key].shape[0]] = np.broadcast_to(c[key], (c[key].shape[0], ny, nx))
+        return a
+    d = dict(xe=dom.x, ye=dom.y, ze=dom.z, ext=[full(c, "ext", np.float32) for c in dom.components],
+             ssa=[full(c, "ssa", np.float32) for c in dom.components], pf=[full(c, "pfi", np.int32) for c in dom.components])
+    inv = [c["table"].inverse_table(10001) for c in dom.components]
+    fwd = [c["table"].forward_table(10001) for c in dom.components]
+    g = M.new_Integrator(dom)
+    g.specifyParameters(surfaceAlbedo=0.1, minInverseTableSize=10001, intensityMus=[0.8], intensityPhis=[30.0], useRussianRouletteForIntensity=True, zetaMin=0.3)
+    for k in range(3):
+        g.set_tables(k + 1, inverse=inv[k], forward=fwd[k], forward_orig=fwd[k])
+    o = make_oracle(oracle, d, inv, fwd, fwd)
+    o.specify(intensityMus=[0.8], intensityPhis=[30.0], useRRForIntensity=1, zetaMin=0.3, surfaceAlbedo=0.1)
+    gr, orr = _two_stage(oracle, g, o, 12, 50000, 0.6, ("fluxUp", "fluxDown", "fluxAbsorbed", "intensity"))
+    dz = np.diff(dom.z).astype(np.float64)
+    pg = np.array([(r["volumeAbsorption"].astype(np.float64)[:, 0, 0] * dz) for r in gr])
+    po = np.array([(r["volumeAbsorption"].astype(np.float64)[:, 0, 0] * dz) for r in orr])
+    tol = 3.0 * np.sqrt(pg.var(0, ddof=1) / len(gr) + po.var(0, ddof=1) / len(orr)) + 1e-6
+    assert np.all(np.abs(pg.mean(0) - po.mean(0)) <= 1.35 * tol), (pg.mean(0), po.mean(0), tol)     # (eleven layers at once: 4 sigma each)
+    assert pg.mean(0).min() > 0                                                                   # every layer absorbs: the gas is in all of them
+    up, dn, ab = (np.mean([float(r[k].mean()) for r in gr]) for k in ("fluxUp", "fluxDown", "fluxAbsorbed"))
+    assert abs(up + ab + dn * (1 - 0.1) - 1.0) < 3e-3 and ab > 0.05
+    g.finalize_Integrator()
+
+
 def test_config4_column_by_column_against_the_oracles_fixture():
     """Config 4 (Landsat 128 x 128 x 119 + 7 radiance directions + the surface object) COLUMN BY COLUMN against a fixture the oracle
     wrote in the build container (tests/golden/make_config4_columns.py: 48 batches of 5e5 photons, 2.4e7 in all -- thirty photons
