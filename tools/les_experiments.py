@@ -7,12 +7,13 @@ import i3rc_monte_carlo_model_amd as M
 from tools import workloads as W
 name, w = W.get("les_stcu_rayleigh")
 dom, d = W.domain_from_file(w)
-def run(label, comps, albedo=0.06, mu0=0.5, n=20_000_000):
+def run(label, comps, albedo=0.06, mu0=0.5, n=20_000_000, dirs=None):
     dm = M.new_Domain(dom.x, dom.y, dom.z)
     for c in comps:
         dm.addOpticalComponent(c["name"], c["ext"][:, 0, 0] if c["uniform"] else c["ext"], c["ssa"][:, 0, 0] if c["uniform"] else c["ssa"], c["pfi"][:, 0, 0] if c["uniform"] else c["pfi"], c["table"], zLevelBase=c["zbase"])
     g = M.new_Integrator(dm)
-    g.specifyParameters(surfaceAlbedo=albedo, minInverseTableSize=10001, useRayTracing=True, useRussianRoulette=True)
+    kw = dict(intensityMus=dirs[0], intensityPhis=dirs[1], useRussianRouletteForIntensity=True, zetaMin=0.3) if dirs else {}
+    g.specifyParameters(surfaceAlbedo=albedo, minInverseTableSize=10001, useRayTracing=True, useRussianRoulette=True, **kw)
     g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 0)), M.new_PhotonStream(mu0, 0.0, 1))
     for k in range(2):
         r = g.computeRadiativeTransfer(M.new_RandomNumberSequence((10, 1 + k)), M.new_PhotonStream(mu0, 0.0, n))
@@ -34,3 +35,6 @@ run("two components, a table of one entry", [single, gas])
 run("cloud only, 35-entry table", [cloud])
 run("cloud only, every cloudy cell entry 25", [one])
 run("cloud only, a table of one entry", [single])
+two = ([1.0, 0.6], [0.0, 135.0])
+run("two components + 2 radiance directions", [cloud, gas], n=10_000_000, dirs=two)
+run("two components + 2 radiance directions, omega -> 1", [lossless, gas], n=10_000_000, dirs=two)
