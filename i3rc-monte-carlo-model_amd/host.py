@@ -20,7 +20,7 @@ import numpy as np
 
 from . import binding as B
 from .binding import I3RCError, f32, pf
-from .phasefunctions import PI_MCRT, PhaseFunction, PhaseFunctionTable, hybrid_phase_functions, spacing
+from .phasefunctions import PI_MCRT, PhaseFunction, PhaseFunctionTable, hybrid_phase_functions, libm_f32, spacing
 
 r32 = np.float32  # scalar float32 (f32() from the binding makes contiguous ARRAYS)
 
@@ -292,7 +292,7 @@ class Integrator:
             for m, ph in zip(f32(kw["intensityMus"]), f32(kw["intensityPhis"])):
                 phr = r32(r32(ph * PI_MCRT) / r32(180.0))
                 st = np.sqrt(r32(1.0) - m * m, dtype=np.float32)
-                d.append([st * np.cos(phr, dtype=np.float32), st * np.sin(phr, dtype=np.float32), m])  # :2041-2059
+                d.append([st * libm_f32("cosf", phr), st * libm_f32("sinf", phr), m])  # :2041-2059 (libm: what the reference's cos / sin are)
             dirs = np.array(d, np.float32).reshape(-1, 3)
             self._check(self._lib.i3rc_hip_set_directions(self._h, len(d), pf(dirs)), "specifyParameters")
             self.intensityDirections = dirs      # (only once the device has taken them: a refusal leaves the object as it was)

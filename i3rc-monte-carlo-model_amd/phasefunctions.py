@@ -22,6 +22,24 @@ _libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
 _libm.sinf.restype = ctypes.c_float
 _libm.sinf.argtypes = [ctypes.c_float]
 _sinf = _libm.sinf
+for _name in ("cosf", "acosf", "expf", "logf"):
+    getattr(_libm, _name).restype = ctypes.c_float
+    getattr(_libm, _name).argtypes = [ctypes.c_float]
+
+
+def libm_f32(name, x):
+    """libm's float32 routine `name` -- the C library's cosf, sinf, ... which the reference's intrinsics are compiled to (amdflang and
+    gfortran alike); numpy's float32 routines are SIMD code of their own and differ from them in the last bit here and there.
+    Scalar or array in, float32 of the same shape out."""
+    f = getattr(_libm, name)
+    a = np.asarray(x, np.float32)
+    if a.ndim == 0:
+        return np.float32(f(float(a)))
+    return np.fromiter((f(float(v)) for v in a.ravel()), np.float32, a.size).reshape(a.shape)
+
+
+def cos32(x):
+    return libm_f32("cosf", x)
 
 
 def spacing(x):
@@ -144,7 +162,7 @@ class PhaseFunction:
             if np.any(self.values_ < 0):
                 raise ValueError("newPhaseFunction: Negative phase function values supplied.")
             # normalizePhaseFunction (:1329-1345): integral over cos(angle) = 2, as the constructors do (:145)
-            cosa = np.cos(self.angles).astype(np.float32)
+            cosa = cos32(self.angles)
             terms = (cosa[1:] - cosa[:-1]) * (f32(0.5) * (self.values_[1:] + self.values_[:-1]))
             dot = f32(0.0)
             for t in terms:
@@ -162,7 +180,7 @@ class PhaseFunction:
             c = self.legendre
             if c.size == 0:
                 return np.full(angles.shape, f32(0.5), np.float32)
-            P = legendre_polynomials(c.size, np.cos(angles).astype(np.float32))
+            P = legendre_polynomials(c.size, cos32(angles))
             wts = np.concatenate([[f32(1.0)], c * (2 * np.arange(1, c.size + 1) + 1).astype(np.float32)]).astype(np.float32)
             s = np.zeros(angles.shape, np.float32)
             for l in range(c.size + 1):
@@ -175,8 +193,8 @@ def _interp_tabulated(tab_angles, tab_values, angles, chained_guess):
     """Linear interpolation in cos(angle) (:497-524 and :581-609)."""
     n = tab_angles.size
     out = np.empty(angles.size, np.float32)
-    cos_tab = np.cos(tab_angles).astype(np.float32)
-    cos_a = np.cos(angles).astype(np.float32)
+    cos_tab = cos32(tab_angles)
+    cos_a = cos32(angles)
     prev = 0
     huge = np.finfo(np.float32).max
     for i, a in enumerate(angles):
@@ -223,7 +241,7 @@ class PhaseFunctionTable:
                 if c.size == 0:
                     out.append(np.full(n_steps, f32(0.5), np.float32))
                     continue
-                P = legendre_polynomials(c.size, np.cos(angles).astype(np.float32))
+                P = legendre_polynomials(c.size, cos32(angles))
                 s = np.zeros(n_steps, np.float32)
                 for l in range(c.size + 1):
                     cl = f32(1.0) if l == 0 else c[l - 1]
@@ -239,11 +257,11 @@ def inverse_phase_function(p, n_steps):
     if p.stored_as_legendre:
         n = max(p.legendre.size, 2)
         mus, _ = lobatto(n)
-        vals = p.values(np.arccos(mus[::-1]).astype(np.float32))[::-1].copy()
+        vals = p.values(libm_f32("acosf", mus[::-1]))[::-1].copy()
     else:
         n = p.angles.size
         vals = p.values(p.angles)[::-1].copy()
-        mus = np.cos(p.angles[::-1]).astype(np.float32)
+        mus = cos32(p.angles[::-1])
     incr = ((mus[1:] - mus[:-1]) * f32(0.5)) * (vals[1:] + vals[:-1])
     cdf = np.concatenate([[f32(0.0)], np.cumsum(incr, dtype=np.float32)]).astype(np.float32)
     cdf = (cdf / cdf[-1]).astype(np.float32)
@@ -263,7 +281,7 @@ def inverse_phase_function(p, n_steps):
         rad = ((c1 - pr) * (v0 * v0) + (pr - c0) * (v1 * v1)) / (c1 - c0)
         a_gen = m0 + (m1 - m0) / (v0 - v1) * (v0 - np.sqrt(rad, dtype=np.float32))
         arg = np.where(flat, a_flat, np.where(const, a_const, a_gen)).astype(np.float32)
-        table = np.arccos(arg).astype(np.float32)
+        table = libm_f32("acosf", arg)
     return np.concatenate([table, [f32(0.0)]]).astype(np.float32)
 
 
@@ -274,9 +292,9 @@ def hybrid_phase_functions(values, width_deg):
     values = np.atleast_2d(np.asarray(values, np.float32))
     n = values.shape[1]
     angles = ((np.arange(n, dtype=np.float32) / f32(n - 1)) * PI_MCRT).astype(np.float32)
-    cos_a = np.cos(angles).astype(np.float32)
+    cos_a = cos32(angles)
     w = f32(width_deg) * PI_MCRT / f32(180.0)
-    gau = np.exp(-((angles / w) ** 2)).astype(np.float32)
+    gau = libm_f32("expf", (-((angles / w) ** 2)).astype(np.float32))
     dcos = (cos_a[:-1] - cos_a[1:]).astype(np.float32)
     new = values.copy()
 

@@ -90,6 +90,19 @@ def lib():
     return _lib
 
 
+def _libm_f(name, x):
+    """libm's float32 routine `name` at x (the C library the reference's intrinsics are compiled to)"""
+    import ctypes.util
+    global _LIBM
+    try:
+        _LIBM
+    except NameError:
+        _LIBM = C.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+    f = getattr(_LIBM, name)
+    f.restype, f.argtypes = C.c_float, [C.c_float]
+    return np.float32(f(float(x)))
+
+
 def _f(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
@@ -279,7 +292,9 @@ class Integrator:
             for m, ph in zip(mus, phis):
                 phr = np.float32(np.float32(ph * pi) / np.float32(180.0))
                 st = np.sqrt(np.float32(1.0) - m * m, dtype=np.float32)
-                d.append([st * np.float32(np.cos(phr, dtype=np.float32)), st * np.float32(np.sin(phr, dtype=np.float32)), m])
+                # (libm's cosf / sinf, which the reference's cos / sin end in: numpy's float32 routines are SIMD code of their own and
+                # differ from them in the last bit here and there -- enough to move a ray: tests/test_ref_loop.py)
+                d.append([st * _libm_f("cosf", phr), st * _libm_f("sinf", phr), m])
             self.dirs = np.array(d, np.float32).reshape(-1, 3)
         if "surfaceBDRF" in kw:
             xs, ys, alb = kw.pop("surfaceBDRF")

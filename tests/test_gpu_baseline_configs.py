@@ -330,17 +330,24 @@ def test_tool_chain_les_stratocumulus_with_rayleigh_against_the_oracle(oracle, t
     fwd = [c["table"].forward_table(10001) for c in dom.components]
     mus, phis = [1.0, 0.6], [0.0, 135.0]
     g = M.new_Integrator(dom)
+    # (the droplets' forward peak is 3e4: a plain local estimate of such a phase function has a long-tailed error, which twelve batches do not
+    # measure.  The reference's own remedy -- hybrid phase functions, a Gaussian peak of 7 degrees for every order of scattering,
+    # :1925-1998 -- is what a user of such a table would switch on, and what both sides estimate with here.)
+    hyb = [oracle.hybrid_tables(f, 7.0) for f in fwd]
     g.specifyParameters(surfaceAlbedo=0.06, minInverseTableSize=10001, intensityMus=mus, intensityPhis=phis,
-                        useRussianRouletteForIntensity=True, zetaMin=0.3)
+                        useRussianRouletteForIntensity=True, zetaMin=0.3, useHybridPhaseFunsForIntenCalcs=True, hybridPhaseFunWidth=7.0,
+                        numOrdersOrigPhaseFunIntenCalcs=0)
     for k in range(len(dom.components)):
-        g.set_tables(k + 1, inverse=inv[k], forward=fwd[k], forward_orig=fwd[k])
-    o = make_oracle(oracle, d, inv, fwd, fwd)
-    o.specify(intensityMus=mus, intensityPhis=phis, useRRForIntensity=1, zetaMin=0.3, surfaceAlbedo=0.06)
-    gr, orr = _two_stage(oracle, g, o, 12, 50000, 0.5, ("fluxUp", "fluxDown", "fluxAbsorbed", "intensity"), per_direction=True)
+        g.set_tables(k + 1, inverse=inv[k], forward=hyb[k], forward_orig=fwd[k])
+    o = make_oracle(oracle, d, inv, hyb, fwd)
+    o.specify(intensityMus=mus, intensityPhis=phis, useRRForIntensity=1, zetaMin=0.3, surfaceAlbedo=0.06, useHybrid=1, numOrdersOrig=0)
+    # (at the largest sample -- 1e7 photons against 2.4e6, tests/manual/les_parity_large.py, profiles/r05_parity_large_les.txt -- the five means
+    # agree within 1.4 combined standard errors of 0.1 ... 0.5 %)
+    gr, orr = _two_stage(oracle, g, o, 16, 100000, 0.5, ("fluxUp", "fluxDown", "fluxAbsorbed", "intensity"), per_direction=True)
     assert "wide" in g.kernel_name(), g.kernel_name()
     # the same work on both sides: scatterings per photon (the Mie table's entries are chosen per cell, the gas by the compare chain)
-    kg = sum(r["counters"]["scatterings"] for r in gr) / (len(gr) * 50000)
-    ko = sum(r["scatterings"] for r in orr) / (len(orr) * 50000)
+    kg = sum(r["counters"]["scatterings"] for r in gr) / (len(gr) * 100000)
+    ko = sum(r["scatterings"] for r in orr) / (len(orr) * 100000)
     assert abs(kg - ko) < 0.02 * ko, (kg, ko)
     g.finalize_Integrator()
 
