@@ -36,6 +36,15 @@ if __name__ == "__main__":
             if any(isinstance(e, tuple) for e in comp["coefficients"]):
                 out[f"{name}/tables{c}/inverse"], out[f"{name}/tables{c}/forward"] = t["inverse"], t["forward"]
         print(name, "fluxUp", float(batches[0]["fluxUp"].mean()), "fluxDown", float(batches[0]["fluxDown"].mean()))
+    for name, case in R.big_cases().items():        # BASELINE.json's configurations at their full grids: a hash per field
+        with tempfile.TemporaryDirectory() as tmp:
+            batches, _ = R.run(case, tmp)
+        for b, res in enumerate(batches):
+            for k, v in res.items():
+                out[f"{name}/batch{b}/{k}/sha256"] = np.array(hashlib.sha256(np.ascontiguousarray(v, np.float32).tobytes()).hexdigest())
+        out[f"{name}/means"] = np.array([[float(r[k].mean(dtype=np.float64)) for k in ("fluxUp", "fluxDown")] for r in batches])
+        print(name, "fluxUp", float(batches[0]["fluxUp"].mean()), "fluxDown", float(batches[0]["fluxDown"].mean()))
+    out["big_cases"] = np.array(sorted(R.big_cases()))
     path = os.path.join(HERE, "ref_loop.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

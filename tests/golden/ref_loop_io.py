@@ -1,82 +1,13 @@
-"""The case / result files of oracle/_ref/ref_loop (oracle/ref_loop.f95's header has the layout): writer, reader, runner.
-Test infrastructure, shared by tests/golden/make_ref_loop.py (which runs the reference's loop, build container only) and the tests."""
-import os
-import subprocess
-
+"""The problems of tests/golden/ref_loop.npz (the reference's own photon loop: oracle/ref_loop.f95); the file formats and the runner are
+oracle/ref_loop_io.py's."""
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-REF_LOOP = os.path.join(ROOT, "oracle", "_ref", "ref_loop")
-f4, i4 = np.dtype("<f4"), np.dtype("<i4")
-
-DEFAULTS = dict(surfaceAlbedo=0.0, useRayTracing=1, useRussianRoulette=1, useRRForIntensity=0, zetaMin=0.3, useHybrid=0, hybridWidth=7.0,
-                numOrdersOrig=0, limitContrib=0, maxContrib=77.0, nInverse=10001, nForward=10001, mus=(), phis=(), surface=None,
-                solarMu=1.0, solarAzimuth=0.0, nBatches=2, nPhotons=10000, seed=(10, 1), dumpTables=1)
+from oracle.ref_loop_io import DEFAULTS, REF_LOOP, ROOT, read_result, run, write_case  # noqa: F401
+import oracle.ref_loop_io as _io
 
 
-def write_case(path, case):
-    """case: dict(xe, ye, ze, components=[dict(coefficients=[array, ...], ext[z,y,x], ssa, pf)], **DEFAULTS overrides)"""
-    c = dict(DEFAULTS, **case)
-    nz, ny, nx = c["components"][0]["ext"].shape
-    with open(path, "wb") as f:
-        def w(a, t):
-            f.write(np.ascontiguousarray(a, t).tobytes())
-        w([nx, ny, nz, len(c["components"])], i4)
-        w(c["xe"], f4), w(c["ye"], f4), w(c["ze"], f4)
-        for comp in c["components"]:
-            w([len(comp["coefficients"])], i4)
-            for coef in comp["coefficients"]:                                     # Legendre coefficients, or (angles, values) of a tabulated one
-                if isinstance(coef, tuple):
-                    w([-len(coef[0])], i4), w(coef[0], f4), w(coef[1], f4)
-                else:
-                    w([len(coef)], i4), w(coef, f4)
-            w(comp["ext"], f4), w(comp["ssa"], f4), w(comp["pf"], i4)          # [z][y][x] in C order = (x, y, z) in Fortran order
-        w([c["surfaceAlbedo"]], f4), w([c["useRayTracing"], c["useRussianRoulette"], c["useRRForIntensity"]], i4), w([c["zetaMin"]], f4)
-        w([c["useHybrid"]], i4), w([c["hybridWidth"]], f4), w([c["numOrdersOrig"], c["limitContrib"]], i4), w([c["maxContrib"]], f4)
-        w([c["nInverse"], c["nForward"], len(c["mus"])], i4), w(c["mus"], f4), w(c["phis"], f4)
-        if c["surface"] is None:
-            w([0, 0], i4)
-        else:
-            xs, ys, refl = c["surface"]                                           # refl[y][x]
-            w([len(xs) - 1, len(ys) - 1], i4), w(xs, f4), w(ys, f4), w(refl, f4)
-        w([c["solarMu"], c["solarAzimuth"]], f4), w([c["nBatches"], c["nPhotons"], c["seed"][0], c["seed"][1], c["dumpTables"]], i4)
-    return c
-
-
-def read_result(path, c):
-    nz, ny, nx = c["components"][0]["ext"].shape
-    nd = len(c["mus"])
-    raw = np.fromfile(path, f4)
-    at = 0
-
-    def take(*shape):
-        nonlocal at
-        n = int(np.prod(shape))
-        out = raw[at:at + n].reshape(shape).copy()
-        at += n
-        return out
-    batches = []
-    for _ in range(c["nBatches"]):
-        b = dict(fluxUp=take(ny, nx), fluxDown=take(ny, nx), fluxAbsorbed=take(ny, nx), absorbedProfile=take(nz), volumeAbsorption=take(nz, ny, nx))
-        if nd:
-            b["intensity"] = take(nd, ny, nx)
-        batches.append(b)
-    tables = []
-    if c["dumpTables"]:
-        for comp in c["components"]:
-            ne = len(comp["coefficients"])
-            tables.append(dict(inverse=take(ne, c["nInverse"]), forward=take(ne, c["nForward"])))
-    assert at == raw.size, (at, raw.size)
-    return batches, tables
-
-
-def run(case, directory):
-    cf, rf = os.path.join(directory, "case.bin"), os.path.join(directory, "result.bin")
-    c = write_case(cf, case)
-    r = subprocess.run([REF_LOOP, cf, rf], capture_output=True, text=True, timeout=1800)
-    if r.returncode != 0:
-        raise RuntimeError(f"ref_loop failed: {r.stdout}\n{r.stderr}")
-    return read_result(rf, c)
+def __getattr__(name):   # (REF_LOOP is a setting of the runner: tests point it at the shell's build of the same caller)
+    return getattr(_io, name)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -119,3 +50,21 @@ def cases():
     crop = dict(xe=d["xe"][:33], ye=d["ye"][:33], ze=d["ze"], ext=d["ext"][:, 40:72, 40:72].copy(), ssa=d["ssa"][:, 40:72, 40:72].copy(), pf=d["pf"][:, 40:72, 40:72].copy())
     out["landsat_crop_7dir"] = one(crop, hg299, solarMu=0.5, surfaceAlbedo=0.2, useRRForIntensity=1, nPhotons=5000, **dirs7)
     return out
+
+
+def big_cases():
+    """BASELINE.json's configurations at their full grids (the fixture holds the SHA-256 of each field, not the field)"""
+    from oracle import pyoracle as O
+    from tools import cases as K
+
+    hg64, hg299 = O.hg_coefficients(0.85, 64), O.hg_coefficients(0.85, 299)
+    dirs7 = dict(mus=[1.0, 0.5, 0.5, 0.8, 0.8, 0.3, 0.3], phis=[0.0, 0.0, 180.0, 90.0, 270.0, 45.0, 225.0])
+
+    def one(d, coef, **kw):
+        return dict(xe=d["xe"], ye=d["ye"], ze=d["ze"], components=[dict(coefficients=[coef], ext=d["ext"], ssa=d["ssa"], pf=d["pf"])], dumpTables=0, **kw)
+    return {"config0_step32": one(K.step_cloud(nlayers=32), hg64, solarMu=0.5, nPhotons=100000),                          # the reference generator's own shape
+            "config2_radar64_nadir": one(K.radar_cloud_64(), hg299, mus=[1.0], phis=[0.0], useRRForIntensity=1, nPhotons=20000),
+            "config3_landsat36": one(K.landsat_cloud(nlayers=36), hg299, nPhotons=50000),
+            "config4_landsat119_7dir": one(K.landsat_cloud(), hg299, solarMu=0.5, useRRForIntensity=1, nPhotons=10000,
+                                           surface=(np.array([0.0, np.finfo(np.float32).max], np.float32), np.array([0.0, np.finfo(np.float32).max], np.float32),
+                                                    np.array([[0.2]], np.float32)), **dirs7)}

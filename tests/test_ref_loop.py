@@ -97,6 +97,32 @@ def test_oracle_equals_the_references_own_loop_bit_for_bit(oracle, fixture, name
         assert fixture[f"{name}/batch0/fluxUp"].mean() > 0.1
 
 
+@pytest.mark.parametrize("name", sorted(R.big_cases()))
+def test_oracle_equals_the_references_loop_on_the_baseline_configurations(oracle, fixture, name):
+    """BASELINE.json's configurations at their FULL grids -- the step cloud in the reference generator's shape (32 x 1 x 32, mu0 = 0.5),
+    radar-64 + nadir radiance, Landsat 128 x 128 x 36, Landsat 128 x 128 x 119 + seven directions over the uniform surface OBJECT -- two
+    batches each through the reference's own loop: the fixture holds the SHA-256 of every field it handed out (the fields are up to 1.9
+    million cells), and the oracle's fields hash the same."""
+    O = oracle
+    c = dict(R.DEFAULTS, **R.big_cases()[name])
+    nd = len(c["mus"])
+    comp = c["components"][0]
+    inv, fwd = _oracle_tables(O, comp["coefficients"], c["nInverse"], c["nForward"])
+    o = O.Integrator(c["xe"], c["ye"], c["ze"], comp["ext"], comp["ssa"], comp["pf"], [inv], [fwd] if nd else None, [fwd] if nd else None)
+    kw = dict(surfaceAlbedo=c["surfaceAlbedo"])
+    if nd:
+        kw.update(intensityMus=list(c["mus"]), intensityPhis=list(c["phis"]), useRRForIntensity=c["useRRForIntensity"], zetaMin=c["zetaMin"])
+    if c["surface"] is not None:
+        kw.update(surfaceBDRF=c["surface"])
+    o.specify(**kw)
+    for b in range(c["nBatches"]):
+        rng = O.RandomNumberSequence([c["seed"][0], c["seed"][1] + b])
+        r = o.compute(rng, *O.photons_directional(rng, c["solarMu"], c["solarAzimuth"], c["nPhotons"]))
+        assert abs(float(r["fluxUp"].mean(dtype=np.float64)) - fixture[f"{name}/means"][b][0]) < 1e-9
+        for key in ("fluxUp", "fluxDown", "fluxAbsorbed", "volumeAbsorption") + (("intensity",) if nd else ()):
+            assert _sha(r[key]) == str(fixture[f"{name}/batch{b}/{key}/sha256"]), (name, b, key)
+
+
 def test_python_mirror_tables_equal_the_references(fixture):
     """phasefunctions.py (the tables the GPU tests hand to the device): every Legendre table of the fixture, bit for bit -- with libm's
     cosf / acosf / expf where the reference's intrinsics end in them (numpy's float32 routines differ in the last bit here and there:
@@ -126,7 +152,8 @@ def test_shell_tables_equal_the_references(fixture, tmp_path):
     shell_loop = os.path.join(R.ROOT, "i3rc-monte-carlo-model_amd", "fortran", "build", "shellLoop")
     if not os.path.exists(shell_loop):
         pytest.skip("the shell is not built")
-    saved, R.REF_LOOP = R.REF_LOOP, shell_loop
+    import oracle.ref_loop_io as io
+    saved, io.REF_LOOP = io.REF_LOOP, shell_loop
     try:
         for name in ("step16", "two_components", "radar640_nadir", "radar640_c1"):
             case = dict(R.cases()[name], nBatches=0)
@@ -138,4 +165,4 @@ def test_shell_tables_equal_the_references(fixture, tmp_path):
                 else:
                     assert [_sha(t["inverse"]), _sha(t["forward"])] == [str(v) for v in fixture[f"{name}/tables{k}/sha256"]], (name, k)
     finally:
-        R.REF_LOOP = saved
+        io.REF_LOOP = saved

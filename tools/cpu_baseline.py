@@ -2,9 +2,11 @@
 computeRT) on the host cores of the box, one process per core over disjoint batches -- the reference's own
 decomposition (Example-Drivers/monteCarloDriver.f95:264-274).  Never touches the GPU.  Prints one JSON line.
 
-kind "port": this is the C restatement, NOT the reference's Fortran (the reference cannot be built in this image:
-netCDF-Fortran is absent).  `reference_note` carries the survey-time figure of the reference
-itself for the nearest shape, so that the two can be set side by side."""
+kind "port": this is the C restatement, NOT the reference's Fortran (netCDF-Fortran is absent from this image and the rules call
+a reference that needs it unbuildable: DESIGN.md section 2).  `reference_note` carries the survey-time figure of the reference
+itself for the nearest shape; `reference_loop` (round 5) is the reference's own loop timed HERE, on one core,
+beside the port on the same batches -- oracle/_ref/ref_loop, the reference's sources unmodified over this repository's netCDF module --
+where the tree holds that binary: the ratio of the two is the calibration, and their fields are compared bit for bit on the way."""
 import argparse
 import json
 import os
@@ -62,6 +64,50 @@ def _worker(args):
     return time.perf_counter() - t0, fu / n_batches, cols
 
 
+def reference_loop_rate(name, w, photons):
+    """The REFERENCE'S OWN loop on this workload, one core: oracle/_ref/ref_loop (the whole of the reference's Code/ and its integrator
+    compiled unmodified over this repository's netCDF module -- oracle/ref_loop.f95 says what that build is), where the tree holds it and
+    the workload is one it can be handed (Henyey-Greenstein components from recipes, a uniform surface), timed beside the port on the
+    SAME batches on the same core: the ratio bench.py's calibration used to take from survey-time figures.  None where it cannot be run."""
+    import tempfile
+
+    import numpy as np
+
+    from oracle import pyoracle as O
+    from oracle import ref_loop_io as R
+    from tools import workloads as W
+
+    if not os.path.exists(R.REF_LOOP) or "domain_file" in w or "surface_grid" in w or "irregular" in w:
+        return None
+    d = W.domain(w)
+    comps = [dict(coefficients=[O.hg_coefficients(0.85, w["moments"])], ext=d["ext"], ssa=d["ssa"], pf=d["pf"])]
+    if "gas" in w:
+        gas = W.gas_component(w, d)
+        comps.append(dict(coefficients=[np.array(W.GAS_LEGENDRE, np.float32)], ext=gas, ssa=np.full_like(gas, np.float32(w.get("gas_ssa", 1.0))), pf=np.ones(gas.shape, np.int32)))
+    p = w["params"]
+    case = dict(xe=d["xe"], ye=d["ye"], ze=d["ze"], components=comps, solarMu=w["mu0"], nBatches=2, nPhotons=int(photons), seed=(10, 1), dumpTables=0,
+                mus=p.get("intensityMus", ()), phis=p.get("intensityPhis", ()), useRRForIntensity=int(bool(p.get("useRussianRouletteForIntensity"))), zetaMin=p.get("zetaMin", 0.3))
+    if "surface" in w:
+        huge = np.finfo(np.float32).max
+        case["surface"] = (np.array([0.0, huge], np.float32), np.array([0.0, huge], np.float32), np.array([[w["surface"]]], np.float32))
+    with tempfile.TemporaryDirectory() as tmp:
+        # a first call of one photon per batch: tables and start-up, taken off the timed call's wall time
+        t0 = time.perf_counter(); R.run(dict(case, nPhotons=1), tmp); setup = time.perf_counter() - t0
+        t0 = time.perf_counter(); batches, _ = R.run(case, tmp); ref_s = time.perf_counter() - t0 - setup
+    integ, _ = W.make_oracle(w)
+    t0 = time.perf_counter()
+    same = True
+    for b in range(2):
+        rng = O.RandomNumberSequence([10, 1 + b])
+        r = integ.compute(rng, *O.photons_directional(rng, w["mu0"], 0.0, int(photons)))
+        same = same and np.array_equal(r["fluxUp"], batches[b]["fluxUp"]) and np.array_equal(r["fluxDown"], batches[b]["fluxDown"])
+    port_s = time.perf_counter() - t0
+    return {"photons_per_s_per_core": 2 * photons / max(ref_s, 1e-9), "port_photons_per_s_per_core_same_batches": 2 * photons / port_s,
+            "port_over_reference": ref_s / port_s, "fields_bit_identical": bool(same),
+            "what": "oracle/_ref/ref_loop: the reference's Code/ + integrator, unmodified, amdflang -O2, over this repository's netCDF module; "
+                    f"2 batches x {int(photons)} photons of this workload on one core, start-up and tables taken off"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="step16")
@@ -109,7 +155,11 @@ def main():
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown CPU"
-    print(json.dumps({"value": total / busy, "unit": "photons/s", "cores": cores, "kind": "port",
+    try:
+        reference_loop = reference_loop_rate(name, w, photons)
+    except Exception as e:   # noqa: BLE001  (a report beside the baseline, never a reason to lose it)
+        reference_loop = {"error": str(e)[:200]}
+    print(json.dumps({"value": total / busy, "unit": "photons/s", "cores": cores, "kind": "port", "reference_loop": reference_loop,
                       "sample": f"{cores} processes x {a.batches_per_core} batches x {photons} photons of the same workload "
                                 f"({name}), max busy time {busy:.1f} s, wall {wall:.1f} s, host {model}",
                       "per_core": total / busy / cores, "oracle_per_photon": per_photon,
