@@ -420,7 +420,9 @@ contains
     type(domain),       intent(in   ) :: thisDomain
     character(len = *), intent(in   ) :: fileName
     type(ErrorMessage), intent(inout) :: status
-    integer :: rc(12), ncid, xE, yE, zE, xG, yG, zG, zDim, v, c, nc, flagXY, flagZ
+    integer :: rc(12), ncid, xE, yE, zE, xG, yG, zG, zDim, v, c, nc
+    integer(kind = selected_int_kind(2)) :: flagXY, flagZ   ! (one-byte attributes, as the reference's asInt makes them, :593-594, :1018-1022:
+                                                            !  its own write_Domain over this netCDF module gives this writer's bytes)
     integer, dimension(:), allocatable :: extVar, ssaVar, idxVar
 
     if(.not. isValid(thisDomain)) then

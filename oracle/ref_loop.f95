@@ -11,7 +11,7 @@
 ! itself; it is what it is: the reference's loop, every line of it, run here, for oracle/integrator.c to be held against
 ! (tests/golden/make_ref_loop.py -> tests/golden/ref_loop.npz, tests/test_ref_loop.py).
 !
-! usage: ref_loop <case file> <result file>      both little-endian streams of 4-byte words:
+! usage: ref_loop <case file> <result file> [<domain file to write> [<domain file to read back>]]      case and result: little-endian streams of 4-byte words:
 !   case:   nx ny nz ncomp | xEdges yEdges zEdges | per component: nEntries, per entry (nCoef, coef(1:nCoef) -- or -n, angles(n), values(n)), ext(nx,ny,nz),
 !           ssa(nx,ny,nz), phaseFunctionIndex(nx,ny,nz) | surfaceAlbedo useRayTracing useRussianRoulette
 !           useRussianRouletteForIntensity zetaMin useHybrid hybridWidth numOrdersOrig limitContributions maxContribution
@@ -30,7 +30,7 @@ program refLoop
   use monteCarloRadiativeTransfer
   implicit none
 
-  character(len = 512) :: caseFile, resultFile
+  character(len = 512) :: caseFile, resultFile, domainFile
   integer :: nx, ny, nz, ncomp, c, e, nEntries, nCoef, b, k
   integer :: useRT, useRR, useRRI, useHybrid, numOrdersOrig, limitC, nInv, nFwd, nDir, nxs, nys
   integer :: nBatches, nPhotons, seed1, seed2, dumpTables
@@ -88,6 +88,20 @@ program refLoop
     call addOpticalComponent(theDomain, "component", ext, ssa, pf, tables(c), status = status)
     call check("addOpticalComponent")
   end do
+
+  ! a third argument: the domain as a file (write_Domain, Code/opticalProperties.f95:554-706) -- and a fourth: that file read back
+  ! (read_Domain, :708-871) into the domain the rest of the program goes on with
+  if(command_argument_count() >= 3) then
+    call get_command_argument(3, domainFile)
+    call write_Domain(theDomain, trim(domainFile), status)
+    call check("write_Domain")
+  end if
+  if(command_argument_count() >= 4) then
+    call get_command_argument(4, domainFile)
+    call finalize_Domain(theDomain)
+    call read_Domain(trim(domainFile), theDomain, status)
+    call check("read_Domain")
+  end if
 
   read(10) albedo, useRT, useRR, useRRI, zetaMin, useHybrid, hybridWidth, numOrdersOrig, limitC, maxContribution, nInv, nFwd, nDir
   allocate(mus(nDir), phis(nDir))
@@ -171,15 +185,3 @@ contains
     end if
   end subroutine check
 end program refLoop
-
-! The reference does not link as it is shipped: Code/monteCarloIllumination.f95:17-19 imports ErrorMessages with an only-list that
-! lacks setStateToWarning and calls it all the same (:266, :268, :374-379: the flux / intensity / spotlight streams' checks), which
-! leaves an EXTERNAL reference `setstatetowarning_` in its object.  This is that external -- it hands on to the module procedure it
-! was meant to be; a Directional stream, the only kind this program makes, never gets there.
-subroutine setStateToWarning(messageVariable, messageText)
-  use ErrorMessages, only: ErrorMessage, moduleProcedure => setStateToWarning
-  implicit none
-  type(ErrorMessage), intent(inout) :: messageVariable
-  character(len = *), intent(in)    :: messageText
-  call moduleProcedure(messageVariable, messageText)
-end subroutine setStateToWarning

@@ -628,6 +628,19 @@ def test_photon_stream_constructors_equal_the_oracles_bit_for_bit(shell_built, o
         mine = np.array(got[name], dtype=np.uint32)
         assert mine.shape == (n, 5), (name, mine.shape)
         assert np.array_equal(mine, bits), (name, np.argwhere(mine != bits)[:5])
+    # ... and both against the REFERENCE'S OWN constructors: the same dump program compiled against the reference's unmodified
+    # Code/monteCarloIllumination.f95 (oracle/_ref/ref_streams; tests/golden/make_ref_photon_streams.py), 500 photons a stream
+    # (a stream draws its deviates array by array: its first 500 photons depend on how many it has)
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "ref_photon_streams.npz"))
+    assert sorted(ref.files) == sorted(want)
+    r = _run([os.path.join(shell_built, "dumpPhotonStreams"), str(len(ref["flux"]))])
+    assert r.returncode == 0, r.stdout + r.stderr
+    shell = {}
+    for line in r.stdout.splitlines():
+        f = line.split()
+        shell.setdefault(f[0], []).append([int(h, 16) for h in f[2:7]])
+    for name in want:
+        assert np.array_equal(ref[name], np.array(shell[name], dtype=np.uint32)), name
 
 
 def _gpu_count():

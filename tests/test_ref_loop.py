@@ -166,3 +166,29 @@ def test_shell_tables_equal_the_references(fixture, tmp_path):
                     assert [_sha(t["inverse"]), _sha(t["forward"])] == [str(v) for v in fixture[f"{name}/tables{k}/sha256"]], (name, k)
     finally:
         io.REF_LOOP = saved
+
+
+@pytest.mark.skipif(not os.path.exists(R.REF_LOOP), reason="the reference's loop is built in the build container only")
+def test_domain_files_of_the_reference_and_of_the_shell_are_the_same_bytes(tmp_path):
+    """SURVEY.md 8f row 1, which the reference itself could not pin (it ships no domain file): the reference's OWN write_Domain
+    (Code/opticalProperties.f95:554-706, with add_PhaseFunctionTable of Code/scatteringPhaseFunctions.f95) and the shell's, each over the
+    same netCDF-classic module, write the SAME BYTES for the same domain -- dimensions, variables, attributes and their types in the same
+    order (the pin found the shell writing the two regular-spacing flags as 4-byte integers where the reference's asInt makes them one
+    byte) --, and each side's read_Domain takes the other's file: the tables made from the domain read back are the same bits."""
+    import subprocess
+
+    shell = os.path.join(R.ROOT, "i3rc-monte-carlo-model_amd", "fortran", "build", "shellLoop")
+    if not os.path.exists(shell):
+        pytest.skip("the shell is not built")
+    for name in ("step16", "two_components", "irregular_ground", "radar640_nadir"):
+        case = dict(R.cases()[name], nBatches=0)
+        cf = str(tmp_path / f"{name}.case")
+        R.write_case(cf, case)
+        for who, exe in (("ref", R.REF_LOOP), ("shell", shell)):
+            r = subprocess.run([exe, cf, str(tmp_path / f"{who}.out"), str(tmp_path / f"{who}.dom")], capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, (name, who, r.stdout, r.stderr)
+        assert (tmp_path / "ref.dom").read_bytes() == (tmp_path / "shell.dom").read_bytes(), name
+        for who, exe, other in (("ref", R.REF_LOOP, "shell.dom"), ("shell", shell, "ref.dom")):
+            r = subprocess.run([exe, cf, str(tmp_path / f"{who}2.out"), str(tmp_path / f"{who}2.dom"), str(tmp_path / other)], capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, (name, who, r.stdout, r.stderr)
+            assert (tmp_path / f"{who}2.out").read_bytes() == (tmp_path / f"{who}.out").read_bytes(), (name, who)
