@@ -1,0 +1,49 @@
+"""Makes tests/golden/ref_driver_*.nc: the result files of THE WHOLE REFERENCE -- Example-Drivers/monteCarloDriver.f95 on the reference's
+own integrator and modules, all unmodified (oracle/Makefile, target _ref_loop: oracle/_ref/ref_driver; what that build is:
+oracle/ref_loop.f95's header) -- for BASELINE.json's CPU-reference configuration, the I3RC step cloud as the reference's generator makes it
+(32 x 1 x 32): sun at the zenith, conservative, with the nadir radiance; and sun at 60 degrees, omega = 0.99, over a surface of albedo 0.2.
+Two hundred batches of 1e5 photons each (2e7 photons: eight minutes of the reference on one core) (the driver's batch / seed scheme, monteCarloDriver.f95:264-326), written by the driver's own
+writeResults_netcdf (:609-854).  The GPU tests run the shell's driver on the same decks and compare column by column.
+Only runs where /root/reference exists.   usage: python3 tests/golden/make_ref_driver.py"""
+import os
+import shutil
+import subprocess
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+BUILD = os.path.join(ROOT, "i3rc-monte-carlo-model_amd", "fortran", "build")
+
+DECK = """&radiativeTransfer
+  solarFlux = 1., solarMu = {mu0}, solarAzimuth = 0., surfaceAlbedo = {albedo}, intensityMus = 1., intensityPhis = 0. /
+&monteCarlo
+  numPhotonsPerBatch = 100000, numBatches = 200, iseed = 10, nPhaseIntervals = 10001 /
+&algorithms
+  useRayTracing = .true., useRussianRoulette = .true., useRussianRouletteForIntensity = .true., zetaMin = 0.3,
+  useHybridPhaseFunsForIntenCalcs = .false., hybridPhaseFunWidth = 7., numOrdersOrigPhaseFunIntenCalcs = 0,
+  limitIntensityContributions = .false., maxIntensityContribution = 77. /
+&output
+  reportVolumeAbsorption = .false., reportAbsorptionProfile = .true. /
+&fileNames
+  domainFileName = "{dom}", outputNetcdfFile = "{out}" /
+"""
+CASES = {"stepcloud_mu1": dict(ssa="1.0", mu0="1.", albedo="0."), "stepcloud_mu05_absorbing": dict(ssa="0.99", mu0="0.5", albedo="0.2")}
+
+
+def deck(case, dom, out):
+    return DECK.format(mu0=CASES[case]["mu0"], albedo=CASES[case]["albedo"], dom=dom, out=out)
+
+
+if __name__ == "__main__":
+    if not os.path.isdir("/root/reference/Example-Drivers"):
+        raise SystemExit("needs /root/reference")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "_ref_loop"])
+    for case, c in CASES.items():
+        with tempfile.TemporaryDirectory() as tmp:
+            dom, out, nml = os.path.join(tmp, "step.dom"), os.path.join(tmp, "results.nc"), os.path.join(tmp, "deck.nml")
+            subprocess.check_call([os.path.join(BUILD, "makeStepCloudDomain"), dom, "32", c["ssa"]], stdout=subprocess.DEVNULL)
+            open(nml, "w").write(deck(case, dom, out))
+            r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_driver"), nml], capture_output=True, text=True, cwd=tmp)
+            assert r.returncode == 0 and "Wrote netcdf results" in r.stdout, r.stdout + r.stderr
+            shutil.copy(out, os.path.join(HERE, f"ref_driver_{case}.nc"))
+            print(case, r.stdout.strip().splitlines()[-3:])

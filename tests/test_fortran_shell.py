@@ -598,6 +598,47 @@ def test_reference_tool_chain_domain_through_the_drivers_on_gpu(tmp_path):
     g.finalize_Integrator()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["stepcloud_mu1", "stepcloud_mu05_absorbing"])
+def test_the_shell_driver_on_gpu_against_the_whole_reference_column_by_column(tmp_path, case):
+    """BASELINE.json's parity rule -- per column and domain mean |gpu - ref| <= 3 sqrt(se_gpu^2 + se_ref^2) -- against THE REFERENCE ITSELF:
+    tests/golden/ref_driver_*.nc are the result files of the reference's own driver on the reference's own integrator and modules, all
+    unmodified (oracle/_ref/ref_driver, tests/golden/make_ref_driver.py: the step cloud of the reference's generator, 200 batches of 1e5
+    photons; sun at the zenith, conservative; sun at 60 degrees, omega = 0.99, albedo 0.2), and the shell's driver runs the same decks on
+    the device: fluxUp, fluxDown, fluxAbsorbed, the nadir radiance per column (Student-t allowance for 32 columns at 398 degrees of
+    freedom), the absorbed profile per layer and every domain mean."""
+    import importlib.util
+
+    from scipy import stats
+    from scipy.io import netcdf_file
+
+    spec = importlib.util.spec_from_file_location("make_ref_driver", os.path.join(ROOT, "tests", "golden", "make_ref_driver.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    drv, gen = _need(os.path.join(BUILD, "i3rcDriver")), _need(os.path.join(BUILD, "makeStepCloudDomain"))
+    dom, out = str(tmp_path / "step.dom"), str(tmp_path / "results.nc")
+    assert _run([gen, dom, "32", mod.CASES[case]["ssa"]]).returncode == 0
+    (tmp_path / "deck.nml").write_text(mod.deck(case, dom, out))
+    r = _run([drv, str(tmp_path / "deck.nml")], cwd=ROOT)
+    assert r.returncode == 0 and "Wrote netCDF results" in r.stdout, r.stdout + r.stderr
+    g, ref = netcdf_file(out, "r", mmap=False), netcdf_file(os.path.join(ROOT, "tests", "golden", f"ref_driver_{case}.nc"), "r", mmap=False)
+    assert int(ref.Number_of_batches) == int(g.Number_of_batches) == 200 and int(ref.Total_number_of_photons) == int(g.Total_number_of_photons)
+    dof = 200 + 200 - 2
+    for key in ("fluxUp", "fluxDown", "fluxAbsorbed", "intensity", "absorptionProfile"):
+        mg, sg = g.variables[key].data.astype(np.float64).ravel(), g.variables[key + "_StdErr"].data.astype(np.float64).ravel()
+        mr, sr = ref.variables[key].data.astype(np.float64).ravel(), ref.variables[key + "_StdErr"].data.astype(np.float64).ravel()
+        if not mr.any():
+            assert not mg.any(), key          # (nothing absorbs in the conservative case: zeros on both sides)
+            continue
+        z = np.abs(mg - mr) / (np.sqrt(sg ** 2 + sr ** 2) + 1e-7)
+        expected = 2 * stats.t.sf(3.0, dof) * z.size
+        assert (z > 3.0).sum() <= int(np.ceil(expected + 3 * np.sqrt(expected) + 1)), (key, int((z > 3.0).sum()), float(z.max()))
+        assert z.max() < stats.t.isf(0.5e-3 / z.size, dof), (key, float(z.max()))
+        # the domain mean: its standard error from the columns' (columns of a batch are not independent: an upper bound, as the drivers' own)
+        se = np.sqrt((sg ** 2).sum() + (sr ** 2).sum()) / z.size
+        assert abs(mg.mean() - mr.mean()) <= 3 * se + 1e-6, (key, mg.mean(), mr.mean(), se)
+
+
 def test_photon_stream_constructors_equal_the_oracles_bit_for_bit(shell_built, oracle):
     """the shell's six photon sources (fortran/monteCarloIllumination.f95, written from the
     reference's interface) against the oracle's restatement of Code/monteCarloIllumination.f95:62-424
