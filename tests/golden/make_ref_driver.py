@@ -4,9 +4,11 @@ oracle/ref_loop.f95's header) -- for BASELINE.json's CPU-reference configuration
 (32 x 1 x 32): sun at the zenith, conservative, with the nadir radiance; and sun at 60 degrees, omega = 0.99, over a surface of albedo 0.2.
 Two hundred batches of 1e5 photons each (2e7 photons: eight minutes of the reference on one core) (the driver's batch / seed scheme, monteCarloDriver.f95:264-326), written by the driver's own
 writeResults_netcdf (:609-854).  The GPU tests run the shell's driver on the same decks and compare column by column.
-Only runs where /root/reference exists.   usage: python3 tests/golden/make_ref_driver.py"""
+Also BASELINE.json configs[2]'s reference-exact field, the radar cloud 640 x 1 x 54 with its nadir radiance (40 batches of 5e4 photons).
+Only runs where /root/reference exists.   usage: python3 tests/golden/make_ref_driver.py [--all]"""
 import os
 import shutil
+import sys
 import subprocess
 import tempfile
 
@@ -27,11 +29,25 @@ DECK = """&radiativeTransfer
 &fileNames
   domainFileName = "{dom}", outputNetcdfFile = "{out}" /
 """
-CASES = {"stepcloud_mu1": dict(ssa="1.0", mu0="1.", albedo="0."), "stepcloud_mu05_absorbing": dict(ssa="0.99", mu0="0.5", albedo="0.2")}
+CASES = {"stepcloud_mu1": dict(ssa="1.0", mu0="1.", albedo="0."), "stepcloud_mu05_absorbing": dict(ssa="0.99", mu0="0.5", albedo="0.2"),
+         # BASELINE.json configs[2]'s reference-exact field: the radar cloud 640 x 1 x 54, flux + nadir radiance, 40 batches of 5e4 photons
+         "radar640_nadir": dict(ssa="1.0", mu0="1.", albedo="0.", radar=True, batches=40, photons=50000)}
 
 
 def deck(case, dom, out):
-    return DECK.format(mu0=CASES[case]["mu0"], albedo=CASES[case]["albedo"], dom=dom, out=out)
+    c = CASES[case]
+    text = DECK.format(mu0=c["mu0"], albedo=c["albedo"], dom=dom, out=out)
+    return text.replace("numPhotonsPerBatch = 100000, numBatches = 200", f"numPhotonsPerBatch = {c.get('photons', 100000)}, numBatches = {c.get('batches', 200)}")
+
+
+def make_domain(case, dom, data_dir):
+    """the case's domain file through the shell's generators (whose files are the reference generators' bit for bit: tests/test_fortran_shell.py)"""
+    c = CASES[case]
+    if c.get("radar"):
+        cmd = [os.path.join(BUILD, "makeRadarCloudDomain"), data_dir, dom, c["ssa"], "hg"]
+    else:
+        cmd = [os.path.join(BUILD, "makeStepCloudDomain"), dom, "32", c["ssa"]]
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
 
 
 if __name__ == "__main__":
@@ -41,7 +57,9 @@ if __name__ == "__main__":
     for case, c in CASES.items():
         with tempfile.TemporaryDirectory() as tmp:
             dom, out, nml = os.path.join(tmp, "step.dom"), os.path.join(tmp, "results.nc"), os.path.join(tmp, "deck.nml")
-            subprocess.check_call([os.path.join(BUILD, "makeStepCloudDomain"), dom, "32", c["ssa"]], stdout=subprocess.DEVNULL)
+            if os.path.exists(os.path.join(HERE, f"ref_driver_{case}.nc")) and "--all" not in sys.argv:
+                continue                      # (the step cloud's two take eight minutes: --all makes them again)
+            make_domain(case, dom, "/root/reference/I3RC-Examples/Data")
             open(nml, "w").write(deck(case, dom, out))
             r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_driver"), nml], capture_output=True, text=True, cwd=tmp)
             assert r.returncode == 0 and "Wrote netcdf results" in r.stdout, r.stdout + r.stderr
