@@ -142,6 +142,14 @@ def test_python_mirror_tables_equal_the_references(fixture):
             tab = M.PhaseFunctionTable([M.PhaseFunction(legendre=e) for e in comp["coefficients"]])
             assert [_sha(tab.inverse_table(c["nInverse"])), _sha(tab.forward_table(c["nForward"]))] == [str(v) for v in fixture[f"{name}/tables{k}/sha256"]], (name, k)
     assert len(done) >= 4
+    # ... and the hybrid tables (computeHydridPhaseFunctions, :1925-1998: private to the reference's integrator, but the hybrid case above is
+    # its loop on the oracle's hybrid tables, bit for bit): the mirror's equal the oracle's
+    from oracle import pyoracle as O
+    from i3rc_monte_carlo_model_amd.phasefunctions import hybrid_phase_functions
+
+    for g, n in ((0.85, 64), (0.85, 299), (0.6, 16)):
+        fwd = np.asarray(O.forward_table_legendre(O.hg_coefficients(g, n), 10001)).reshape(1, -1)
+        assert np.array_equal(np.asarray(O.hybrid_tables(fwd, 7.0)), hybrid_phase_functions(fwd, 7.0)), (g, n)
 
 
 def test_shell_tables_equal_the_references(fixture, tmp_path):
