@@ -31,6 +31,14 @@ PLAN = {
     "landsat119_gas_7dir": (100, 250_000, 8, 30_000),
     "landsat119_irregular_7dir": (100, 250_000, 8, 40_000),
     "landsat119_brdfgrid_7dir": (100, 250_000, 8, 40_000),
+    # (round 5, after the absorption tallies were rewritten: the cell's tally only, in LDS or merged per run, column sums formed afterwards)
+    # (small oracle batches: the reference -- and so the oracle -- tallies in float32, and adding increments of 0.01 to a column's sum of
+    # 2000 rounds each of them to 2.4e-4: batches of 4e5 photons on these 32 columns read fluxAbsorbed 1.2e-4 too high, the energy balance
+    # says -- up + down + absorbed + dropped = 1.000121, 1.000012 with batches of 5e4, 0.999999 with 5e3 -- and the GPU's float64 sums,
+    # which close to 1 - dropped at any size, were 5 sigma away from them at 6e8 photons: profiles/r05_parity_large_absorbing.txt)
+    "step16_absorbing": (100, 1_000_000, 640, 5_000),
+    "landsat119_absorbing": (100, 1_000_000, 8, 150_000),
+    "les_stcu_rayleigh": (100, 1_000_000, 8, 300_000),
 }
 # (round 4) per-column fields of every workload (the oracle child saves them whatever the size of the domain), and config 4 also
 # against the oracle's committed fixture of 2.4e7 photons (tests/golden/config4_columns.npz), with 1e8 photons on the GPU
