@@ -69,6 +69,7 @@ struct i3rc_hip_integrator {
   int nx = 0, ny = 0, nz = 0, ncomp = 0;
   std::vector<float> xE, yE, zE;  // host copies (normalisation, checks)
   DevBuf dxE, dyE, dzE, dExt, dCum, dSsa, dPf;
+  DevBuf dCellRec;               // two components: a scattering's reads of its cell as one 16-byte record (DevProblem::cellRec)
   DevBuf dExtBrick;              // totalExt in bricks of 32 cells (DevProblem::extBrick)
   DevBuf dClearMap;              // ... and its clear-air map (DevProblem::clearMap)
   int clearShift = 0, clearNx = 1, clearWords = 1;
@@ -393,6 +394,19 @@ int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int n
   CCHK(h->dCum.upload(cumExt, sizeof(float) * ncell * ncomp));
   CCHK(h->dSsa.upload(ssa, sizeof(float) * ncell * ncomp));
   CCHK(h->dPf.upload(pfIndex, sizeof(int32_t) * ncell * ncomp));
+  if (ncomp == 2) {   // (DevProblem::cellRec)
+    static const bool recOn = !(std::getenv("I3RC_CELL_RECORDS") && std::atoi(std::getenv("I3RC_CELL_RECORDS")) == 0);
+    bool fits = recOn;
+    for (size_t i = 0; i < 2 * ncell && fits; ++i) fits = pfIndex[i] >= 0 && pfIndex[i] < 65536;
+    if (fits) {
+      std::vector<uint32_t> rec(4 * ncell);
+      for (size_t i = 0; i < ncell; ++i) {
+        std::memcpy(&rec[4 * i], &cumExt[i], 4); std::memcpy(&rec[4 * i + 1], &ssa[i], 4); std::memcpy(&rec[4 * i + 2], &ssa[ncell + i], 4);
+        rec[4 * i + 3] = (uint32_t)pfIndex[i] | ((uint32_t)pfIndex[ncell + i] << 16);
+      }
+      CCHK(h->dCellRec.upload(rec.data(), sizeof(uint32_t) * rec.size()));
+    }
+  }
   CCHK(h->workCounter.alloc(sizeof(unsigned long long)));
   CCHK(h->dComp.alloc(sizeof(CompTables) * ncomp));
   CCHK(h->dDir.alloc(sizeof(float) * 3 * I3RC_MAX_DIRECTIONS));
@@ -847,6 +861,7 @@ int make_problem(i3rc_hip_integrator *h, LaunchPlan &plan, bool fused = false, b
   P.clearMap = (const uint32_t *)h->dClearMap.p; P.clearShift = h->clearShift; P.clearNx = h->clearNx;
   P.totalExt = (const float *)h->dExt.p; P.cumExt = (const float *)h->dCum.p; P.ssa = (const float *)h->dSsa.p;
   P.pfIndex = (const int32_t *)h->dPf.p;
+  P.cellRec = (const uint4 *)h->dCellRec.p;
   if (h->compDirty) {
     // the device copy of the table descriptors follows the host copy when a table was (re)set: a blocking copy after
     // the stream has drained (launches in flight read the old descriptors), not an asynchronous copy from the

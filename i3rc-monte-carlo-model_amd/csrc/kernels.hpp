@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(256) slab_fill_kernel(uint32_t seed0, uint32_t
 // tracing, no BRDF grid, Directional source -- as compiled out as in the one-component kernels; the deviates are drawn as the general
 // kernels draw them (the component's from the stream's cursor), so that a MULTI launch traces the general kernels' photons.
 template <class Rng, bool INTENSITY, bool GENERAL, int GRID, bool TBL = false, bool DIRECT = false, bool MULTI = false>
-__global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (MULTI ? I3RC_MULTI_WAVES : I3RC_RADIANCE_WAVES)) : ((GENERAL || GRID == GRID_BRICKS) ? I3RC_MIN_WAVES : ((Rng::kBatched && !TBL) ? (MULTI ? I3RC_FUSED_WAVES - 1 : I3RC_FUSED_WAVES) : I3RC_FLUX_WAVES))) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
+__global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (MULTI ? I3RC_MULTI_WAVES : I3RC_RADIANCE_WAVES)) : ((GENERAL || GRID == GRID_BRICKS) ? I3RC_MIN_WAVES : ((Rng::kBatched && !TBL) ? (MULTI ? I3RC_FUSED_WAVES - 2 : I3RC_FUSED_WAVES) : I3RC_FLUX_WAVES))) photon_kernel(const DevProblem P, const RunArgs A, const int evThreshold, const int lightThreshold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Lds L;
   {
@@ -1239,6 +1239,27 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
               const bool needCell = GENERAL || MULTI || !(Pe.uniformSsa >= 0.0f) || Pe.uniformSsa < 1.0f || Pe.uniformPf < 1;
               if (needCell) cell = cell_index(Pe, r.ix, r.iy, r.iz);
               int comp = 1;                                               // :637-638
+#ifndef I3RC_TWO_COMPONENTS_AT_ONCE
+#define I3RC_TWO_COMPONENTS_AT_ONCE 1
+#endif
+              // TWO components (cloud + gas, cloud + aerosol: the usual production domain): what the scattering needs of its cell comes as
+              // ONE 16-byte record (DevProblem::cellRec) -- one cache line, one trip to L2 -- and the component's pair is picked when the
+              // deviate has been compared, instead of one read to choose the component and then two more, from two more arrays, that wait
+              // for it.  (Asking the three arrays for both components' words at once -- five reads, five lines -- was measured: 9 - 15 %
+              // SLOWER on the flux workloads; it is the lines that cost.  findIndex on (/0, c1, c2/) without a first guess answers 1 or 2,
+              // never 3: see below.)
+              bool twoAtOnce = false;
+              float ssaTwo = 0.0f;
+              int pfiTwo = 0;
+              if (I3RC_TWO_COMPONENTS_AT_ONCE && (GENERAL || MULTI) && !REPLAY && multiComp && Pe.cellRec != nullptr) {
+                const uint4 rec = Pe.cellRec[cell];
+                const float c0 = __uint_as_float(rec.x), s0 = __uint_as_float(rec.y), s1 = __uint_as_float(rec.z);
+                const int p0 = (int)(rec.w & 0xffffu), p1 = (int)(rec.w >> 16);
+                const float rc = rng.next();
+                const bool second = rc >= c0;
+                comp = second ? 2 : 1; ssaTwo = second ? s1 : s0; pfiTwo = second ? p1 : p0;
+                twoAtOnce = true;
+              } else
               if (multiComp || REPLAY) {
                 const float rc = rng.next();
                 if (multiComp) {
@@ -1260,6 +1281,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
               // domain comes from the kernel arguments instead of two dependent memory reads
               float ssa;
               if (!GENERAL && !MULTI && Pe.uniformSsa >= 0.0f) ssa = Pe.uniformSsa;
+              else if (twoAtOnce) ssa = ssaTwo;
               else ssa = Pe.ssa[(size_t)(comp - 1) * ncell + cell];
               if (ssa < 1.0f) {                                           // :642-649
                 const float inc = w * (1.0f - ssa);
@@ -1275,6 +1297,7 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
               }
               int pfi;
               if (!GENERAL && !MULTI && Pe.uniformPf >= 1) pfi = Pe.uniformPf;
+              else if (twoAtOnce) pfi = max(pfiTwo, 1);
               else pfi = max(Pe.pfIndex[(size_t)(comp - 1) * ncell + cell], 1);   // (index 0 marks clear cells: never a table offset of -1)
               if (defer) {                                                // :654-668: pushed after this event, traced in ray mode
                 pendingShadow = true; wI = w;

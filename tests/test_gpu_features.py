@@ -825,6 +825,41 @@ def _three_components_one_empty():
                 pf=[d["pf"], np.zeros(empty.shape, np.int32), np.ones(gas.shape, np.int32)])
 
 
+def test_two_component_cell_records_change_nothing():
+    """Two components -- the usual production domain -- read what a scattering needs of its cell from ONE 16-byte record (DevProblem::cellRec:
+    the first cumulative extinction, both albedos, both table entries) instead of three words in three arrays: +10 ... 19 % on the flux
+    workloads.  The same domain with a third, EMPTY component has no records (three components) and must trace the same photons: identical
+    work counters, fluxes, absorption and radiances equal to the order of the float64 additions -- general flux kernel, widened-class radiance
+    kernels (ring and one direction), plain and fused launches."""
+    t_cloud = M.PhaseFunctionTable([M.henyey_greenstein(0.85, 32), M.henyey_greenstein(0.6, 16)])
+    t_gas = M.PhaseFunctionTable([M.PhaseFunction(legendre=np.array([0.0, 0.1], np.float32))])
+    big = cases.landsat_cloud(nlayers=36, ssa=0.99)
+    gas = np.broadcast_to(np.linspace(2.0e-5, 1.5e-5, 36, dtype=np.float32)[:, None, None], big["ext"].shape).copy()
+    hg = M.PhaseFunctionTable([M.henyey_greenstein(0.85, 32)])
+    big = dict(big, ext=[big["ext"], gas], ssa=[big["ssa"], np.full_like(gas, f32(0.9))], pf=[big["pf"], np.ones(gas.shape, np.int32)])
+    rri = dict(useRussianRouletteForIntensity=True, zetaMin=0.3)
+    for label, d, tabs, n in (("two", cases.two_component(), [t_cloud, t_gas], 80_000), ("Landsat-36 + gas", big, [hg, t_gas], 150_000)):
+        empty = np.zeros_like(d["ext"][0])
+        d3 = dict(d, ext=d["ext"] + [empty], ssa=d["ssa"] + [empty], pf=d["pf"] + [empty.astype(np.int32)])
+        for params in (dict(surfaceAlbedo=0.3), dict(rri, surfaceAlbedo=0.2, intensityMus=[1.0, 0.4], intensityPhis=[0.0, 100.0]), dict(rri, intensityMus=[0.8], intensityPhis=[200.0])):
+            g2, g3 = make_gpu(d, tabs, **params), make_gpu(d3, tabs + [t_gas], **params)
+            a = g2.computeRadiativeTransfer(M.new_RandomNumberSequence((8, 3)), M.new_PhotonStream(0.6, 40.0, n))
+            b = g3.computeRadiativeTransfer(M.new_RandomNumberSequence((8, 3)), M.new_PhotonStream(0.6, 40.0, n))
+            assert a["counters"] == b["counters"], (label, params.keys())
+            nd = len(params.get("intensityMus", ()))
+            for key in ("fluxUp", "fluxDown", "fluxAbsorbed", "volumeAbsorption") + (("intensity",) if nd else ()):
+                assert_same_sums(a[key], b[key], a["counters"], directions=nd, what=(label, key))
+            if nd:   # by component: the surface's and the two components' planes; the empty component's stays empty
+                assert_same_sums(a["intensityByComponent"], b["intensityByComponent"][:3], a["counters"], directions=nd, what=(label, "by component"))
+                assert not b["intensityByComponent"][3].any()
+            fa = g2.computeRadiativeTransferBatches((8, 3), 3, 0.6, 40.0, n // 4)
+            fb = g3.computeRadiativeTransferBatches((8, 3), 3, 0.6, 40.0, n // 4)
+            for x, y in zip(fa, fb):
+                for key in ("fluxUp", "fluxDown", "fluxAbsorbed") + (("intensity",) if nd else ()):
+                    assert_same_sums(x[key], y[key], x["counters"], directions=nd, what=(label, "fused", key))
+            g2.finalize_Integrator(), g3.finalize_Integrator()
+
+
 def test_several_components_kernels_trace_the_general_kernels_photons():
     """Round 5: domains of several components on a regular grid (cloud + aerosol + gas: what Tools/PhysicalPropertiesToDomain.f95
     makes) no longer fall to the general kernels: photon_kernel<..., MULTI> picks the component by a compare chain where the general
