@@ -394,15 +394,22 @@ int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int n
   CCHK(h->dCum.upload(cumExt, sizeof(float) * ncell * ncomp));
   CCHK(h->dSsa.upload(ssa, sizeof(float) * ncell * ncomp));
   CCHK(h->dPf.upload(pfIndex, sizeof(int32_t) * ncell * ncomp));
-  if (ncomp == 2) {   // (DevProblem::cellRec)
+  if (ncomp == 2 || ncomp == 3) {   // (DevProblem::cellRec)
     static const bool recOn = !(std::getenv("I3RC_CELL_RECORDS") && std::atoi(std::getenv("I3RC_CELL_RECORDS")) == 0);
     bool fits = recOn;
-    for (size_t i = 0; i < 2 * ncell && fits; ++i) fits = pfIndex[i] >= 0 && pfIndex[i] < 65536;
+    for (size_t i = 0; i < 2 * ncell && fits; ++i) fits = pfIndex[i] >= 0 && pfIndex[i] < 65536;   // (the first two entries share a word)
     if (fits) {
-      std::vector<uint32_t> rec(4 * ncell);
+      auto bits = [](float v) { uint32_t b; std::memcpy(&b, &v, 4); return b; };
+      const size_t words = ncomp == 2 ? 4 : 8;
+      std::vector<uint32_t> rec(words * ncell, 0u);
       for (size_t i = 0; i < ncell; ++i) {
-        std::memcpy(&rec[4 * i], &cumExt[i], 4); std::memcpy(&rec[4 * i + 1], &ssa[i], 4); std::memcpy(&rec[4 * i + 2], &ssa[ncell + i], 4);
-        rec[4 * i + 3] = (uint32_t)pfIndex[i] | ((uint32_t)pfIndex[ncell + i] << 16);
+        uint32_t *r = &rec[words * i];
+        const uint32_t pf01 = (uint32_t)pfIndex[i] | ((uint32_t)pfIndex[ncell + i] << 16);
+        if (ncomp == 2) { r[0] = bits(cumExt[i]); r[1] = bits(ssa[i]); r[2] = bits(ssa[ncell + i]); r[3] = pf01; }
+        else {
+          r[0] = bits(cumExt[i]); r[1] = bits(cumExt[ncell + i]); r[2] = bits(ssa[i]); r[3] = bits(ssa[ncell + i]);
+          r[4] = bits(ssa[2 * ncell + i]); r[5] = pf01; r[6] = (uint32_t)pfIndex[2 * ncell + i];
+        }
       }
       CCHK(h->dCellRec.upload(rec.data(), sizeof(uint32_t) * rec.size()));
     }

@@ -1252,12 +1252,20 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
               float ssaTwo = 0.0f;
               int pfiTwo = 0;
               if (I3RC_TWO_COMPONENTS_AT_ONCE && (GENERAL || MULTI) && !REPLAY && multiComp && Pe.cellRec != nullptr) {
-                const uint4 rec = Pe.cellRec[cell];
-                const float c0 = __uint_as_float(rec.x), s0 = __uint_as_float(rec.y), s1 = __uint_as_float(rec.z);
-                const int p0 = (int)(rec.w & 0xffffu), p1 = (int)(rec.w >> 16);
                 const float rc = rng.next();
-                const bool second = rc >= c0;
-                comp = second ? 2 : 1; ssaTwo = second ? s1 : s0; pfiTwo = second ? p1 : p0;
+                if (Pe.ncomp == 2) {
+                  const uint4 rec = Pe.cellRec[cell];
+                  const float c0 = __uint_as_float(rec.x), s0 = __uint_as_float(rec.y), s1 = __uint_as_float(rec.z);
+                  const int p0 = (int)(rec.w & 0xffffu), p1 = (int)(rec.w >> 16);
+                  const bool second = rc >= c0;
+                  comp = second ? 2 : 1; ssaTwo = second ? s1 : s0; pfiTwo = second ? p1 : p0;
+                } else {   // three components (droplets + aerosol + gas): 32 bytes of the same line
+                  const uint4 a = Pe.cellRec[2 * (size_t)cell], b = Pe.cellRec[2 * (size_t)cell + 1];
+                  const bool ge0 = rc >= __uint_as_float(a.x), ge1 = rc >= __uint_as_float(a.y);
+                  comp = 1 + (ge0 ? 1 : 0) + (ge1 ? 1 : 0);
+                  ssaTwo = comp == 1 ? __uint_as_float(a.z) : (comp == 2 ? __uint_as_float(a.w) : __uint_as_float(b.x));
+                  pfiTwo = comp == 1 ? (int)(b.y & 0xffffu) : (comp == 2 ? (int)(b.y >> 16) : (int)b.z);
+                }
                 twoAtOnce = true;
               } else
               if (multiComp || REPLAY) {

@@ -68,6 +68,7 @@ struct DevProblem {
   // cumulative extinction, both single-scattering albedos, both table entries (16 bits each) -- instead of three words in three arrays
   // (three cache lines).  nullptr: no records (another number of components, an entry beyond 65535).
   const uint4 *cellRec;               // [nz][ny][nx] {cumExt_1, ssa_1, ssa_2, pfIndex_1 | pfIndex_2 << 16}
+                                      // THREE components: two of them per cell, {cumExt_1, cumExt_2, ssa_1, ssa_2} {ssa_3, pfIndex_1 | pfIndex_2 << 16, pfIndex_3, -}
   const CompTables *comp;             // [ncomp] phase-function tables (device memory: indexed per lane)
   CompTables comp0;                   // tables of component 1 by value: the specialised (one-component) kernel reads them
                                       // from scalar registers, and its table loads are global_load, not flat_load

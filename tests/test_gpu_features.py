@@ -828,7 +828,8 @@ def _three_components_one_empty():
 def test_two_component_cell_records_change_nothing():
     """Two components -- the usual production domain -- read what a scattering needs of its cell from ONE 16-byte record (DevProblem::cellRec:
     the first cumulative extinction, both albedos, both table entries) instead of three words in three arrays: +10 ... 19 % on the flux
-    workloads.  The same domain with a third, EMPTY component has no records (three components) and must trace the same photons: identical
+    workloads; three components from one of 32 bytes.  The same domain with one more, EMPTY component has no records (three components:
+    another record; four: none) and must trace the same photons: identical
     work counters, fluxes, absorption and radiances equal to the order of the float64 additions -- general flux kernel, widened-class radiance
     kernels (ring and one direction), plain and fused launches."""
     t_cloud = M.PhaseFunctionTable([M.henyey_greenstein(0.85, 32), M.henyey_greenstein(0.6, 16)])
@@ -838,7 +839,14 @@ def test_two_component_cell_records_change_nothing():
     hg = M.PhaseFunctionTable([M.henyey_greenstein(0.85, 32)])
     big = dict(big, ext=[big["ext"], gas], ssa=[big["ssa"], np.full_like(gas, f32(0.9))], pf=[big["pf"], np.ones(gas.shape, np.int32)])
     rri = dict(useRussianRouletteForIntensity=True, zetaMin=0.3)
-    for label, d, tabs, n in (("two", cases.two_component(), [t_cloud, t_gas], 80_000), ("Landsat-36 + gas", big, [hg, t_gas], 150_000)):
+    # ... and THREE components (droplets + aerosol + gas, PhysicalPropertiesToDomain's own example): records of 32 bytes
+    three = cases.two_component(seed=9, nx=7, ny=3, nz=9)
+    aer = np.zeros_like(three["ext"][0]); aer[:3] = f32(0.002)
+    three = dict(three, ext=[three["ext"][0], aer, three["ext"][1]], ssa=[three["ssa"][0], np.where(aer > 0, f32(0.92), f32(0)).astype(np.float32), three["ssa"][1]],
+                 pf=[three["pf"][0], (aer > 0).astype(np.int32), three["pf"][1]])
+    t_aer = M.PhaseFunctionTable([M.henyey_greenstein(0.7, 24)])
+    for label, d, tabs, n in (("two", cases.two_component(), [t_cloud, t_gas], 80_000), ("Landsat-36 + gas", big, [hg, t_gas], 150_000),
+                              ("three", three, [t_cloud, t_aer, t_gas], 80_000)):
         empty = np.zeros_like(d["ext"][0])
         d3 = dict(d, ext=d["ext"] + [empty], ssa=d["ssa"] + [empty], pf=d["pf"] + [empty.astype(np.int32)])
         for params in (dict(surfaceAlbedo=0.3), dict(rri, surfaceAlbedo=0.2, intensityMus=[1.0, 0.4], intensityPhis=[0.0, 100.0]), dict(rri, intensityMus=[0.8], intensityPhis=[200.0])):
@@ -850,8 +858,9 @@ def test_two_component_cell_records_change_nothing():
             for key in ("fluxUp", "fluxDown", "fluxAbsorbed", "volumeAbsorption") + (("intensity",) if nd else ()):
                 assert_same_sums(a[key], b[key], a["counters"], directions=nd, what=(label, key))
             if nd:   # by component: the surface's and the two components' planes; the empty component's stays empty
-                assert_same_sums(a["intensityByComponent"], b["intensityByComponent"][:3], a["counters"], directions=nd, what=(label, "by component"))
-                assert not b["intensityByComponent"][3].any()
+                nc1 = len(d["ext"]) + 1
+                assert_same_sums(a["intensityByComponent"], b["intensityByComponent"][:nc1], a["counters"], directions=nd, what=(label, "by component"))
+                assert not b["intensityByComponent"][nc1].any()
             fa = g2.computeRadiativeTransferBatches((8, 3), 3, 0.6, 40.0, n // 4)
             fb = g3.computeRadiativeTransferBatches((8, 3), 3, 0.6, 40.0, n // 4)
             for x, y in zip(fa, fb):

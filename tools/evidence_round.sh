@@ -14,7 +14,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=$1; PART=$2; O=$R/gpurun_out/$TAG
 WL="step16 radar64_nadir landsat36 landsat119_7dir"
 # round 5: the problems beyond the common class -- several components, an irregular x / y grid, a gridded surface (tools/workloads.py)
-GL="landsat119_gas landsat119_gas_7dir landsat119_irregular_7dir landsat119_brdfgrid_7dir"
+GL="landsat119_gas landsat119_gas_7dir landsat119_irregular_7dir landsat119_brdfgrid_7dir landsat36_aerosol_gas"
 # ... the I3RC cases' absorbing versions (omega = 0.99) and the LES stratocumulus + Rayleigh domain the reference's tool chain wrote
 AL="step16_absorbing landsat36_absorbing landsat119_absorbing les_stcu_rayleigh les_stcu_rayleigh_2dir"
 clean() { grep -v "amdgpu.ids" "$1" > "$1.clean" && mv "$1.clean" "$1"; }
@@ -40,7 +40,7 @@ general|absorbing)
   # the same three things -- counter passes, rocprofv3 kernel stats of the bench, the bench line -- for the general-class workloads
   # (absorbing: for the I3RC cases' absorbing versions and the domain of the reference's tool chain)
   mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-  declare -A N=( [landsat119_gas]=50000000 [landsat119_gas_7dir]=10000000 [landsat119_irregular_7dir]=10000000 [landsat119_brdfgrid_7dir]=10000000
+  declare -A N=( [landsat119_gas]=50000000 [landsat119_gas_7dir]=10000000 [landsat119_irregular_7dir]=10000000 [landsat119_brdfgrid_7dir]=10000000 [landsat36_aerosol_gas]=50000000
                  [step16_absorbing]=50000000 [landsat36_absorbing]=50000000 [landsat119_absorbing]=50000000 [les_stcu_rayleigh]=50000000 [les_stcu_rayleigh_2dir]=20000000 )
   [ $PART = absorbing ] && GL=$AL
   for w in ${WORKLOADS:-$GL}; do

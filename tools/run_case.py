@@ -14,7 +14,7 @@ if os.environ.get("I3RC_LIB"):
 PROFILE_PHOTONS = {"step16": 20_000_000, "step32": 20_000_000, "radar640": 10_000_000, "radar640_nadir": 5_000_000,
                    "radar64_nadir": 5_000_000, "landsat119": 10_000_000, "landsat36": 10_000_000, "landsat119_7dir": 1_000_000,
                    "landsat36_7dir": 1_000_000, "landsat119_gas": 5_000_000, "landsat36_gas": 5_000_000, "landsat119_gas_7dir": 1_000_000,
-                   "landsat119_irregular_7dir": 1_000_000, "landsat119_brdfgrid_7dir": 1_000_000, "les_stcu_rayleigh": 10_000_000, "step16_absorbing": 20_000_000,
+                   "landsat119_irregular_7dir": 1_000_000, "landsat119_brdfgrid_7dir": 1_000_000, "les_stcu_rayleigh": 10_000_000, "step16_absorbing": 20_000_000, "landsat36_aerosol_gas": 10_000_000,
                    "landsat119_absorbing": 10_000_000, "landsat36_absorbing": 10_000_000,
                    "les_stcu_rayleigh_2dir": 5_000_000}
 name, w = W.get(sys.argv[1])

@@ -74,6 +74,11 @@ WORKLOADS = {
     "landsat36_gas_absorbing": dict(label="i3rcLandsatCloud 128x128x36, omega = 0.99, + gas with omega = 0.9 (two components), mu0=1, flux + absorption",
                                     baseline_config=3, domain=("landsat_cloud", dict(nlayers=36, ssa=0.99)), gas=(2.0e-5, 1.5e-5), gas_ssa=0.9, moments=299,
                                     mu0=1.0, params={}, photons=125_000_000, cpu_photons=40_000),
+    # ... three components, what PhysicalPropertiesToDomain's own example makes (droplets + aerosol + gas): the Landsat scene, an aerosol layer
+    # (HG g = 0.7, omega = 0.92, optical depth 0.15 in the lowest third of the domain) and the gas
+    "landsat36_aerosol_gas": dict(label="i3rcLandsatCloud 128x128x36 (omega 0.99) + aerosol layer (omega 0.92) + gas (omega 0.9): three components, mu0=1, flux + absorption",
+                                  baseline_config=3, domain=("landsat_cloud", dict(nlayers=36, ssa=0.99)), gas=(2.0e-5, 1.5e-5), gas_ssa=0.9, aerosol=0.15, moments=299,
+                                  mu0=1.0, params={}, photons=125_000_000, cpu_photons=40_000),
     "landsat119_irregular_7dir": dict(label="i3rcLandsatCloud 128x128x119 on an irregular x / y grid (cell widths 30 m +- 20 %) + 7 radiance "
                                             "directions + Lambertian surface 0.2, mu0=0.5", baseline_config=4, domain=("landsat_cloud", {}), irregular=0.2,
                                       moments=299, mu0=0.5, params=dict(**DIRS7, **RRI), surface=0.2, photons=125_000_000, cpu_photons=6_000),
@@ -159,6 +164,21 @@ def domain_from_file(w):
     return dom, d
 
 
+AEROSOL_G, AEROSOL_SSA, AEROSOL_MOMENTS = 0.7, 0.92, 32
+
+
+def aerosol_component(w, d):
+    """extinction of the horizontally uniform aerosol layer of an `aerosol=<optical depth>` workload: the lowest third of the layers, [nz][ny][nx]"""
+    import numpy as np
+
+    nz = d["ext"].shape[0]
+    top = max(1, nz // 3)
+    depth = float(d["ze"][top] - d["ze"][0])
+    profile = np.zeros(nz, np.float32)
+    profile[:top] = np.float32(w["aerosol"] / depth)
+    return np.broadcast_to(profile[:, None, None], d["ext"].shape).copy()
+
+
 def gas_component(w, d):
     """extinction of the horizontally uniform gas of a `gas=(bottom, top)` workload, [nz][ny][nx]"""
     import numpy as np
@@ -200,6 +220,10 @@ def make_integrator(w, device=0):
         table = M.PhaseFunctionTable([M.henyey_greenstein(0.85, w["moments"])])
         dom = M.new_Domain(d["xe"], d["ye"], d["ze"])
         dom.addOpticalComponent("cloud", d["ext"], d["ssa"], d["pf"], table)
+    if "aerosol" in w:
+        aer = aerosol_component(w, d)
+        dom.addOpticalComponent("aerosol", aer, np.where(aer > 0, np.float32(AEROSOL_SSA), np.float32(0)).astype(np.float32), (aer > 0).astype(np.int32),
+                                M.PhaseFunctionTable([M.henyey_greenstein(AEROSOL_G, AEROSOL_MOMENTS)]))
     if "gas" in w:
         gas = gas_component(w, d)
         dom.addOpticalComponent("gas", gas, np.full_like(gas, np.float32(w.get("gas_ssa", 1.0))), np.ones(gas.shape, np.int32),
@@ -234,13 +258,23 @@ def make_oracle(w):
         inv = [O.inverse_table_legendre(coef, 10001)]
         fwd = [O.forward_table_legendre(coef, 10001)] if nd else None
     ext, ssa, pf = d["ext"], d["ssa"], d["pf"]
-    if "gas" in w:
-        gas = gas_component(w, d)
-        gcoef = np.array(GAS_LEGENDRE, np.float32)
-        ext, ssa, pf = np.stack([ext, gas]), np.stack([ssa, np.full_like(gas, np.float32(w.get("gas_ssa", 1.0)))]), np.stack([pf, np.ones(gas.shape, np.int32)])
-        inv.append(O.inverse_table_legendre(gcoef, 10001))
-        if nd:
-            fwd.append(O.forward_table_legendre(gcoef, 10001))
+    if "aerosol" in w or "gas" in w:
+        ext, ssa, pf = [ext], [ssa], [pf]
+        if "aerosol" in w:
+            aer = aerosol_component(w, d)
+            acoef = O.hg_coefficients(AEROSOL_G, AEROSOL_MOMENTS)
+            ext.append(aer), ssa.append(np.where(aer > 0, np.float32(AEROSOL_SSA), np.float32(0)).astype(np.float32)), pf.append((aer > 0).astype(np.int32))
+            inv.append(O.inverse_table_legendre(acoef, 10001))
+            if nd:
+                fwd.append(O.forward_table_legendre(acoef, 10001))
+        if "gas" in w:
+            gas = gas_component(w, d)
+            gcoef = np.array(GAS_LEGENDRE, np.float32)
+            ext.append(gas), ssa.append(np.full_like(gas, np.float32(w.get("gas_ssa", 1.0)))), pf.append(np.ones(gas.shape, np.int32))
+            inv.append(O.inverse_table_legendre(gcoef, 10001))
+            if nd:
+                fwd.append(O.forward_table_legendre(gcoef, 10001))
+        ext, ssa, pf = np.stack(ext), np.stack(ssa), np.stack(pf)
     o = O.Integrator(d["xe"], d["ye"], d["ze"], ext, ssa, pf, inv, fwd, fwd)
     kw = {}
     if nd:
