@@ -143,7 +143,22 @@ def general_kernel_rows():
     rows["… Landsat-119 + 7 directions + uniform surface, 1e7"] = [rate("landsat119_7dir", "GRID_COLUMNS>")]
 
 
-bench_rows(); config_rows(); phase_rows(); loop_rows(); general_kernel_rows()
+def fused_wide_rows():
+    """profiles/<tag>_fused_wide.txt: the batch loops of the workloads beyond the BASELINE four, fused launches against one launch per batch"""
+    ft = text("fused_wide.txt")
+    def pair(w):
+        a = re.search(rf"^{w} \d+ x 1e\+06 photons .*fused=1 .*?: ([\d.]+) ms per batch", ft, re.M).group(1)
+        b = re.search(rf"^{w} \d+ x 1e\+06 photons .*fused=0 .*?: ([\d.]+) ms per batch", ft, re.M).group(1)
+        return [a, b]
+    for label, w in (("Landsat 128×128×36 + gas (two components), flux", "landsat36_gas"), ("Landsat 128×128×119 + gas, flux", "landsat119_gas"),
+                     ("Landsat-119 + gas + 7 directions + surface", "landsat119_gas_7dir"), ("Landsat-119 + 7 directions, irregular x / y grid", "landsat119_irregular_7dir"),
+                     ("Landsat-119 + 7 directions, gridded surface", "landsat119_brdfgrid_7dir"), ("Landsat-36 + aerosol layer + gas (three components), flux", "landsat36_aerosol_gas"),
+                     ("LES stratocumulus + Rayleigh gas (the tool chain's domain), flux", "les_stcu_rayleigh"), ("step cloud 32×1×16, ω = 0.99", "step16_absorbing"),
+                     ("Landsat 128×128×36, ω = 0.99", "landsat36_absorbing")):
+        rows[label + " | "] = pair(w)
+
+
+bench_rows(); config_rows(); phase_rows(); loop_rows(); general_kernel_rows(); fused_wide_rows()
 lines = open(os.path.join(ROOT, "DESIGN.md")).read().split("\n")
 # the Fortran drivers end to end: two runs in the file; the row quotes both and carries the smaller one as its value
 dt = text("driver_timing.txt")

@@ -58,6 +58,9 @@ general|absorbing)
       case $w in *gas*) GRID=bricks KERNEL=general python3 $R/tools/run_case.py $w $n | tail -1;; esac
     done
     python3 $R/tools/run_case.py landsat119 50000000 | tail -1; python3 $R/tools/run_case.py landsat119_7dir 10000000 | tail -1 ) > $O/general_kernels.txt 2>&1; clean $O/general_kernels.txt   # (REPEAT=3: the last of three launches, not a process's first)
+  # ... and their batch loops: fused launches of the widened class against one launch per batch
+  ( cd $R; for spec in "landsat36_gas 1e6 60" "landsat119_gas 1e6 40" "landsat119_gas_7dir 1e6 20" "landsat119_irregular_7dir 1e6 20" "landsat119_brdfgrid_7dir 1e6 20" "landsat36_aerosol_gas 1e6 50" "les_stcu_rayleigh 1e6 50" "step16_absorbing 1e6 300" "landsat36_absorbing 1e6 100"; do
+      python3 tools/fused_timing.py $spec; I3RC_FUSED=0 python3 tools/fused_timing.py $spec; done ) > $O/fused_wide.txt 2>&1; clean $O/fused_wide.txt
   echo "evidence $TAG: general done";;
 loop)
   mkdir -p $O; cd $R
@@ -78,6 +81,7 @@ loop)
   echo "evidence $TAG: loop done";;
 collect)
   [ -f $O/general_kernels.txt ] && cp $O/general_kernels.txt $R/profiles/${TAG}_general_kernels.txt
+  [ -f $O/fused_wide.txt ] && cp $O/fused_wide.txt $R/profiles/${TAG}_fused_wide.txt
   for w in $WL $GL $AL; do
     [ -f $O/bench_$w.json ] && cp $O/bench_$w.json $R/profiles/${TAG}_${w}_bench.json
     f=$(ls -t $O/stats_$w/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $R/profiles/${TAG}_${w}_kernel_stats.csv
