@@ -458,6 +458,14 @@ int i3rc_hip_create(i3rc_hip_integrator **out, int device, int nx, int ny, int n
     h->uniformSsa = (sameSsa && ssa0 >= 0.f) ? ssa0 : -1.f;
     h->uniformPf = (samePf && pf0 >= 1) ? pf0 : 0;
   }
+  if (ncomp == 1 && h->uniformSsa < 0.0f && h->uniformPf < 1) {   // one component, neither albedo nor entry shared: {ssa, pfIndex}, 8 bytes a cell
+    static const bool recOn1 = !(std::getenv("I3RC_CELL_RECORDS") && std::atoi(std::getenv("I3RC_CELL_RECORDS")) == 0);
+    if (recOn1) {
+      std::vector<uint32_t> rec(2 * ncell);
+      for (size_t i = 0; i < ncell; ++i) { std::memcpy(&rec[2 * i], &ssa[i], 4); rec[2 * i + 1] = (uint32_t)pfIndex[i]; }
+      if (h->dCellRec.upload(rec.data(), sizeof(uint32_t) * rec.size()) != hipSuccess) { g_createError = "i3rc_hip_create: device allocation of the cell records failed"; delete h; return 1; }
+    }
+  }
   // defaults of type(integrator) :54-129
   h->params.surfaceAlbedo = 0.f; h->params.useSurfaceBDRF = 0; h->params.useRayTracing = 1; h->params.useRussianRoulette = 1;
   h->params.useHybridPhaseFunsForIntenCalcs = 0; h->params.numOrdersOrigPhaseFunIntenCalcs = 0;

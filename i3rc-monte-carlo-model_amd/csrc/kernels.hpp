@@ -1288,8 +1288,15 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
               // single-scattering albedo and phase-function entry of the cell; a value shared by the whole (one-component)
               // domain comes from the kernel arguments instead of two dependent memory reads
               float ssa;
-              if (!GENERAL && !MULTI && Pe.uniformSsa >= 0.0f) ssa = Pe.uniformSsa;
-              else if (twoAtOnce) ssa = ssaTwo;
+              if ((GENERAL || MULTI) && twoAtOnce) ssa = ssaTwo;
+              else if (!GENERAL && !MULTI && Pe.uniformSsa >= 0.0f) ssa = Pe.uniformSsa;
+              else if (I3RC_TWO_COMPONENTS_AT_ONCE && !GENERAL && !MULTI && !REPLAY && Pe.cellRec != nullptr) {
+                // ONE component whose cells share neither albedo nor table entry (a Mie cloud: every cell its effective radius): the two as one
+                // 8-byte record (the same pointer: i3rc_hip_create makes the record that fits the domain, and only where NEITHER is shared, so
+                // that the kernels of the BASELINE workloads -- both shared -- never ask)
+                const uint2 rec = ((const uint2 *)Pe.cellRec)[cell];
+                ssa = __uint_as_float(rec.x); pfiTwo = (int)rec.y; twoAtOnce = true;
+              }
               else ssa = Pe.ssa[(size_t)(comp - 1) * ncell + cell];
               if (ssa < 1.0f) {                                           // :642-649
                 const float inc = w * (1.0f - ssa);
@@ -1304,8 +1311,9 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
                 w = w * ssa;
               }
               int pfi;
-              if (!GENERAL && !MULTI && Pe.uniformPf >= 1) pfi = Pe.uniformPf;
-              else if (twoAtOnce) pfi = max(pfiTwo, 1);
+              if ((GENERAL || MULTI) && twoAtOnce) pfi = max(pfiTwo, 1);
+              else if (!GENERAL && !MULTI && Pe.uniformPf >= 1) pfi = Pe.uniformPf;
+              else if (!GENERAL && !MULTI && twoAtOnce) pfi = max(pfiTwo, 1);
               else pfi = max(Pe.pfIndex[(size_t)(comp - 1) * ncell + cell], 1);   // (index 0 marks clear cells: never a table offset of -1)
               if (defer) {                                                // :654-668: pushed after this event, traced in ray mode
                 pendingShadow = true; wI = w;
