@@ -39,6 +39,7 @@ PLAN = {
     "step16_absorbing": (100, 1_000_000, 640, 5_000),
     "landsat119_absorbing": (100, 1_000_000, 8, 150_000),
     "les_stcu_rayleigh": (100, 1_000_000, 8, 300_000),
+    "landsat36_aerosol_gas": (100, 1_000_000, 8, 200_000),   # three components: cell records of 32 bytes
 }
 # (round 4) per-column fields of every workload (the oracle child saves them whatever the size of the domain), and config 4 also
 # against the oracle's committed fixture of 2.4e7 photons (tests/golden/config4_columns.npz), with 1e8 photons on the GPU
