@@ -1239,8 +1239,8 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
               const bool needCell = GENERAL || MULTI || !(Pe.uniformSsa >= 0.0f) || Pe.uniformSsa < 1.0f || Pe.uniformPf < 1;
               if (needCell) cell = cell_index(Pe, r.ix, r.iy, r.iz);
               int comp = 1;                                               // :637-638
-#ifndef I3RC_TWO_COMPONENTS_AT_ONCE
-#define I3RC_TWO_COMPONENTS_AT_ONCE 1
+#ifndef I3RC_CELL_RECORD_READS
+#define I3RC_CELL_RECORD_READS 1
 #endif
               // TWO components (cloud + gas, cloud + aerosol: the usual production domain): what the scattering needs of its cell comes as
               // ONE 16-byte record (DevProblem::cellRec) -- one cache line, one trip to L2 -- and the component's pair is picked when the
@@ -1248,25 +1248,25 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
               // for it.  (Asking the three arrays for both components' words at once -- five reads, five lines -- was measured: 9 - 15 %
               // SLOWER on the flux workloads; it is the lines that cost.  findIndex on (/0, c1, c2/) without a first guess answers 1 or 2,
               // never 3: see below.)
-              bool twoAtOnce = false;
-              float ssaTwo = 0.0f;
-              int pfiTwo = 0;
-              if (I3RC_TWO_COMPONENTS_AT_ONCE && (GENERAL || MULTI) && !REPLAY && multiComp && Pe.cellRec != nullptr) {
+              bool fromRecord = false;
+              float ssaRec = 0.0f;
+              int pfiRec = 0;
+              if (I3RC_CELL_RECORD_READS && (GENERAL || MULTI) && !REPLAY && multiComp && Pe.cellRec != nullptr) {
                 const float rc = rng.next();
                 if (Pe.ncomp == 2) {
                   const uint4 rec = Pe.cellRec[cell];
                   const float c0 = __uint_as_float(rec.x), s0 = __uint_as_float(rec.y), s1 = __uint_as_float(rec.z);
                   const int p0 = (int)(rec.w & 0xffffu), p1 = (int)(rec.w >> 16);
                   const bool second = rc >= c0;
-                  comp = second ? 2 : 1; ssaTwo = second ? s1 : s0; pfiTwo = second ? p1 : p0;
+                  comp = second ? 2 : 1; ssaRec = second ? s1 : s0; pfiRec = second ? p1 : p0;
                 } else {   // three components (droplets + aerosol + gas): 32 bytes of the same line
                   const uint4 a = Pe.cellRec[2 * (size_t)cell], b = Pe.cellRec[2 * (size_t)cell + 1];
                   const bool ge0 = rc >= __uint_as_float(a.x), ge1 = rc >= __uint_as_float(a.y);
                   comp = 1 + (ge0 ? 1 : 0) + (ge1 ? 1 : 0);
-                  ssaTwo = comp == 1 ? __uint_as_float(a.z) : (comp == 2 ? __uint_as_float(a.w) : __uint_as_float(b.x));
-                  pfiTwo = comp == 1 ? (int)(b.y & 0xffffu) : (comp == 2 ? (int)(b.y >> 16) : (int)b.z);
+                  ssaRec = comp == 1 ? __uint_as_float(a.z) : (comp == 2 ? __uint_as_float(a.w) : __uint_as_float(b.x));
+                  pfiRec = comp == 1 ? (int)(b.y & 0xffffu) : (comp == 2 ? (int)(b.y >> 16) : (int)b.z);
                 }
-                twoAtOnce = true;
+                fromRecord = true;
               } else
               if (multiComp || REPLAY) {
                 const float rc = rng.next();
@@ -1288,14 +1288,14 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
               // single-scattering albedo and phase-function entry of the cell; a value shared by the whole (one-component)
               // domain comes from the kernel arguments instead of two dependent memory reads
               float ssa;
-              if ((GENERAL || MULTI) && twoAtOnce) ssa = ssaTwo;
+              if ((GENERAL || MULTI) && fromRecord) ssa = ssaRec;
               else if (!GENERAL && !MULTI && Pe.uniformSsa >= 0.0f) ssa = Pe.uniformSsa;
-              else if (I3RC_TWO_COMPONENTS_AT_ONCE && !GENERAL && !MULTI && !REPLAY && Pe.cellRec != nullptr) {
+              else if (I3RC_CELL_RECORD_READS && !GENERAL && !MULTI && !REPLAY && Pe.cellRec != nullptr) {
                 // ONE component whose cells share neither albedo nor table entry (a Mie cloud: every cell its effective radius): the two as one
                 // 8-byte record (the same pointer: i3rc_hip_create makes the record that fits the domain, and only where NEITHER is shared, so
                 // that the kernels of the BASELINE workloads -- both shared -- never ask)
                 const uint2 rec = ((const uint2 *)Pe.cellRec)[cell];
-                ssa = __uint_as_float(rec.x); pfiTwo = (int)rec.y; twoAtOnce = true;
+                ssa = __uint_as_float(rec.x); pfiRec = (int)rec.y; fromRecord = true;
               }
               else ssa = Pe.ssa[(size_t)(comp - 1) * ncell + cell];
               if (ssa < 1.0f) {                                           // :642-649
@@ -1311,9 +1311,9 @@ __global__ void __launch_bounds__(TBL ? 1024 : 256, INTENSITY ? (GENERAL ? 3 : (
                 w = w * ssa;
               }
               int pfi;
-              if ((GENERAL || MULTI) && twoAtOnce) pfi = max(pfiTwo, 1);
+              if ((GENERAL || MULTI) && fromRecord) pfi = max(pfiRec, 1);
               else if (!GENERAL && !MULTI && Pe.uniformPf >= 1) pfi = Pe.uniformPf;
-              else if (!GENERAL && !MULTI && twoAtOnce) pfi = max(pfiTwo, 1);
+              else if (!GENERAL && !MULTI && fromRecord) pfi = max(pfiRec, 1);
               else pfi = max(Pe.pfIndex[(size_t)(comp - 1) * ncell + cell], 1);   // (index 0 marks clear cells: never a table offset of -1)
               if (defer) {                                                // :654-668: pushed after this event, traced in ray mode
                 pendingShadow = true; wI = w;
