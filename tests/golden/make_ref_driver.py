@@ -31,12 +31,16 @@ DECK = """&radiativeTransfer
 """
 CASES = {"stepcloud_mu1": dict(ssa="1.0", mu0="1.", albedo="0."), "stepcloud_mu05_absorbing": dict(ssa="0.99", mu0="0.5", albedo="0.2"),
          # BASELINE.json configs[2]'s reference-exact field: the radar cloud 640 x 1 x 54, flux + nadir radiance, 40 batches of 5e4 photons
-         "radar640_nadir": dict(ssa="1.0", mu0="1.", albedo="0.", radar=True, batches=40, photons=50000)}
+         "radar640_nadir": dict(ssa="1.0", mu0="1.", albedo="0.", radar=True, batches=40, photons=50000),
+         # BASELINE.json configs[3]: the Landsat scene re-binned to 36 layers, flux, sun at the zenith: 100 batches of 1e5 photons
+         "landsat36_flux": dict(ssa="1.0", mu0="1.", albedo="0.", landsat=36, batches=100, photons=100000, no_radiance=True)}
 
 
 def deck(case, dom, out):
     c = CASES[case]
     text = DECK.format(mu0=c["mu0"], albedo=c["albedo"], dom=dom, out=out)
+    if c.get("no_radiance"):
+        text = text.replace(", intensityMus = 1., intensityPhis = 0.", "")
     return text.replace("numPhotonsPerBatch = 100000, numBatches = 200", f"numPhotonsPerBatch = {c.get('photons', 100000)}, numBatches = {c.get('batches', 200)}")
 
 
@@ -45,6 +49,8 @@ def make_domain(case, dom, data_dir):
     c = CASES[case]
     if c.get("radar"):
         cmd = [os.path.join(BUILD, "makeRadarCloudDomain"), data_dir, dom, c["ssa"], "hg"]
+    elif c.get("landsat"):
+        cmd = [os.path.join(BUILD, "makeLandsatCloudDomain"), data_dir, dom, c["ssa"], str(c["landsat"])]
     else:
         cmd = [os.path.join(BUILD, "makeStepCloudDomain"), dom, "32", c["ssa"]]
     subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
