@@ -78,6 +78,8 @@ enum {
 typedef struct i3rc_tally_layout {
   int64_t fluxUp, fluxDown, fluxAbsorbed; /* offsets; nx*ny each                          (:135-136) */
   int64_t volumeAbsorption;               /* nx*ny*nz                                      (:137)     */
+  /* (fluxAbsorbed of a raw block is the sum of its column's volumeAbsorption words, formed on the device after every launch: the
+   *  reference adds one increment to both, :644-647, the kernels tally the cell) */
   int64_t intensityByComponent;           /* (ncomp+1)*nDir*nx*ny, component 0 = surface   (:139-140) */
   int64_t intensityExcess;                /* (ncomp+1)*nDir                                (:130)     */
   int64_t counters;                       /* I3RC_NUM_COUNTERS                                        */
