@@ -33,7 +33,12 @@ CASES = {"stepcloud_mu1": dict(ssa="1.0", mu0="1.", albedo="0."), "stepcloud_mu0
          # BASELINE.json configs[2]'s reference-exact field: the radar cloud 640 x 1 x 54, flux + nadir radiance, 40 batches of 5e4 photons
          "radar640_nadir": dict(ssa="1.0", mu0="1.", albedo="0.", radar=True, batches=40, photons=50000),
          # BASELINE.json configs[3]: the Landsat scene re-binned to 36 layers, flux, sun at the zenith: 100 batches of 1e5 photons
-         "landsat36_flux": dict(ssa="1.0", mu0="1.", albedo="0.", landsat=36, batches=100, photons=100000, no_radiance=True)}
+         "landsat36_flux": dict(ssa="1.0", mu0="1.", albedo="0.", landsat=36, batches=100, photons=100000, no_radiance=True),
+         # THE REFERENCE'S OWN EXAMPLE as it ships it (Example-Drivers/monteCarloDriver.nml): the three-component column its tool chain makes
+         # (Tools/Examples -> mixture.dom: tests/golden/tools_mixture.dom.gz), sun at 60 degrees, three radiance directions; 200 batches of
+         # 1e4 photons where the shipped deck runs 4
+         "example_mixture": dict(mu0="0.5", albedo="0.", fixture="tools_mixture.dom.gz", batches=200, photons=10000,
+                                 directions=("1., .5, .5", "0., 0., 180."))}
 
 
 def deck(case, dom, out):
@@ -41,12 +46,19 @@ def deck(case, dom, out):
     text = DECK.format(mu0=c["mu0"], albedo=c["albedo"], dom=dom, out=out)
     if c.get("no_radiance"):
         text = text.replace(", intensityMus = 1., intensityPhis = 0.", "")
+    if c.get("directions"):
+        text = text.replace("intensityMus = 1., intensityPhis = 0.", "intensityMus = %s, intensityPhis = %s" % c["directions"])
     return text.replace("numPhotonsPerBatch = 100000, numBatches = 200", f"numPhotonsPerBatch = {c.get('photons', 100000)}, numBatches = {c.get('batches', 200)}")
 
 
 def make_domain(case, dom, data_dir):
     """the case's domain file through the shell's generators (whose files are the reference generators' bit for bit: tests/test_fortran_shell.py)"""
     c = CASES[case]
+    if c.get("fixture"):
+        import gzip
+        with open(dom, "wb") as f:
+            f.write(gzip.decompress(open(os.path.join(HERE, c["fixture"]), "rb").read()))
+        return
     if c.get("radar"):
         cmd = [os.path.join(BUILD, "makeRadarCloudDomain"), data_dir, dom, c["ssa"], "hg"]
     elif c.get("landsat"):

@@ -599,13 +599,14 @@ def test_reference_tool_chain_domain_through_the_drivers_on_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["stepcloud_mu1", "stepcloud_mu05_absorbing", "radar640_nadir", "landsat36_flux"])
+@pytest.mark.parametrize("case", ["stepcloud_mu1", "stepcloud_mu05_absorbing", "radar640_nadir", "landsat36_flux", "example_mixture"])
 def test_the_shell_driver_on_gpu_against_the_whole_reference_column_by_column(tmp_path, case):
     """BASELINE.json's parity rule -- per column and domain mean |gpu - ref| <= 3 sqrt(se_gpu^2 + se_ref^2) -- against THE REFERENCE ITSELF:
     tests/golden/ref_driver_*.nc are the result files of the reference's own driver on the reference's own integrator and modules, all
     unmodified (oracle/_ref/ref_driver, tests/golden/make_ref_driver.py: the step cloud of the reference's generator, 200 batches of 1e5
     photons; sun at the zenith, conservative; sun at 60 degrees, omega = 0.99, albedo 0.2; and the radar cloud 640 x 1 x 54 of BASELINE.json configs[2] with its nadir radiance, 40 batches of
-    5e4; the Landsat scene in 36 layers of configs[3], 100 batches of 1e5, 16 384 columns), and the shell's driver runs the same decks on the device: fluxUp, fluxDown, fluxAbsorbed, the nadir radiance per column (Student-t allowance for 32 columns at 398 degrees of
+    5e4; the Landsat scene in 36 layers of configs[3], 100 batches of 1e5, 16 384 columns; and THE REFERENCE'S OWN EXAMPLE as shipped -- Example-Drivers/monteCarloDriver.nml on the
+    three-component column of Tools/Examples, three radiance directions, 200 batches of 1e4 where the deck has 4), and the shell's driver runs the same decks on the device: fluxUp, fluxDown, fluxAbsorbed, the nadir radiance per column (Student-t allowance for 32 columns at 398 degrees of
     freedom), the absorbed profile per layer and every domain mean."""
     import importlib.util
 
